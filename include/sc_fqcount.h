@@ -1,0 +1,171 @@
+/*
+ * sc_fqcount.h — C ABI of libsc_fqcount_hip.so, the MI355X (gfx950) drop-in for the
+ * `sc fq-count` hot path of danielecook/seq-collection.
+ *
+ * What this boundary replaces in the reference (all paths relative to the reference tree):
+ *   src/fq_count.nim:30-45   open stream (plain / ".gz"), per-line loop, i mod 4 classifier,
+ *                            count("G")+count("C"), count("N"), line.len accumulation
+ *   src/fq_count.nim:47-51   the five output fields and their `$` formatting
+ *   gzip_stream.nim:13-23    readData == zlib gzread (the host inflate semantics kept here)
+ * The reference has no FFI of its own for this path; the seam is the Nim proc
+ *   fq_count*(fastq: string, basename: bool, absolute: bool)          (src/fq_count.nim:14)
+ * A Nim host keeps that proc and calls scfq_count_file() + scfq_format_tsv() in place of
+ * lines :30-51 (binding shown in INTEGRATION.md and seq-collection_amd/nim/fq_count.nim).
+ *
+ * Plain C: pointers and sizes only, no C++ types, no exceptions cross this boundary, the
+ * library never calls exit() and never writes to stdout.
+ */
+#ifndef SC_FQCOUNT_H
+#define SC_FQCOUNT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCFQ_ABI_VERSION 1u
+
+/* ---- return codes (0 = success; negative = error) -------------------------------------- */
+#define SCFQ_OK       0
+#define SCFQ_EOPEN   (-1)  /* cannot open input: host maps to quit_error("Unable to open file: "&path, 2), src/fq_count.nim:35-36 */
+#define SCFQ_EGZ     (-2)  /* zlib reported a corrupt / truncated gzip stream */
+#define SCFQ_EHIP    (-3)  /* a HIP runtime call or kernel launch failed (no GPU, OOM, ...) */
+#define SCFQ_ERCCL   (-4)  /* collective exchange failed */
+#define SCFQ_EARG    (-5)  /* bad argument (NULL pointer, struct_size mismatch, bad flag) */
+#define SCFQ_EIO     (-6)  /* read error after a successful open */
+#define SCFQ_ENOMEM  (-7)  /* host allocation failed */
+
+/* ---- option flags ------------------------------------------------------------------------ */
+#define SCFQ_QUAL_HIST     0x1u  /* also build the 256-bin histogram of quality-line bytes (K3; not in reference) */
+#define SCFQ_STRUCT_CHECK  0x2u  /* also count header lines not starting '@' / separator lines not starting '+' (K4) */
+#define SCFQ_TIMING        0x4u  /* bracket the scan kernel with HIP events; read back with scfq_last_timing() */
+#define SCFQ_PREV_IN_MEMORY 0x8u /* scfq_partial_buffer: the byte before `ptr` is addressable and is the look-behind halo */
+
+/* ---- results: the counters of src/fq_count.nim:22-28 plus derivation inputs ------------- */
+typedef struct scfq_counts {
+  uint64_t struct_size;   /* caller sets to sizeof(scfq_counts) before the call */
+  uint64_t abi_version;   /* library writes SCFQ_ABI_VERSION */
+  uint64_t reads;         /* n_reads   = #{lines i : i mod 4 == 1}      fq_count.nim:40-41 */
+  uint64_t gc_bases;      /* gc_cnt    = count("G")+count("C") on i mod 4 == 2   :43 */
+  uint64_t n_bases;       /* n_cnt     = count("N")                              :44 */
+  uint64_t bases;         /* total_len = sum line.len (EOL stripped)             :45 */
+  uint64_t lines;         /* number of lines the reference's `lines(stream)` yields */
+  uint64_t newlines;      /* number of '\n' bytes */
+  uint64_t input_bytes;   /* bytes scanned (inflated bytes for .gz) */
+  uint64_t bad_at;        /* K4: header lines whose first byte is not '@'   (0 unless SCFQ_STRUCT_CHECK) */
+  uint64_t bad_plus;      /* K4: separator lines whose first byte is not '+' (0 unless SCFQ_STRUCT_CHECK) */
+  uint64_t qual_hist[256];/* K3: byte histogram of quality lines (i mod 4 == 0), EOL bytes excluded; zeros unless SCFQ_QUAL_HIST */
+} scfq_counts;
+
+typedef struct scfq_opts {
+  uint64_t struct_size;     /* sizeof(scfq_opts) */
+  int32_t  n_devices;       /* 0 = use the current / default device only; >0 = shard byte ranges across device_ids[0..n) */
+  const int32_t* device_ids;/* may be NULL when n_devices == 0 */
+  uint32_t flags;           /* SCFQ_* option flags */
+  uint32_t reserved;
+  uint64_t chunk_bytes;     /* host->device staging chunk for file / host-buffer ingest; 0 = default (64 MiB) */
+} scfq_opts;
+
+/*
+ * The shard partial: what a contiguous byte range contributes when its line
+ * phase at the first byte is unknown. Index r = (number of '\n' seen so far in THIS range) mod 4.
+ * Flat u64 so it can be exchanged with one collective (RCCL uint64 / torch int64).
+ *   combine  (A (+) B).nl = A.nl + B.nl ; (A (+) B).x[r] = A.x[r] + B.x[(r - A.nl) mod 4]
+ * Associative, NOT commutative. Fold in file order from the identity.
+ */
+#define SCFQ_PARTIAL_WORDS 32
+typedef struct scfq_partial {
+  uint64_t nl;            /* '\n' count in range */
+  uint64_t gc[4];         /* 'G'|'C' bytes per relative class */
+  uint64_t n[4];          /* 'N' bytes per relative class */
+  uint64_t len[4];        /* bytes that are not '\n' and not a '\r' directly before '\n' */
+  uint64_t starts[4];     /* K4: line-start events (first byte of a line lies in this range) */
+  uint64_t first_at[4];   /* K4: ... whose first byte is '@' */
+  uint64_t first_plus[4]; /* K4: ... whose first byte is '+' */
+  uint64_t bytes;         /* bytes covered */
+  uint64_t last_byte;     /* value of the last byte covered (undefined when bytes == 0) */
+  uint64_t reserved[5];
+} scfq_partial;
+
+#define SCFQ_HIST_WORDS (4 * 256)  /* optional K3 side array: uint64_t hist[4][256], class-major */
+
+typedef struct scfq_timing {
+  uint64_t struct_size;
+  double scan_kernel_ms;  /* device time of the last scan launch(es) on the library stream (HIP events) */
+  double fold_kernel_ms;  /* device time of the partial fold */
+  uint64_t scan_bytes;    /* bytes those scan launches covered */
+  uint64_t scan_launches;
+} scfq_timing;
+
+/* ---- whole-input entry points (what a host binds) ---------------------------------------- */
+
+/* Opens `path`; last three bytes ".gz" (case-sensitive, src/fq_count.nim:31) selects host zlib
+ * inflate (gzread semantics incl. concatenated members, gzip_stream.nim:16-17) overlapped with
+ * device scans via pinned buffers on a copy stream; otherwise plain pread. */
+int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out);
+
+/* Counts an in-memory FASTQ image. is_device != 0: `ptr` is a device pointer on the current
+ * device (bytes already resident in HBM: the roofline configuration). */
+int scfq_count_buffer(const void* ptr, uint64_t n, int is_device, const scfq_opts* opts, scfq_counts* out);
+
+/* ---- shard-level entry points (multi-GPU / streaming hosts, tests of shard boundaries) --- */
+
+/* Partial of one contiguous byte range. prev_byte: the byte immediately before the range in the
+ * file (0..255), or -1 when the range starts the file. Needed because a '\r' directly before a
+ * '\n' is not part of the line (look-behind halo of 1 byte). With SCFQ_PREV_IN_MEMORY set in
+ * opts->flags prev_byte is ignored and ptr[-1] is read instead.
+ * hist: NULL, or uint64_t[SCFQ_HIST_WORDS] (written only when SCFQ_QUAL_HIST is set). */
+int scfq_partial_buffer(const void* ptr, uint64_t n, int is_device, int prev_byte,
+                        const scfq_opts* opts, scfq_partial* out, uint64_t* hist);
+
+void scfq_partial_identity(scfq_partial* p, uint64_t* hist);
+/* acc = acc (+) b   (hist arrays may be NULL) */
+int  scfq_partial_combine(scfq_partial* acc, const scfq_partial* b, uint64_t* hist_acc, const uint64_t* hist_b);
+/* Interpret a partial folded from the start of the file: select the sequence class, derive
+ * lines and reads (ceil(lines/4), src/fq_count.nim:39-41). */
+int  scfq_partial_finalize(const scfq_partial* p, const uint64_t* hist, scfq_counts* out);
+
+/* ---- formatting: src/fq_count.nim:47-51 ---------------------------------------------------
+ * "<reads>\t<gc_content>\t<gc_bases>\t<n_bases>\t<bases>" without trailing newline;
+ * gc_content = gc/(bases-n) as IEEE double printed the way Nim 1.0.6 `$float` does: C "%.16g",
+ * then ".0" appended when the text has no '.', no letter; NaN prints "nan".
+ * Returns the number of bytes needed (excluding NUL); writes at most cap bytes incl. NUL. */
+int scfq_format_tsv(const scfq_counts* c, char* buf, uint64_t cap);
+
+const char* scfq_strerror(int rc);   /* static storage */
+const char* scfq_last_error_detail(void); /* static, thread-local: e.g. the failing HIP call */
+int  scfq_last_timing(scfq_timing* t);
+int  scfq_device_count(void);        /* number of visible HIP devices, or negative on error */
+int  scfq_shutdown(void);            /* frees streams, pinned and device scratch; safe to call twice */
+
+/* Diagnostic only (used by the parity tests as a second, independent device implementation):
+ * byte-serial HIP kernel, one thread per 256 bytes. Never called by the counting entry points. */
+int  scfq_debug_partial_simple(const void* device_ptr, uint64_t n, int prev_byte, scfq_partial* out);
+
+/* ---- synthetic workloads of SURVEY.md §8(d) / BASELINE.json configs ------------------------
+ * Counter-based generator: record i of a workload is a pure function of (seed, i), so host and
+ * device produce identical bytes and any shard can be produced independently.
+ * kind: 0 = Illumina 150 bp (config 2/3), 1 = Nanopore-style 500 bp..50 kb (config 5). */
+#define SCFQ_SYNTH_ILLUMINA 0
+#define SCFQ_SYNTH_NANOPORE 1
+typedef struct scfq_synth_info {
+  uint64_t struct_size;
+  uint64_t records;      /* records generated */
+  uint64_t bytes;        /* exact byte length of those records */
+  uint64_t gc_bases, n_bases, bases;  /* tallied by the generator itself, independent of the scan */
+} scfq_synth_info;
+
+/* Smallest record count whose total length is >= min_bytes (and its exact length). */
+int scfq_synth_plan(int kind, uint64_t seed, uint64_t first_record, uint64_t min_bytes, scfq_synth_info* info);
+/* Generate records [first_record, first_record+records) into host memory (cap >= info->bytes). */
+int scfq_synth_host(int kind, uint64_t seed, uint64_t first_record, uint64_t records,
+                    void* dst, uint64_t cap, scfq_synth_info* info);
+/* Same bytes, produced by a HIP kernel directly in HBM (dst is a device pointer). */
+int scfq_synth_device(int kind, uint64_t seed, uint64_t first_record, uint64_t records,
+                      void* dst_device, uint64_t cap, scfq_synth_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_FQCOUNT_H */

@@ -1,0 +1,567 @@
+// fq_scan_kernels.hpp — hand-written gfx950 (CDNA4, wave64) kernels for the `sc fq-count` hot path.
+//
+// Replaces the per-line loop of the reference (src/fq_count.nim:38-45: `for line in lines(stream)`,
+// `i mod 4` classifier, count("G")+count("C"), count("N"), line.len) by a phase-agnostic byte-stream
+// reduction: every byte is read from HBM exactly once and attributed to the class
+// r = (number of '\n' before it in the scanned range) mod 4; which r is the sequence line is only
+// decided by the ordered fold of the per-range partials (K2).
+//
+// K1 fq_scan_tiles : one wave = one contiguous "range" of 4 KiB tiles. Tiles are streamed
+//      HBM -> LDS with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB coalesced per
+//      instruction, 4 per tile, a 3-slot ring per wave => 8 KiB in flight per wave, no VGPR
+//      staging, no barriers: a wave only ever reads LDS bytes it loaded itself).  Each lane then
+//      owns 64 contiguous bytes of the tile (4 x ds_read_b128), turns them into three 64-bit
+//      match masks ('\n', G|C, N) with byte-transposed SWAR compares, gets its line phase from a
+//      DPP wave prefix-sum of newline counts, and adds per-segment popcounts into 8-bit packed
+//      per-class fields (4 classes in one VGPR; the class index is a shift amount, never a
+//      register index).  No MFMA: this is an HBM-bound byte reduction.
+// K2 fq_fold_partials : ordered (non-commutative) fold of the per-range partials.
+//
+// Byte semantics follow Nim 1.0.6 readLine as used by the reference: '\n' ends a line, a '\r'
+// directly before that '\n' is not part of the line; G/C/N are case-sensitive (fq_count.nim:43-44).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scfq {
+
+constexpr int kTile = 4096;          // bytes per wave-iteration (64 lanes x 64 B)
+constexpr int kWavesPerBlock = 4;
+constexpr int kRing = 3;             // LDS ring slots per wave (1 consumed + 2 in flight)
+constexpr int kPartialWords = 32;    // == SCFQ_PARTIAL_WORDS
+constexpr uint32_t kMaxTilesPerRange = 960;  // 16-bit per-lane class fields: 64 B/tile * 960 < 65536
+
+// word offsets inside a partial (scfq_partial layout, include/sc_fqcount.h)
+enum : int { W_NL = 0, W_GC = 1, W_N = 5, W_LEN = 9, W_STARTS = 13, W_FAT = 17, W_FPLUS = 21, W_BYTES = 25, W_LAST = 26 };
+
+constexpr uint32_t F_QUAL_HIST = 1u, F_STRUCT = 2u;
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane helpers (wave64, DPP)
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+  // v + (v moved by DPP control CTRL); lanes without a source add 0
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (Kogge-Stone in rows of 16, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  v = wave_inclusive_scan(v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// value of lane-1 (lane 0 receives `lane0`), one DPP move
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA tile loads.  Issued from inline asm on purpose: hipcc (ROCm 7.2) drains vmcnt(0) before
+// any ds_read while a builtin LDS-DMA is pending, which would serialise the ring; as asm the
+// loads are invisible to its bookkeeping and are retired by our own counted s_waitcnt vmcnt(N).
+// The leading lgkmcnt(0) retires this wave's earlier ds_reads of the slot being overwritten.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds_tile(const uint8_t* lane_src, uint32_t lds_slot_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_src), "s"(lds_slot_addr)
+      : "memory");
+}
+
+// edge tiles: every piece has its own (clamped) source address; still exactly 4 VMEM ops
+__device__ __forceinline__ void glds_tile_edge(const uint8_t* s0, const uint8_t* s1, const uint8_t* s2,
+                                               const uint8_t* s3, uint32_t lds_slot_addr) {
+  uint32_t keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %3, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %4, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "s"(lds_slot_addr)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// symbol masks: 64 bytes (16 dwords, memory order) -> three 64-bit masks, bit k <=> byte k
+// ------------------------------------------------------------------------------------------------
+// byte b != 0 -> bit 7 of that byte set.  ASCII form needs every byte of t <= 0x7F.
+template <bool ASCII>
+__device__ __forceinline__ uint32_t nonzero_bit7(uint32_t t) {
+  if (ASCII) return t + 0x7F7F7F7Fu;
+  return (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t);
+}
+
+// 4x4 byte transpose with v_perm_b32: in a,b,c,e (4 dwords) -> o[j] = {a.j, b.j, c.j, e.j}
+__device__ __forceinline__ void transpose4x4(uint32_t a, uint32_t b, uint32_t c, uint32_t e, uint32_t* o) {
+  uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+  uint32_t t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+  uint32_t t2 = __builtin_amdgcn_perm(e, c, 0x05010400u);  // c0 e0 c1 e1
+  uint32_t t3 = __builtin_amdgcn_perm(e, c, 0x07030602u);  // c2 e2 c3 e3
+  o[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+  o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+  o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+// 32 bytes (8 dwords) -> 32-bit NON-match words for '\n', G|C, 'N' (and optionally '@', '+').
+// After the transpose dword j holds the bytes at positions j, 8+j, 16+j, 24+j, so the bit-7
+// flags of dword j land on mask bits j, 8+j, 16+j, 24+j with one shift + one and_or.
+template <bool ASCII, bool STRUCT>
+__device__ __forceinline__ void masks32(const uint32_t* d, uint32_t& nl, uint32_t& gc, uint32_t& nn,
+                                        uint32_t& at, uint32_t& pl) {
+  uint32_t x[8];
+  transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
+  transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
+  uint32_t wnl = 0, wgc = 0, wnn = 0, wat = 0, wpl = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t sel = 0x01010101u << j;
+    const uint32_t v = x[j];
+    uint32_t e;
+    e = nonzero_bit7<ASCII>(v ^ 0x0A0A0A0Au);
+    wnl = ((e >> (7 - j)) & sel) | wnl;
+    e = nonzero_bit7<ASCII>((v & 0xFBFBFBFBu) ^ 0x43434343u);  // (b & 0xFB) == 0x43  <=>  b in {'C','G'}
+    wgc = ((e >> (7 - j)) & sel) | wgc;
+    e = nonzero_bit7<ASCII>(v ^ 0x4E4E4E4Eu);
+    wnn = ((e >> (7 - j)) & sel) | wnn;
+    if (STRUCT) {
+      e = nonzero_bit7<ASCII>(v ^ 0x40404040u);
+      wat = ((e >> (7 - j)) & sel) | wat;
+      e = nonzero_bit7<ASCII>(v ^ 0x2B2B2B2Bu);
+      wpl = ((e >> (7 - j)) & sel) | wpl;
+    }
+  }
+  nl = ~wnl; gc = ~wgc; nn = ~wnn; at = ~wat; pl = ~wpl;
+}
+
+struct Masks {
+  uint64_t nl, gc, nn, at, pl;
+};
+
+template <bool ASCII, bool STRUCT>
+__device__ __forceinline__ Masks masks64(const uint32_t* d) {
+  uint32_t a[5], b[5];
+  masks32<ASCII, STRUCT>(d, a[0], a[1], a[2], a[3], a[4]);
+  masks32<ASCII, STRUCT>(d + 8, b[0], b[1], b[2], b[3], b[4]);
+  Masks m;
+  m.nl = (uint64_t)a[0] | ((uint64_t)b[0] << 32);
+  m.gc = (uint64_t)a[1] | ((uint64_t)b[1] << 32);
+  m.nn = (uint64_t)a[2] | ((uint64_t)b[2] << 32);
+  m.at = (uint64_t)a[3] | ((uint64_t)b[3] << 32);
+  m.pl = (uint64_t)a[4] | ((uint64_t)b[4] << 32);
+  return m;
+}
+
+__device__ __forceinline__ uint32_t popc64(uint64_t v) { return (uint32_t)__popcll(v); }
+
+// per-lane accumulators: 16-bit fields, [0] holds classes 0 (bits 0..15) and 2 (bits 16..31),
+// [1] holds classes 1 and 3.  Fed once per tile from 8-bit x 4-class tile fields.
+struct Acc16 {
+  uint32_t e, o;
+  __device__ __forceinline__ void add_tile8(uint32_t t8) {
+    e += t8 & 0x00FF00FFu;
+    o += (t8 >> 8) & 0x00FF00FFu;
+  }
+};
+
+struct WaveState {
+  Acc16 gc, nn, len, crlf, starts, fat, fplus;
+  uint32_t phase;      // wave-uniform: newlines seen so far in this range, mod 4
+  uint32_t nl_total;   // wave-uniform: newlines seen so far in this range
+  int32_t prev_last;   // wave-uniform: byte before the next tile (-1: none / start of input)
+};
+
+// ------------------------------------------------------------------------------------------------
+// one 4 KiB tile, already resident in this wave's LDS slot
+//   EDGE   : tile is not entirely inside [B, E): per-lane valid mask V applies
+//   STRUCT : K4 line-start checks ('@' / '+')
+//   HIST   : K3 byte histogram per class into this wave's LDS histogram
+// ------------------------------------------------------------------------------------------------
+template <bool EDGE, bool STRUCT, bool HIST>
+__device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint64_t V, int64_t first_valid_pos,
+                                             int32_t prev_byte_param, WaveState& st, uint32_t* hist_lds) {
+  const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
+  const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+  uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                    q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+
+  uint32_t hb = (d[0] | d[1] | d[2]) | (d[3] | d[4] | d[5]) | (d[6] | d[7] | d[8]) |
+                (d[9] | d[10] | d[11]) | (d[12] | d[13] | d[14]) | d[15];
+  Masks m;
+  if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0)
+    m = masks64<true, STRUCT>(d);     // all 4096 bytes < 0x80: carry-free 1-op zero test
+  else
+    m = masks64<false, STRUCT>(d);    // exact form for arbitrary bytes
+
+  uint64_t NL = m.nl, GC = m.gc, NN = m.nn, VR = ~0ull;
+  if (EDGE) { NL &= V; GC &= V; NN &= V; VR = V; }
+
+  // line phase of this lane's first byte: wave prefix sum of newline counts
+  const uint32_t cnt = popc64(NL);
+  const uint32_t incl = wave_inclusive_scan(cnt);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t sh = ((st.phase + incl - cnt) & 3u) * 8u;   // shift of this lane's current class field
+
+  uint64_t LS = 0;
+  if (STRUCT) {
+    // line-start bytes: the byte after a '\n' (previous lane's / previous tile's last byte for bit 0)
+    uint32_t last_is_nl = (uint32_t)(NL >> 63);
+    uint32_t carry0 = (st.prev_last == '\n' || st.prev_last == -1) ? 1u : 0u;
+    uint32_t carry = wave_shr1(last_is_nl, carry0);
+    if (EDGE) {
+      // the valid region may start inside this tile: its first valid byte starts a line iff the
+      // caller's prev byte says so; bytes before it do not exist
+      LS = (NL << 1);
+      int64_t fv = first_valid_pos - (int64_t)lane * 64;   // lane-local index of first valid byte of the input
+      if (fv >= 0 && fv < 64) {
+        uint64_t bit = 1ull << fv;
+        bool starts = (prev_byte_param == '\n' || prev_byte_param == -1);
+        LS = (LS & ~bit) | (starts ? bit : 0);
+      } else if (first_valid_pos < (int64_t)lane * 64) {
+        LS |= carry;
+      }
+      LS &= V;
+    } else {
+      LS = (NL << 1) | carry;
+    }
+  }
+
+  uint32_t t_gc = 0, t_nn = 0, t_len = 0, t_crlf = 0, t_st = 0, t_fat = 0, t_fpl = 0;
+  const int lane_base = lane * 64;
+  uint64_t x = NL;
+  for (;;) {
+    const uint64_t xm1 = x - 1;
+    const uint64_t below = ~x & xm1;     // bits strictly below the first remaining newline (all if none)
+    const uint64_t upto = x ^ xm1;       // ... plus the newline itself
+    const bool has_nl = (x != 0);
+    const uint64_t seg = below & VR;
+    t_len += popc64(seg) << sh;
+    t_gc += popc64(GC & below) << sh;
+    t_nn += popc64(NN & below) << sh;
+    if (STRUCT) {
+      const uint64_t ls = LS & below;
+      t_st += popc64(ls) << sh;
+      t_fat += popc64(ls & m.at) << sh;
+      t_fpl += popc64(ls & m.pl) << sh;
+    }
+    if (HIST) {
+      // K3 (opt-in): every non-newline byte of this segment into hist[class][byte]
+      uint64_t s = seg;
+      const uint32_t cls = sh >> 3;
+      while (s) {
+        const int k = __builtin_ctzll(s);
+        s &= s - 1;
+        const uint32_t byte = slot[lane_base + k];
+        atomicAdd(&hist_lds[cls * 256 + byte], 1u);
+      }
+    }
+    // the '\r' of a "\r\n" line end is not part of the line: look one byte behind the newline
+    const int q = (int)popc64(below);                 // lane-local index of the newline (64 if none)
+    int idx = lane_base + q - 1;
+    int pb = slot[idx < 0 ? 0 : idx];
+    if (idx < 0) pb = st.prev_last;
+    if (EDGE) { if ((int64_t)(lane_base + q) == first_valid_pos) pb = prev_byte_param; }
+    t_crlf += ((has_nl && pb == '\r') ? 1u : 0u) << sh;
+    if (HIST) { if (has_nl && pb == '\r') atomicAdd(&hist_lds[(sh >> 3) * 256 + '\r'], 0xFFFFFFFFu); }
+
+    GC &= ~upto; NN &= ~upto; VR &= ~upto; x &= ~upto;
+    if (STRUCT) LS &= ~upto;
+    sh = (sh + 8u) & 31u;
+    if (__builtin_amdgcn_ballot_w64(has_nl) == 0) break;   // every lane has consumed its last segment
+  }
+
+  st.gc.add_tile8(t_gc);
+  st.nn.add_tile8(t_nn);
+  st.len.add_tile8(t_len);
+  st.crlf.add_tile8(t_crlf);
+  if (STRUCT) { st.starts.add_tile8(t_st); st.fat.add_tile8(t_fat); st.fplus.add_tile8(t_fpl); }
+  st.phase = (st.phase + total) & 3u;
+  st.nl_total += total;
+  st.prev_last = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)d[15], 63) >> 24);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------
+struct ScanArgs {
+  const uint8_t* base;     // first byte of the range to scan (any alignment)
+  uint64_t n;              // bytes
+  int32_t prev_byte;       // byte before base[0]: 0..255, -1 = start of input, -2 = read base[-1]
+  uint32_t tiles_per_range;
+  uint64_t n_ranges;
+  uint64_t* partials;      // [n_ranges][kPartialWords]
+  uint32_t* hist_partials; // [n_ranges][4][256] u32, HIST only
+};
+
+template <bool STRUCT, bool HIST>
+__global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* ring = smem + wave * (kRing * kTile);
+  uint32_t* hist_lds = nullptr;
+  if (HIST) {
+    hist_lds = reinterpret_cast<uint32_t*>(smem + kWavesPerBlock * kRing * kTile) + wave * 1024;
+    for (int k = lane; k < 1024; k += 64) hist_lds[k] = 0;
+  }
+  const uint64_t range = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (range >= a.n_ranges) return;
+
+  const uint64_t B = (uint64_t)(uintptr_t)a.base, E = B + a.n;
+  const uint64_t A0 = B & ~(uint64_t)(kTile - 1);
+  const uint64_t NT = (E - A0 + kTile - 1) / kTile;
+  const uint64_t t_begin = range * a.tiles_per_range;
+  uint64_t t_end = t_begin + a.tiles_per_range;
+  if (t_end > NT) t_end = NT;
+
+  int32_t prev_param = a.prev_byte;
+  if (prev_param == -2) prev_param = a.base[-1];
+
+  WaveState st = {};
+  // byte before this range's first tile: from memory when it belongs to the input, else the caller's halo
+  st.prev_last = prev_param;
+  if (A0 + t_begin * kTile > B) st.prev_last = *reinterpret_cast<const uint8_t*>(A0 + t_begin * kTile - 1);
+
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;   // LDS byte address of slot 0 (wave-uniform)
+
+  auto issue = [&](uint64_t t, uint32_t slot) {
+    const uint64_t ts = A0 + t * kTile;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + slot * kTile));
+    if (ts >= B && ts + kTile <= E) {
+      glds_tile(reinterpret_cast<const uint8_t*>(ts + (uint64_t)lane * 16), dst);
+    } else {
+      // pieces with no valid byte are redirected to a 16 B piece that is certainly readable
+      const uint64_t safe = (B & ~15ull);
+      uint64_t s[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint64_t ps = ts + (uint64_t)k * 1024 + (uint64_t)lane * 16;
+        const bool ok = (ps + 16 > B) && (ps < E);
+        s[k] = (ok ? ps : safe) - (uint64_t)k * 1024;   // the instruction re-adds offset:k*1024
+      }
+      glds_tile_edge(reinterpret_cast<const uint8_t*>(s[0]), reinterpret_cast<const uint8_t*>(s[1]),
+                     reinterpret_cast<const uint8_t*>(s[2]), reinterpret_cast<const uint8_t*>(s[3]), dst);
+    }
+  };
+
+  // prologue: two tiles in flight
+  if (t_begin < t_end) issue(t_begin, 0);
+  if (t_begin + 1 < t_end) issue(t_begin + 1, 1);
+
+  uint32_t slot = 0;
+  for (uint64_t t = t_begin; t < t_end; ++t) {
+    const uint32_t s2 = (slot >= 1) ? slot - 1 : 2;      // (slot + 2) % 3
+    if (t + 2 < t_end) { issue(t + 2, s2); wait_vmcnt<8>(); }
+    else if (t + 1 < t_end) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+
+    const uint8_t* sl = ring + slot * kTile;
+    const uint64_t ts = A0 + t * kTile;
+    if (ts >= B && ts + kTile <= E) {
+      process_tile<false, STRUCT, HIST>(sl, lane, ~0ull, 0, prev_param, st, hist_lds);
+    } else {
+      // valid bytes of this lane: absolute [ts + 64*lane, +64) intersected with [B, E)
+      const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);
+      int64_t lo = (int64_t)B - ls, hi = (int64_t)E - ls;
+      lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
+      hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
+      const uint64_t mhi = (hi >= 64) ? ~0ull : ((1ull << hi) - 1);
+      const uint64_t mlo = (lo >= 64) ? ~0ull : ((1ull << lo) - 1);
+      const uint64_t V = mhi & ~mlo;
+      const int64_t first_valid = (B >= ts) ? (int64_t)(B - ts) : -1;   // tile-local position of input byte 0
+      process_tile<true, STRUCT, HIST>(sl, lane, V, first_valid, prev_param, st, hist_lds);
+    }
+    slot = (slot == 2) ? 0 : slot + 1;
+  }
+
+  // ---- range partial: reduce the per-lane 16-bit fields across the wave, lane 0 stores --------
+  uint64_t* out = a.partials + range * kPartialWords;
+  auto sum4 = [&](const Acc16& acc) {
+    const uint32_t c0 = wave_sum(acc.e & 0xFFFFu), c2 = wave_sum(acc.e >> 16);
+    const uint32_t c1 = wave_sum(acc.o & 0xFFFFu), c3 = wave_sum(acc.o >> 16);
+    return make_uint4(c0, c1, c2, c3);
+  };
+  auto store4 = [&](int w, uint64_t v0, uint64_t v1, uint64_t v2, uint64_t v3) {
+    if (lane == 0) { out[w + 0] = v0; out[w + 1] = v1; out[w + 2] = v2; out[w + 3] = v3; }
+  };
+  const uint4 gc4 = sum4(st.gc), nn4 = sum4(st.nn), len4 = sum4(st.len), cr4 = sum4(st.crlf);
+  store4(W_GC, gc4.x, gc4.y, gc4.z, gc4.w);
+  store4(W_N, nn4.x, nn4.y, nn4.z, nn4.w);
+  // len excludes the '\r' of "\r\n": u64 modular (may wrap when that '\r' lies in the previous range)
+  store4(W_LEN, (uint64_t)len4.x - cr4.x, (uint64_t)len4.y - cr4.y, (uint64_t)len4.z - cr4.z, (uint64_t)len4.w - cr4.w);
+  if (STRUCT) {
+    const uint4 s4 = sum4(st.starts), a4 = sum4(st.fat), p4 = sum4(st.fplus);
+    store4(W_STARTS, s4.x, s4.y, s4.z, s4.w);
+    store4(W_FAT, a4.x, a4.y, a4.z, a4.w);
+    store4(W_FPLUS, p4.x, p4.y, p4.z, p4.w);
+  } else {
+    store4(W_STARTS, 0, 0, 0, 0); store4(W_FAT, 0, 0, 0, 0); store4(W_FPLUS, 0, 0, 0, 0);
+  }
+  if (lane == 0) {
+    out[W_NL] = st.nl_total;
+    for (int k = W_BYTES; k < kPartialWords; ++k) out[k] = 0;
+  }
+  if (HIST) {
+    uint32_t* hp = a.hist_partials + range * 1024;
+    for (int k = lane; k < 1024; k += 64) hp[k] = hist_lds[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: ordered fold.  state = state (+) P_0 (+) P_1 (+) ... ; also records each range's starting
+// phase (for the histogram fold) and finishes bytes / last_byte.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void partial_combine(uint64_t* acc, const uint64_t* b) {
+  const uint32_t k = (uint32_t)acc[W_NL] & 3u;
+#pragma unroll
+  for (int arr = W_GC; arr < W_BYTES; arr += 4) {
+    uint64_t t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = acc[arr + r] + b[arr + ((r - k) & 3u)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[arr + r] = t[r];
+  }
+  acc[W_NL] += b[W_NL];
+}
+
+constexpr int kFoldThreads = 256;
+
+__global__ __launch_bounds__(kFoldThreads) void fq_fold_partials(const uint64_t* partials, uint64_t n_ranges,
+                                                                 uint64_t* state, uint8_t* range_phase,
+                                                                 const uint8_t* base, uint64_t n) {
+  __shared__ uint64_t sh[kFoldThreads][W_BYTES + 1];
+  const int tid = threadIdx.x;
+  const uint64_t per = (n_ranges + kFoldThreads - 1) / kFoldThreads;
+  uint64_t lo = (uint64_t)tid * per, hi = lo + per;
+  if (lo > n_ranges) lo = n_ranges;
+  if (hi > n_ranges) hi = n_ranges;
+  uint64_t acc[W_BYTES];
+#pragma unroll
+  for (int k = 0; k < W_BYTES; ++k) acc[k] = 0;
+  for (uint64_t r = lo; r < hi; ++r) {
+    uint64_t b[W_BYTES];
+    const uint64_t* src = partials + r * kPartialWords;
+#pragma unroll
+    for (int k = 0; k < W_BYTES; ++k) b[k] = src[k];
+    partial_combine(acc, b);
+  }
+#pragma unroll
+  for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = acc[k];
+  __syncthreads();
+  // ordered tree: element j absorbs element j+s (its right neighbour block)
+  for (int s = 1; s < kFoldThreads; s <<= 1) {
+    if ((tid & (2 * s - 1)) == 0) {
+      uint64_t a2[W_BYTES], b2[W_BYTES];
+#pragma unroll
+      for (int k = 0; k < W_BYTES; ++k) { a2[k] = sh[tid][k]; b2[k] = sh[tid + s][k]; }
+      partial_combine(a2, b2);
+#pragma unroll
+      for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = a2[k];
+    }
+    __syncthreads();
+  }
+  if (range_phase) {
+    // starting phase of every range = (state.nl + newlines of all earlier ranges) mod 4
+    // (second sequential pass by thread 0 over nl only when the histogram fold needs it)
+    if (tid == 0) {
+      uint32_t ph = (uint32_t)state[W_NL] & 3u;
+      for (uint64_t r = 0; r < n_ranges; ++r) {
+        range_phase[r] = (uint8_t)ph;
+        ph = (ph + (uint32_t)partials[r * kPartialWords + W_NL]) & 3u;
+      }
+    }
+  }
+  if (tid == 0) {
+    uint64_t a2[W_BYTES], b2[W_BYTES];
+#pragma unroll
+    for (int k = 0; k < W_BYTES; ++k) { a2[k] = state[k]; b2[k] = sh[0][k]; }
+    partial_combine(a2, b2);
+#pragma unroll
+    for (int k = 0; k < W_BYTES; ++k) state[k] = a2[k];
+    state[W_BYTES] += n;
+    if (n) state[W_LAST] = base[n - 1];
+  }
+}
+
+// K3 fold: state_hist[c][b] += sum_r hist_r[(c - phase_r) & 3][b]
+__global__ __launch_bounds__(256) void fq_fold_hist(const uint32_t* hist_partials, const uint8_t* range_phase,
+                                                    uint64_t n_ranges, uint64_t* state_hist) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1023 : c*256 + b
+  const uint32_t c = idx >> 8, b = idx & 255;
+  uint64_t acc = 0;
+  for (uint64_t r = 0; r < n_ranges; ++r) {
+    const uint32_t src = (c - range_phase[r]) & 3u;
+    // u32 partials are modular too (the "\r\n" take-back may wrap): sign-extend the wrap
+    acc += (uint64_t)(int64_t)(int32_t)hist_partials[r * 1024 + src * 256 + b];
+  }
+  state_hist[idx] += acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Diagnostic cross-check kernel (NOT the product path): one thread scans 256 bytes byte-serially
+// and emits its own partial; used by tests as an independent device implementation.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_scan_simple(const uint8_t* base, uint64_t n, int32_t prev_byte,
+                                                      uint64_t n_chunks, uint64_t* partials) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_chunks) return;
+  const uint64_t lo = c * 256, hi = (lo + 256 < n) ? lo + 256 : n;
+  uint64_t o[kPartialWords];
+  for (int k = 0; k < kPartialWords; ++k) o[k] = 0;
+  uint32_t r = 0;
+  int prev = (lo == 0) ? prev_byte : (int)base[lo - 1];
+  for (uint64_t k = lo; k < hi; ++k) {
+    const uint8_t b = base[k];
+    if (prev == -1 || prev == '\n') {
+      o[W_STARTS + r]++;
+      if (b == '@') o[W_FAT + r]++;
+      if (b == '+') o[W_FPLUS + r]++;
+    }
+    if (b == '\n') {
+      if (prev == '\r') o[W_LEN + r]--;
+      o[W_NL]++;
+      r = (r + 1) & 3u;
+    } else {
+      o[W_LEN + r]++;
+      if (b == 'G' || b == 'C') o[W_GC + r]++;
+      if (b == 'N') o[W_N + r]++;
+    }
+    prev = b;
+  }
+  uint64_t* out = partials + c * kPartialWords;
+  for (int k = 0; k < kPartialWords; ++k) out[k] = o[k];
+}
+
+}  // namespace scfq

@@ -1,0 +1,566 @@
+// scfq_api.hip — device side of the C ABI (include/sc_fqcount.h): per-device context, kernel
+// launches, host->HBM staging with copy/compute overlap, file and gzip ingest.
+//
+// Boundary replaced in the reference: src/fq_count.nim:30-45 (open stream, line loop, counters).
+// gzip input keeps the reference's inflate semantics (zlib gzread: gzip_stream.nim:16-17 — multi-member
+// streams, transparent pass-through of non-gzip bytes) but runs it on the host into pinned buffers that a
+// copy stream moves to HBM while the compute stream scans the previous chunk.
+//
+// There is NO CPU fallback in this library: without a HIP device every counting entry point returns
+// SCFQ_EHIP.
+#include "../../include/sc_fqcount.h"
+#include "fq_scan_kernels.hpp"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+#define HIPCHK(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      std::snprintf(g_err, sizeof g_err, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                    __FILE__, __LINE__);                                                      \
+      if (std::getenv("SCFQ_VERBOSE")) std::fprintf(stderr, "scfq: %s\n", g_err);             \
+      return SCFQ_EHIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+constexpr uint64_t kDefaultChunk = 64ull << 20;
+constexpr int kStateWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;
+
+struct Ctx {
+  int dev = -1;
+  int n_cu = 256;
+  hipStream_t compute = nullptr, copy = nullptr;
+  uint64_t* d_partials = nullptr;
+  uint64_t cap_ranges = 0;
+  uint32_t* d_hist_partials = nullptr;
+  uint8_t* d_range_phase = nullptr;
+  uint64_t cap_hist_ranges = 0;
+  uint64_t* d_state = nullptr;   // [32 partial words][1024 hist words]
+  uint64_t* h_state = nullptr;   // pinned mirror
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
+  // staging (host buffers / files)
+  uint8_t* d_stage[2] = {nullptr, nullptr};
+  uint8_t* h_pin[2] = {nullptr, nullptr};
+  uint64_t stage_cap = 0;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
+  scfq_timing timing{};
+};
+
+std::mutex g_mu;
+std::map<int, std::unique_ptr<Ctx>> g_ctx;
+thread_local scfq_timing g_last_timing{};
+
+int get_ctx(Ctx** out) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_ctx.find(dev);
+  if (it != g_ctx.end()) { *out = it->second.get(); return SCFQ_OK; }
+  auto c = std::make_unique<Ctx>();
+  c->dev = dev;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, dev));
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&c->d_state, kStateWords * sizeof(uint64_t)));
+  HIPCHK(hipHostMalloc(&c->h_state, kStateWords * sizeof(uint64_t), hipHostMallocDefault));
+  HIPCHK(hipEventCreate(&c->ev_t0));
+  HIPCHK(hipEventCreate(&c->ev_t1));
+  HIPCHK(hipEventCreate(&c->ev_t2));
+  for (int b = 0; b < 2; ++b) {
+    HIPCHK(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_scanned[b], hipEventDisableTiming));
+  }
+  *out = c.get();
+  g_ctx[dev] = std::move(c);
+  return SCFQ_OK;
+}
+
+int ensure_partials(Ctx* c, uint64_t n_ranges, bool hist) {
+  if (n_ranges > c->cap_ranges) {
+    HIPCHK(hipStreamSynchronize(c->compute));
+    if (c->d_partials) HIPCHK(hipFree(c->d_partials));
+    c->d_partials = nullptr;
+    uint64_t cap = std::max<uint64_t>(n_ranges + n_ranges / 4, 4096);
+    HIPCHK(hipMalloc(&c->d_partials, cap * scfq::kPartialWords * sizeof(uint64_t)));
+    c->cap_ranges = cap;
+  }
+  if (hist && n_ranges > c->cap_hist_ranges) {
+    HIPCHK(hipStreamSynchronize(c->compute));
+    if (c->d_hist_partials) HIPCHK(hipFree(c->d_hist_partials));
+    if (c->d_range_phase) HIPCHK(hipFree(c->d_range_phase));
+    c->d_hist_partials = nullptr;
+    c->d_range_phase = nullptr;
+    uint64_t cap = std::max<uint64_t>(n_ranges + n_ranges / 4, 4096);
+    HIPCHK(hipMalloc(&c->d_hist_partials, cap * 1024 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_range_phase, cap));
+    c->cap_hist_ranges = cap;
+  }
+  return SCFQ_OK;
+}
+
+int ensure_staging(Ctx* c, uint64_t chunk, bool pinned) {
+  if (chunk > c->stage_cap) {
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipStreamSynchronize(c->copy));
+    for (int b = 0; b < 2; ++b) {
+      if (c->d_stage[b]) HIPCHK(hipFree(c->d_stage[b]));
+      if (c->h_pin[b]) HIPCHK(hipHostFree(c->h_pin[b]));
+      c->d_stage[b] = nullptr;
+      c->h_pin[b] = nullptr;
+    }
+    c->stage_cap = 0;
+    for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc(&c->d_stage[b], chunk));
+    c->stage_cap = chunk;
+  }
+  if (pinned) {
+    for (int b = 0; b < 2; ++b)
+      if (!c->h_pin[b]) HIPCHK(hipHostMalloc(&c->h_pin[b], c->stage_cap, hipHostMallocDefault));
+  }
+  return SCFQ_OK;
+}
+
+uint32_t pick_tiles_per_range(const Ctx* c, uint64_t n_tiles) {
+  if (const char* e = std::getenv("SCFQ_TILES_PER_RANGE")) {
+    long v = std::atol(e);
+    if (v >= 1) return (uint32_t)std::min<long>(v, scfq::kMaxTilesPerRange);
+  }
+  // enough ranges that every CU sees many waves come and go (dynamic balance from block dispatch),
+  // few enough that the ordered fold stays negligible
+  const uint64_t target_ranges = (uint64_t)c->n_cu * 12 * 8;
+  uint64_t tpr = (n_tiles + target_ranges - 1) / target_ranges;
+  tpr = std::max<uint64_t>(tpr, 16);
+  tpr = std::min<uint64_t>(tpr, scfq::kMaxTilesPerRange);
+  return (uint32_t)tpr;
+}
+
+template <bool S, bool H>
+void launch_scan(const scfq::ScanArgs& a, unsigned blocks, unsigned lds, hipStream_t st) {
+  hipLaunchKernelGGL((scfq::fq_scan_tiles<S, H>), dim3(blocks), dim3(256), lds, st, a);
+}
+
+// Enqueue scan + fold of one device-resident range onto the compute stream. State accumulates.
+int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t flags, bool timing) {
+  if (n == 0) return SCFQ_OK;
+  const bool hist = flags & SCFQ_QUAL_HIST, strct = flags & SCFQ_STRUCT_CHECK;
+  const uint64_t B = (uint64_t)(uintptr_t)dptr, A0 = B & ~(uint64_t)(scfq::kTile - 1);
+  const uint64_t NT = (B + n - A0 + scfq::kTile - 1) / scfq::kTile;
+  const uint32_t tpr = pick_tiles_per_range(c, NT);
+  const uint64_t n_ranges = (NT + tpr - 1) / tpr;
+  int rc = ensure_partials(c, n_ranges, hist);
+  if (rc) return rc;
+  scfq::ScanArgs a;
+  a.base = dptr;
+  a.n = n;
+  a.prev_byte = prev_byte;
+  a.tiles_per_range = tpr;
+  a.n_ranges = n_ranges;
+  a.partials = c->d_partials;
+  a.hist_partials = c->d_hist_partials;
+  const unsigned blocks = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
+  unsigned lds = scfq::kWavesPerBlock * scfq::kRing * scfq::kTile;
+  if (hist) lds += scfq::kWavesPerBlock * 1024 * sizeof(uint32_t);
+  if (timing) HIPCHK(hipEventRecord(c->ev_t0, c->compute));
+  if (hist && strct) launch_scan<true, true>(a, blocks, lds, c->compute);
+  else if (hist) launch_scan<false, true>(a, blocks, lds, c->compute);
+  else if (strct) launch_scan<true, false>(a, blocks, lds, c->compute);
+  else launch_scan<false, false>(a, blocks, lds, c->compute);
+  HIPCHK(hipGetLastError());
+  if (timing) HIPCHK(hipEventRecord(c->ev_t1, c->compute));
+  hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_partials,
+                     n_ranges, c->d_state, hist ? c->d_range_phase : nullptr, dptr, n);
+  HIPCHK(hipGetLastError());
+  if (hist) {
+    hipLaunchKernelGGL(scfq::fq_fold_hist, dim3(4), dim3(256), 0, c->compute, c->d_hist_partials, c->d_range_phase,
+                       n_ranges, c->d_state + SCFQ_PARTIAL_WORDS);
+    HIPCHK(hipGetLastError());
+  }
+  if (timing) {
+    HIPCHK(hipEventRecord(c->ev_t2, c->compute));
+    HIPCHK(hipEventSynchronize(c->ev_t2));
+    float ms1 = 0, ms2 = 0;
+    HIPCHK(hipEventElapsedTime(&ms1, c->ev_t0, c->ev_t1));
+    HIPCHK(hipEventElapsedTime(&ms2, c->ev_t1, c->ev_t2));
+    c->timing.scan_kernel_ms += ms1;
+    c->timing.fold_kernel_ms += ms2;
+    c->timing.scan_bytes += n;
+    c->timing.scan_launches += 1;
+  }
+  return SCFQ_OK;
+}
+
+int begin_session(Ctx* c) {
+  c->timing = scfq_timing{};
+  c->timing.struct_size = sizeof(scfq_timing);
+  HIPCHK(hipMemsetAsync(c->d_state, 0, kStateWords * sizeof(uint64_t), c->compute));
+  return SCFQ_OK;
+}
+
+int end_session(Ctx* c, bool hist, scfq_partial* out, uint64_t* hist_out) {
+  const size_t words = hist ? kStateWords : SCFQ_PARTIAL_WORDS;
+  HIPCHK(hipMemcpyAsync(c->h_state, c->d_state, words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
+  HIPCHK(hipStreamSynchronize(c->compute));
+  std::memcpy(out, c->h_state, sizeof(scfq_partial));
+  if (hist && hist_out) std::memcpy(hist_out, c->h_state + SCFQ_PARTIAL_WORDS, SCFQ_HIST_WORDS * sizeof(uint64_t));
+  g_last_timing = c->timing;
+  return SCFQ_OK;
+}
+
+uint32_t opt_flags(const scfq_opts* o) { return o ? o->flags : 0u; }
+uint64_t opt_chunk(const scfq_opts* o) {
+  uint64_t ch = (o && o->chunk_bytes) ? o->chunk_bytes : kDefaultChunk;
+  ch = (ch + scfq::kTile - 1) & ~(uint64_t)(scfq::kTile - 1);
+  return std::max<uint64_t>(ch, scfq::kTile);
+}
+int check_opts(const scfq_opts* o) {
+  if (o && o->struct_size != sizeof(scfq_opts)) return SCFQ_EARG;
+  if (o && (o->flags & ~(SCFQ_QUAL_HIST | SCFQ_STRUCT_CHECK | SCFQ_TIMING | SCFQ_PREV_IN_MEMORY))) return SCFQ_EARG;
+  if (o && o->n_devices < 0) return SCFQ_EARG;
+  if (o && o->n_devices > 0 && !o->device_ids) return SCFQ_EARG;
+  return SCFQ_OK;
+}
+
+// A source of bytes for the chunked ingest loop: fills dst with up to cap bytes, returns count,
+// 0 at end, negative SCFQ_* on error.
+struct Source {
+  virtual ~Source() {}
+  virtual int64_t fill(uint8_t* dst, uint64_t cap) = 0;
+};
+
+struct MemSource : Source {
+  const uint8_t* p; uint64_t n, off = 0;
+  MemSource(const uint8_t* p_, uint64_t n_) : p(p_), n(n_) {}
+  int64_t fill(uint8_t* dst, uint64_t cap) override {
+    uint64_t k = std::min(cap, n - off);
+    std::memcpy(dst, p + off, k);
+    off += k;
+    return (int64_t)k;
+  }
+};
+
+struct FdSource : Source {
+  int fd; uint64_t off, end;
+  FdSource(int fd_, uint64_t off_, uint64_t end_) : fd(fd_), off(off_), end(end_) {}
+  int64_t fill(uint8_t* dst, uint64_t cap) override {
+    uint64_t want = std::min(cap, end - off), got = 0;
+    while (got < want) {
+      ssize_t r = pread(fd, dst + got, want - got, (off_t)(off + got));
+      if (r < 0) return SCFQ_EIO;
+      if (r == 0) break;
+      got += (uint64_t)r;
+    }
+    off += got;
+    return (int64_t)got;
+  }
+};
+
+struct GzSource : Source {
+  gzFile f;
+  explicit GzSource(gzFile f_) : f(f_) {}
+  int64_t fill(uint8_t* dst, uint64_t cap) override {
+    uint64_t got = 0;
+    while (got < cap) {
+      unsigned want = (unsigned)std::min<uint64_t>(cap - got, 1u << 30);
+      int r = gzread(f, dst + got, want);   // gzip_stream.nim:16-17 fsReadData == gzread
+      if (r < 0) return SCFQ_EGZ;
+      if (r == 0) break;
+      got += (unsigned)r;
+    }
+    return (int64_t)got;
+  }
+};
+
+// Chunked ingest with copy/compute overlap: the host thread fills pinned buffer b (pread / inflate)
+// while the copy stream moves buffer b^1 to HBM and the compute stream scans the chunk before it.
+int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, bool timing) {
+  int rc = ensure_staging(c, chunk, true);
+  if (rc) return rc;
+  int prev = prev_byte;
+  for (unsigned it = 0;; ++it) {
+    const int b = it & 1;
+    if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));   // pinned buffer b is free again
+    int64_t got = src.fill(c->h_pin[b], chunk);
+    if (got < 0) return (int)got;
+    if (got == 0) break;
+    if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));   // device buffer b consumed
+    HIPCHK(hipMemcpyAsync(c->d_stage[b], c->h_pin[b], (size_t)got, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
+    HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));
+    rc = scan_async(c, c->d_stage[b], (uint64_t)got, prev, flags & ~SCFQ_PREV_IN_MEMORY, timing);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_scanned[b], c->compute));
+    prev = c->h_pin[b][got - 1];
+    if ((uint64_t)got < chunk) {
+      // short fill: could still be followed by data for gz streams; loop again (fill returns 0 at end)
+    }
+  }
+  return SCFQ_OK;
+}
+
+int partial_on_current_device(const void* ptr, uint64_t n, int is_device, int prev_byte, const scfq_opts* opts,
+                              scfq_partial* out, uint64_t* hist) {
+  Ctx* c = nullptr;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  const uint32_t flags = opt_flags(opts);
+  const bool timing = flags & SCFQ_TIMING;
+  rc = begin_session(c);
+  if (rc) return rc;
+  if (is_device) {
+    const int prev = (flags & SCFQ_PREV_IN_MEMORY) ? -2 : prev_byte;
+    rc = scan_async(c, static_cast<const uint8_t*>(ptr), n, prev, flags, timing);
+  } else {
+    int prev = prev_byte;
+    if (flags & SCFQ_PREV_IN_MEMORY) prev = static_cast<const uint8_t*>(ptr)[-1];
+    MemSource src(static_cast<const uint8_t*>(ptr), n);
+    rc = ingest(c, src, prev, flags, std::min<uint64_t>(opt_chunk(opts), std::max<uint64_t>((n + 4095) & ~4095ull, 4096)), timing);
+  }
+  if (rc) return rc;
+  return end_session(c, flags & SCFQ_QUAL_HIST, out, hist);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* scfq_last_error_detail(void) { return g_err; }
+
+int scfq_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    std::snprintf(g_err, sizeof g_err, "hipGetDeviceCount -> %s", hipGetErrorString(e));
+    return SCFQ_EHIP;
+  }
+  return n;
+}
+
+int scfq_last_timing(scfq_timing* t) {
+  if (!t || t->struct_size != sizeof(scfq_timing)) return SCFQ_EARG;
+  *t = g_last_timing;
+  t->struct_size = sizeof(scfq_timing);
+  return SCFQ_OK;
+}
+
+int scfq_partial_buffer(const void* ptr, uint64_t n, int is_device, int prev_byte, const scfq_opts* opts,
+                        scfq_partial* out, uint64_t* hist) {
+  if (!out || (!ptr && n)) return SCFQ_EARG;
+  if (prev_byte < -1 || prev_byte > 255) return SCFQ_EARG;
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  return partial_on_current_device(ptr, n, is_device, prev_byte, opts, out, hist);
+}
+
+int scfq_count_buffer(const void* ptr, uint64_t n, int is_device, const scfq_opts* opts, scfq_counts* out) {
+  if (!out || out->struct_size != sizeof(scfq_counts) || (!ptr && n)) return SCFQ_EARG;
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  scfq_opts o{};
+  if (opts) o = *opts;
+  o.struct_size = sizeof(o);
+  o.flags &= ~SCFQ_PREV_IN_MEMORY;
+  const bool want_hist = o.flags & SCFQ_QUAL_HIST;
+  std::vector<uint64_t> hist(want_hist ? SCFQ_HIST_WORDS : 0);
+  scfq_partial p;
+  if (!is_device && o.n_devices > 1 && n >= (uint64_t)o.n_devices * scfq::kTile) {
+    // byte-range shards, one per device, arbitrary (unaligned) cut points; ordered host fold
+    const int nd = o.n_devices;
+    std::vector<scfq_partial> parts(nd);
+    std::vector<std::vector<uint64_t>> hists(nd, std::vector<uint64_t>(want_hist ? SCFQ_HIST_WORDS : 0));
+    std::vector<int> rcs(nd, 0);
+    std::vector<std::thread> th;
+    const uint8_t* base = static_cast<const uint8_t*>(ptr);
+    for (int d = 0; d < nd; ++d) {
+      th.emplace_back([&, d] {
+        if (hipSetDevice(o.device_ids[d]) != hipSuccess) { rcs[d] = SCFQ_EHIP; return; }
+        const uint64_t lo = n * (uint64_t)d / nd, hi = n * (uint64_t)(d + 1) / nd;
+        scfq_opts od = o;
+        od.n_devices = 0;
+        rcs[d] = partial_on_current_device(base + lo, hi - lo, 0, lo ? base[lo - 1] : -1, &od, &parts[d],
+                                           want_hist ? hists[d].data() : nullptr);
+      });
+    }
+    for (auto& t : th) t.join();
+    for (int d = 0; d < nd; ++d) if (rcs[d]) return rcs[d];
+    scfq_partial_identity(&p, want_hist ? hist.data() : nullptr);
+    for (int d = 0; d < nd; ++d)
+      scfq_partial_combine(&p, &parts[d], want_hist ? hist.data() : nullptr, want_hist ? hists[d].data() : nullptr);
+  } else {
+    if (!is_device && o.n_devices >= 1) HIPCHK(hipSetDevice(o.device_ids[0]));
+    rc = partial_on_current_device(ptr, n, is_device, -1, &o, &p, want_hist ? hist.data() : nullptr);
+    if (rc) return rc;
+  }
+  return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+}
+
+int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
+  if (!path || !out || out->struct_size != sizeof(scfq_counts)) return SCFQ_EARG;
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  scfq_opts o{};
+  if (opts) o = *opts;
+  o.struct_size = sizeof(o);
+  o.flags &= ~SCFQ_PREV_IN_MEMORY;
+  const bool want_hist = o.flags & SCFQ_QUAL_HIST;
+  const bool timing = o.flags & SCFQ_TIMING;
+  std::vector<uint64_t> hist(want_hist ? SCFQ_HIST_WORDS : 0);
+  scfq_partial p;
+  const size_t plen = std::strlen(path);
+  // fastq[^3 .. ^1] == ".gz"      src/fq_count.nim:31 (case-sensitive, last three bytes)
+  const bool is_gz = plen >= 3 && std::memcmp(path + plen - 3, ".gz", 3) == 0;
+  if (is_gz) {
+    gzFile f = gzopen(path, "rb");
+    if (!f) return SCFQ_EOPEN;
+    gzbuffer(f, 1u << 20);
+    if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { gzclose(f); return SCFQ_EHIP; }
+    Ctx* c = nullptr;
+    rc = get_ctx(&c);
+    if (!rc) rc = begin_session(c);
+    if (!rc) {
+      GzSource src(f);
+      rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
+    }
+    gzclose(f);
+    if (rc) return rc;
+    rc = end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
+    if (rc) return rc;
+    return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+  }
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return SCFQ_EOPEN;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || S_ISDIR(sb.st_mode)) { close(fd); return SCFQ_EOPEN; }
+  const bool regular = S_ISREG(sb.st_mode);
+  const uint64_t size = regular ? (uint64_t)sb.st_size : 0;
+  const int nd = (regular && o.n_devices > 1 && size >= (uint64_t)o.n_devices * (1u << 20)) ? o.n_devices : 1;
+  if (nd > 1) {
+    std::vector<scfq_partial> parts(nd);
+    std::vector<std::vector<uint64_t>> hists(nd, std::vector<uint64_t>(want_hist ? SCFQ_HIST_WORDS : 0));
+    std::vector<int> rcs(nd, 0);
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd; ++d) {
+      th.emplace_back([&, d] {
+        if (hipSetDevice(o.device_ids[d]) != hipSuccess) { rcs[d] = SCFQ_EHIP; return; }
+        const uint64_t lo = size * (uint64_t)d / nd, hi = size * (uint64_t)(d + 1) / nd;
+        int prev = -1;
+        if (lo) { uint8_t pb; if (pread(fd, &pb, 1, (off_t)(lo - 1)) != 1) { rcs[d] = SCFQ_EIO; return; } prev = pb; }
+        Ctx* c = nullptr;
+        int r = get_ctx(&c);
+        if (!r) r = begin_session(c);
+        if (!r) { FdSource src(fd, lo, hi); r = ingest(c, src, prev, o.flags, opt_chunk(&o), timing); }
+        if (!r) r = end_session(c, want_hist, &parts[d], want_hist ? hists[d].data() : nullptr);
+        rcs[d] = r;
+      });
+    }
+    for (auto& t : th) t.join();
+    close(fd);
+    for (int d = 0; d < nd; ++d) if (rcs[d]) return rcs[d];
+    scfq_partial_identity(&p, want_hist ? hist.data() : nullptr);
+    for (int d = 0; d < nd; ++d)
+      scfq_partial_combine(&p, &parts[d], want_hist ? hist.data() : nullptr, want_hist ? hists[d].data() : nullptr);
+    return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+  }
+  if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { close(fd); return SCFQ_EHIP; }
+  Ctx* c = nullptr;
+  rc = get_ctx(&c);
+  if (!rc) rc = begin_session(c);
+  if (!rc) {
+    if (regular) {
+      FdSource src(fd, 0, size);
+      rc = ingest(c, src, -1, o.flags, std::min<uint64_t>(opt_chunk(&o), std::max<uint64_t>((size + 4095) & ~4095ull, 4096)), timing);
+    } else {
+      // FIFO / character device: sequential read()
+      struct SeqSource : Source {
+        int fd;
+        explicit SeqSource(int f) : fd(f) {}
+        int64_t fill(uint8_t* dst, uint64_t cap) override {
+          uint64_t got = 0;
+          while (got < cap) {
+            ssize_t r = read(fd, dst + got, cap - got);
+            if (r < 0) return SCFQ_EIO;
+            if (r == 0) break;
+            got += (uint64_t)r;
+          }
+          return (int64_t)got;
+        }
+      } src(fd);
+      rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
+    }
+  }
+  close(fd);
+  if (rc) return rc;
+  rc = end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
+  if (rc) return rc;
+  return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+}
+
+int scfq_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_ctx) {
+    Ctx* c = kv.second.get();
+    (void)hipSetDevice(c->dev);
+    if (c->compute) (void)hipStreamSynchronize(c->compute);
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
+    for (int b = 0; b < 2; ++b) {
+      if (c->d_stage[b]) (void)hipFree(c->d_stage[b]);
+      if (c->h_pin[b]) (void)hipHostFree(c->h_pin[b]);
+      if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
+      if (c->ev_scanned[b]) (void)hipEventDestroy(c->ev_scanned[b]);
+    }
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_hist_partials) (void)hipFree(c->d_hist_partials);
+    if (c->d_range_phase) (void)hipFree(c->d_range_phase);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->ev_t2) (void)hipEventDestroy(c->ev_t2);
+    if (c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
+  }
+  g_ctx.clear();
+  return SCFQ_OK;
+}
+
+// ---- diagnostic: independent byte-serial device kernel (tests only; not used by any counting path) ----
+int scfq_debug_partial_simple(const void* dptr, uint64_t n, int prev_byte, scfq_partial* out) {
+  if (!out || (!dptr && n)) return SCFQ_EARG;
+  Ctx* c = nullptr;
+  int rc = get_ctx(&c);
+  if (rc) return rc;
+  rc = begin_session(c);
+  if (rc) return rc;
+  if (n) {
+    const uint64_t chunks = (n + 255) / 256;
+    rc = ensure_partials(c, chunks, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scfq::fq_scan_simple, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->compute,
+                       static_cast<const uint8_t*>(dptr), n, prev_byte, chunks, c->d_partials);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_partials,
+                       chunks, c->d_state, (uint8_t*)nullptr, static_cast<const uint8_t*>(dptr), n);
+    HIPCHK(hipGetLastError());
+  }
+  return end_session(c, false, out, nullptr);
+}
+
+}  // extern "C"

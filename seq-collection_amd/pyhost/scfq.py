@@ -1,0 +1,322 @@
+"""ctypes host binding of libsc_fqcount_hip.so and a Python mirror of the reference's fq-count operator.
+
+Mirrors (reference tree):
+  src/fq_count.nim:7-11    fq_count_header
+  src/fq_count.nim:14      proc fq_count*(fastq: string, basename: bool, absolute: bool)
+  src/utils/helpers.nim:200-224   output_header / get_absolute / output_w_fnames
+  src/utils/helpers.nim:29-34     error_msg / quit_error
+
+The counting itself always goes through the C ABI (include/sc_fqcount.h) into the HIP kernels; there is
+no Python or CPU fallback here: if the shared library is missing or no GPU is visible the calls raise.
+"""
+import ctypes
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libsc_fqcount_hip.so")
+
+SCFQ_QUAL_HIST = 0x1
+SCFQ_STRUCT_CHECK = 0x2
+SCFQ_TIMING = 0x4
+SCFQ_PREV_IN_MEMORY = 0x8
+SCFQ_EOPEN, SCFQ_EGZ, SCFQ_EHIP, SCFQ_ERCCL, SCFQ_EARG, SCFQ_EIO, SCFQ_ENOMEM = -1, -2, -3, -4, -5, -6, -7
+PARTIAL_WORDS = 32
+HIST_WORDS = 4 * 256
+
+EXPORTS = [
+    "scfq_count_file", "scfq_count_buffer", "scfq_partial_buffer", "scfq_partial_identity",
+    "scfq_partial_combine", "scfq_partial_finalize", "scfq_format_tsv", "scfq_strerror",
+    "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
+    "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device",
+]
+
+
+class Counts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in (
+        "struct_size", "abi_version", "reads", "gc_bases", "n_bases", "bases", "lines", "newlines",
+        "input_bytes", "bad_at", "bad_plus")] + [("qual_hist", ctypes.c_uint64 * 256)]
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint64), ("n_devices", ctypes.c_int32),
+                ("device_ids", ctypes.POINTER(ctypes.c_int32)), ("flags", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("chunk_bytes", ctypes.c_uint64)]
+
+
+class Partial(ctypes.Structure):
+    _fields_ = [("nl", ctypes.c_uint64), ("gc", ctypes.c_uint64 * 4), ("n", ctypes.c_uint64 * 4),
+                ("len", ctypes.c_uint64 * 4), ("starts", ctypes.c_uint64 * 4),
+                ("first_at", ctypes.c_uint64 * 4), ("first_plus", ctypes.c_uint64 * 4),
+                ("bytes", ctypes.c_uint64), ("last_byte", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 5)]
+
+    def words(self):
+        return list((ctypes.c_uint64 * PARTIAL_WORDS).from_buffer_copy(self))
+
+    @classmethod
+    def from_words(cls, w):
+        arr = (ctypes.c_uint64 * PARTIAL_WORDS)(*[int(x) & 0xFFFFFFFFFFFFFFFF for x in w])
+        return cls.from_buffer_copy(arr)
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint64), ("scan_kernel_ms", ctypes.c_double),
+                ("fold_kernel_ms", ctypes.c_double), ("scan_bytes", ctypes.c_uint64),
+                ("scan_launches", ctypes.c_uint64)]
+
+
+class SynthInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("struct_size", "records", "bytes", "gc_bases", "n_bases", "bases")]
+
+
+class ScfqError(RuntimeError):
+    def __init__(self, rc, what, detail=""):
+        self.rc = rc
+        super().__init__("%s failed: rc=%d (%s)%s" % (what, rc, strerror(rc), (" — " + detail) if detail else ""))
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; fails loudly when it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libsc_fqcount_hip.so not built: run `make -C %s` (hipcc --offload-arch=gfx950)"
+                              % os.path.dirname(LIB_PATH))
+        L = ctypes.CDLL(LIB_PATH)
+        L.scfq_count_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(Opts), ctypes.POINTER(Counts)]
+        L.scfq_count_buffer.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(Opts),
+                                        ctypes.POINTER(Counts)]
+        L.scfq_partial_buffer.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(Opts), ctypes.POINTER(Partial), ctypes.c_void_p]
+        L.scfq_partial_identity.argtypes = [ctypes.POINTER(Partial), ctypes.c_void_p]
+        L.scfq_partial_identity.restype = None
+        L.scfq_partial_combine.argtypes = [ctypes.POINTER(Partial), ctypes.POINTER(Partial), ctypes.c_void_p,
+                                           ctypes.c_void_p]
+        L.scfq_partial_finalize.argtypes = [ctypes.POINTER(Partial), ctypes.c_void_p, ctypes.POINTER(Counts)]
+        L.scfq_format_tsv.argtypes = [ctypes.POINTER(Counts), ctypes.c_char_p, ctypes.c_uint64]
+        L.scfq_strerror.argtypes = [ctypes.c_int]
+        L.scfq_strerror.restype = ctypes.c_char_p
+        L.scfq_last_error_detail.restype = ctypes.c_char_p
+        L.scfq_last_timing.argtypes = [ctypes.POINTER(Timing)]
+        L.scfq_debug_partial_simple.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
+                                                ctypes.POINTER(Partial)]
+        for name in ("scfq_synth_plan",):
+            getattr(L, name).argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                         ctypes.POINTER(SynthInfo)]
+        for name in ("scfq_synth_host", "scfq_synth_device"):
+            getattr(L, name).argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                         ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SynthInfo)]
+        _lib = L
+    return _lib
+
+
+def strerror(rc):
+    return lib().scfq_strerror(rc).decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise ScfqError(rc, what, lib().scfq_last_error_detail().decode())
+
+
+def make_opts(flags=0, devices=None, chunk_bytes=0):
+    o = Opts()
+    o.struct_size = ctypes.sizeof(Opts)
+    o.flags = flags
+    o.chunk_bytes = chunk_bytes
+    if devices:
+        arr = (ctypes.c_int32 * len(devices))(*devices)
+        o._keep = arr
+        o.n_devices = len(devices)
+        o.device_ids = ctypes.cast(arr, ctypes.POINTER(ctypes.c_int32))
+    return o
+
+
+def _new_counts():
+    c = Counts()
+    c.struct_size = ctypes.sizeof(Counts)
+    return c
+
+
+def _host_ptr(data):
+    """bytes / bytearray / numpy uint8 array -> (address, length, keepalive)"""
+    if isinstance(data, (bytes, bytearray)):
+        buf = (ctypes.c_char * len(data)).from_buffer_copy(data) if len(data) else (ctypes.c_char * 1)()
+        return ctypes.addressof(buf), len(data), buf
+    import numpy as np
+    a = np.ascontiguousarray(data, dtype=np.uint8)
+    return a.ctypes.data, a.size, a
+
+
+def count_file(path, flags=0, devices=None, chunk_bytes=0):
+    c = _new_counts()
+    o = make_opts(flags, devices, chunk_bytes)
+    _check(lib().scfq_count_file(os.fsencode(path), ctypes.byref(o), ctypes.byref(c)), "scfq_count_file")
+    return c
+
+
+def count_host(data, flags=0, devices=None, chunk_bytes=0):
+    addr, n, keep = _host_ptr(data)
+    c = _new_counts()
+    o = make_opts(flags, devices, chunk_bytes)
+    _check(lib().scfq_count_buffer(addr, n, 0, ctypes.byref(o), ctypes.byref(c)), "scfq_count_buffer")
+    return c
+
+
+def count_device(dev_ptr, n, flags=0):
+    c = _new_counts()
+    o = make_opts(flags)
+    _check(lib().scfq_count_buffer(ctypes.c_void_p(dev_ptr), n, 1, ctypes.byref(o), ctypes.byref(c)),
+           "scfq_count_buffer")
+    return c
+
+
+def partial_device(dev_ptr, n, prev_byte=-1, flags=0, want_hist=False):
+    p = Partial()
+    o = make_opts(flags)
+    hist = (ctypes.c_uint64 * HIST_WORDS)() if want_hist else None
+    _check(lib().scfq_partial_buffer(ctypes.c_void_p(dev_ptr), n, 1, prev_byte, ctypes.byref(o), ctypes.byref(p),
+                                     ctypes.byref(hist) if want_hist else None), "scfq_partial_buffer")
+    return (p, hist) if want_hist else p
+
+
+def partial_host(data, prev_byte=-1, flags=0, want_hist=False, chunk_bytes=0):
+    addr, n, keep = _host_ptr(data)
+    p = Partial()
+    o = make_opts(flags, None, chunk_bytes)
+    hist = (ctypes.c_uint64 * HIST_WORDS)() if want_hist else None
+    _check(lib().scfq_partial_buffer(addr, n, 0, prev_byte, ctypes.byref(o), ctypes.byref(p),
+                                     ctypes.byref(hist) if want_hist else None), "scfq_partial_buffer")
+    return (p, hist) if want_hist else p
+
+
+def partial_simple_device(dev_ptr, n, prev_byte=-1):
+    p = Partial()
+    _check(lib().scfq_debug_partial_simple(ctypes.c_void_p(dev_ptr), n, prev_byte, ctypes.byref(p)),
+           "scfq_debug_partial_simple")
+    return p
+
+
+def combine(acc, b, hist_acc=None, hist_b=None):
+    _check(lib().scfq_partial_combine(ctypes.byref(acc), ctypes.byref(b),
+                                      ctypes.byref(hist_acc) if hist_acc is not None else None,
+                                      ctypes.byref(hist_b) if hist_b is not None else None), "scfq_partial_combine")
+    return acc
+
+
+def identity():
+    p = Partial()
+    lib().scfq_partial_identity(ctypes.byref(p), None)
+    return p
+
+
+def finalize(p, hist=None):
+    c = _new_counts()
+    _check(lib().scfq_partial_finalize(ctypes.byref(p), ctypes.byref(hist) if hist is not None else None,
+                                       ctypes.byref(c)), "scfq_partial_finalize")
+    return c
+
+
+def format_tsv(c):
+    buf = ctypes.create_string_buffer(256)
+    lib().scfq_format_tsv(ctypes.byref(c), buf, 256)
+    return buf.value.decode()
+
+
+def last_timing():
+    t = Timing()
+    t.struct_size = ctypes.sizeof(Timing)
+    _check(lib().scfq_last_timing(ctypes.byref(t)), "scfq_last_timing")
+    return t
+
+
+def synth_plan(kind, seed, min_bytes, first_record=0):
+    info = SynthInfo()
+    info.struct_size = ctypes.sizeof(SynthInfo)
+    _check(lib().scfq_synth_plan(kind, seed, first_record, min_bytes, ctypes.byref(info)), "scfq_synth_plan")
+    return info
+
+
+def synth_host(kind, seed, records, first_record=0):
+    import numpy as np
+    plan = SynthInfo()
+    plan.struct_size = ctypes.sizeof(SynthInfo)
+    # upper bound on size: plan with records via a dry call (dst NULL, cap 0 returns bytes needed)
+    _check(lib().scfq_synth_host(kind, seed, first_record, records, None, 0, ctypes.byref(plan)), "scfq_synth_host")
+    out = np.empty(plan.bytes, dtype=np.uint8)
+    info = SynthInfo()
+    info.struct_size = ctypes.sizeof(SynthInfo)
+    _check(lib().scfq_synth_host(kind, seed, first_record, records, out.ctypes.data, out.size, ctypes.byref(info)),
+           "scfq_synth_host")
+    return out, info
+
+
+def synth_device(kind, seed, records, dev_ptr, cap, first_record=0):
+    info = SynthInfo()
+    info.struct_size = ctypes.sizeof(SynthInfo)
+    _check(lib().scfq_synth_device(kind, seed, first_record, records, ctypes.c_void_p(dev_ptr), cap,
+                                   ctypes.byref(info)), "scfq_synth_device")
+    return info
+
+
+# ---------------------------------------------------------------------------------------------
+# Python mirror of the reference operator (same names, argument meaning and error behaviour)
+# ---------------------------------------------------------------------------------------------
+fq_count_header = "\t".join(["reads", "gc_content", "gc_bases", "n_bases", "bases"])   # src/fq_count.nim:7-11
+
+
+def output_header(header, basename, absolute):
+    """src/utils/helpers.nim:200-208"""
+    return "\t".join([x for x in (header, "basename" if basename else "", "absolute" if absolute else "") if x])
+
+
+def get_absolute(path):
+    """src/utils/helpers.nim:210-213 — symlinks: absolutePath(expandSymlink(path)) (relative targets resolve
+    against the CWD, a reference quirk kept here)."""
+    if os.path.islink(path):
+        return os.path.abspath(os.readlink(path))
+    return os.path.abspath(path)
+
+
+def last_path_part(path):
+    """Nim os.lastPathPart: tail of the path after stripping trailing separators."""
+    return os.path.basename(path.rstrip("/")) if path.rstrip("/") else ""
+
+
+def output_w_fnames(line, path, basename, absolute):
+    """src/utils/helpers.nim:215-224"""
+    parts = [line, last_path_part(path) if basename else "", get_absolute(path) if absolute else ""]
+    return "\t".join([x for x in parts if x])
+
+
+def error_msg(msg, error_code=1, stream=None):
+    """src/utils/helpers.nim:29-30 (colorize fgRed)"""
+    (stream or sys.stderr).write("\x1b[31mError %d: %s\x1b[0m\n" % (error_code, msg))
+
+
+def quit_error(msg, error_code=1):
+    """src/utils/helpers.nim:32-34"""
+    error_msg(msg, error_code)
+    sys.exit(error_code)
+
+
+def fq_count(fastq, basename=False, absolute=False, out=None, flags=0, devices=None):
+    """proc fq_count*(fastq: string, basename: bool, absolute: bool)   (src/fq_count.nim:14-53)
+
+    Prints one TSV row. Unopenable input -> "Error 2: Unable to open file: <path>" and exit status 2
+    (src/fq_count.nim:35-36). Paths shorter than 3 characters raise like the reference's
+    fastq[^3 .. ^1] slice does (IndexError there; surfaces as exit 1 through sc.nim:299-305).
+    """
+    if len(fastq) < 3:
+        raise IndexError("index out of bounds")   # fastq[^3 .. ^1], src/fq_count.nim:31
+    try:
+        c = count_file(fastq, flags=flags, devices=devices)
+    except ScfqError as e:
+        if e.rc == SCFQ_EOPEN:
+            quit_error("Unable to open file: " + fastq, 2)
+        raise
+    (out or sys.stdout).write(output_w_fnames(format_tsv(c), fastq, basename, absolute) + "\n")
+    return c
