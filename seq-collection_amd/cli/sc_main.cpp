@@ -1,0 +1,243 @@
+// sc_main.cpp — C++ host for the `sc fq-count` command over the C ABI (include/sc_fqcount.h).
+//
+// The reference host is Nim (sc.nim + src/fq_count.nim); no Nim toolchain exists in this image, so the
+// host side above the C ABI is written in C++ and mirrors the reference's surface for this path:
+//   sc.nim:103-116                 command "fq-count": -t/--header, -b/--basename, -a/--absolute, [fastq ...]
+//   sc.nim:274-293                 stdin '-' -> literal "STDIN"; bare `sc` -> help
+//   src/fq_count.nim:14-53         one TSV row per file, argv order; "Unable to open file" exit 2
+//   src/utils/helpers.nim:29-34    "Error <code>: <msg>" in red on stderr, exit <code>
+//   src/utils/helpers.nim:200-224  header / basename / absolute columns
+// Everything between "open the file" and "format the row" is one call into libsc_fqcount_hip.so.
+// GPU-only additions are new long options and never change the reference's 5-column row.
+#include "../../include/sc_fqcount.h"
+
+#include <limits.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static const char* kVersion = "0.0.2-mi355x";
+static const char* kHeader = "reads\tgc_content\tgc_bases\tn_bases\tbases";   // src/fq_count.nim:7-11
+
+static void error_msg(const std::string& msg, int code) {           // helpers.nim:29-30 (colorize fgRed)
+  std::fprintf(stderr, "\x1b[31mError %d: %s\x1b[0m\n", code, msg.c_str());
+}
+[[noreturn]] static void quit_error(const std::string& msg, int code = 1) {   // helpers.nim:32-34
+  error_msg(msg, code);
+  std::exit(code);
+}
+
+static std::string join_nonempty(const std::vector<std::string>& parts) {     // filterIt(it.len > 0).join("\t")
+  std::string out;
+  for (const auto& p : parts) {
+    if (p.empty()) continue;
+    if (!out.empty()) out += '\t';
+    out += p;
+  }
+  return out;
+}
+
+static std::string output_header(const std::string& header, bool basename, bool absolute) {   // helpers.nim:200-208
+  return join_nonempty({header, basename ? "basename" : "", absolute ? "absolute" : ""});
+}
+
+static std::string last_path_part(std::string p) {   // Nim os.lastPathPart
+  while (p.size() > 1 && p.back() == '/') p.pop_back();
+  if (p == "/") return "";
+  const size_t k = p.find_last_of('/');
+  return k == std::string::npos ? p : p.substr(k + 1);
+}
+
+static std::string normalize_join(const std::string& root, const std::string& rel) {   // Nim os.absolutePath/joinPath
+  std::vector<std::string> comp;
+  auto feed = [&](const std::string& s) {
+    size_t i = 0;
+    while (i <= s.size()) {
+      size_t j = s.find('/', i);
+      if (j == std::string::npos) j = s.size();
+      std::string c = s.substr(i, j - i);
+      if (c == "..") { if (!comp.empty()) comp.pop_back(); }
+      else if (!c.empty() && c != ".") comp.push_back(c);
+      i = j + 1;
+    }
+  };
+  feed(root);
+  feed(rel);
+  std::string out;
+  for (const auto& c : comp) { out += '/'; out += c; }
+  return out.empty() ? "/" : out;
+}
+
+static std::string absolute_path(const std::string& p) {
+  if (!p.empty() && p[0] == '/') return p;          // absolute inputs are returned verbatim
+  char cwd[PATH_MAX];
+  if (!getcwd(cwd, sizeof cwd)) return p;
+  return normalize_join(cwd, p);
+}
+
+static std::string get_absolute(const std::string& path) {   // helpers.nim:210-213
+  struct stat sb;
+  if (lstat(path.c_str(), &sb) == 0 && S_ISLNK(sb.st_mode)) {
+    char buf[PATH_MAX];
+    ssize_t n = readlink(path.c_str(), buf, sizeof buf - 1);
+    if (n >= 0) { buf[n] = 0; return absolute_path(buf); }   // relative targets resolve against the CWD (reference quirk)
+  }
+  return absolute_path(path);
+}
+
+static std::string output_w_fnames(const std::string& line, const std::string& path, bool basename, bool absolute) {
+  return join_nonempty({line, basename ? last_path_part(path) : "", absolute ? get_absolute(path) : ""});   // helpers.nim:215-224
+}
+
+static void help_fq_count(FILE* f) {   // docs/fq-count.md:5-19
+  std::fputs(
+      "Counts lines in a FASTQ\n\n"
+      "Usage:\n"
+      "  fq-count [options] [fastq ...]\n\n"
+      "Arguments:\n"
+      "  [fastq ...]      Input FASTQ\n\n"
+      "Options:\n"
+      "  -t, --header               Output the header\n"
+      "  -b, --basename             Add basename column\n"
+      "  -a, --absolute             Add column for absolute path\n"
+      "  -h, --help                 Show this help\n"
+      "\nMI355X options (additions; the TSV row is unchanged):\n"
+      "      --devices=LIST         Comma-separated HIP device ids to shard each file across (default: current device)\n"
+      "      --struct-check         Report header lines not starting '@' / separator lines not starting '+' on stderr\n"
+      "      --qual-hist            Print the quality-byte histogram on stderr\n"
+      "      --stats                Print bytes / device milliseconds / GB/s as JSON on stderr\n",
+      f);
+}
+
+static void help_top(FILE* f) {
+  std::fprintf(f,
+               "sc (%s) — MI355X-native host for the fq-count path of seq-collection\n\n"
+               "Usage:\n  sc COMMAND\n\nCommands:\n\nFASTQ\n  fq-count         Counts lines in a FASTQ\n\n"
+               "Options:\n  -h, --help                 Show this help\n  -v, --version              Show version\n"
+               "      --debug                Debug mode\n",
+               kVersion);
+}
+
+static bool stdin_is_fifo() {   // sc.nim:50-53
+  struct stat st;
+  return fstat(0, &st) == 0 && S_ISFIFO(st.st_mode);
+}
+
+// proc fq_count*(fastq: string, basename: bool, absolute: bool)      src/fq_count.nim:14
+static void fq_count(const std::string& fastq, bool basename, bool absolute, const scfq_opts& opts, bool stats) {
+  if (fastq.size() < 3) quit_error("index out of bounds", 1);   // fastq[^3 .. ^1] raises; sc.nim:299-305 -> exit 1
+  scfq_counts c;
+  std::memset(&c, 0, sizeof c);
+  c.struct_size = sizeof c;
+  const int rc = scfq_count_file(fastq.c_str(), &opts, &c);
+  if (rc == SCFQ_EOPEN) {
+    const bool gz = fastq.compare(fastq.size() - 3, 3, ".gz") == 0;
+    // plain: stream == nil -> quit_error(..., 2) (fq_count.nim:35-36); .gz: the stream constructor raises -> exit 1 (sc.nim:299-305)
+    quit_error("Unable to open file: " + fastq, gz ? 1 : 2);
+  }
+  if (rc != SCFQ_OK) {
+    std::string m = std::string(scfq_strerror(rc));
+    const char* d = scfq_last_error_detail();
+    if (d && *d) { m += ": "; m += d; }
+    quit_error(m, 1);
+  }
+  char row[256];
+  scfq_format_tsv(&c, row, sizeof row);
+  std::printf("%s\n", output_w_fnames(row, fastq, basename, absolute).c_str());   // echo ...  fq_count.nim:53
+  if (std::fflush(stdout) != 0) { /* EPIPE is swallowed like sc.nim:304 */ }
+  if (opts.flags & SCFQ_STRUCT_CHECK)
+    std::fprintf(stderr, "%s\tbad_at=%llu\tbad_plus=%llu\n", fastq.c_str(), (unsigned long long)c.bad_at, (unsigned long long)c.bad_plus);
+  if (opts.flags & SCFQ_QUAL_HIST) {
+    std::fprintf(stderr, "%s\tqual_hist", fastq.c_str());
+    for (int v = 0; v < 256; ++v)
+      if (c.qual_hist[v]) std::fprintf(stderr, "\t%d:%llu", v, (unsigned long long)c.qual_hist[v]);
+    std::fprintf(stderr, "\n");
+  }
+  if (stats) {
+    scfq_timing t;
+    std::memset(&t, 0, sizeof t);
+    t.struct_size = sizeof t;
+    scfq_last_timing(&t);
+    const double gbs = t.scan_kernel_ms > 0 ? (double)t.scan_bytes / (t.scan_kernel_ms * 1e-3) / 1e9 : 0.0;
+    std::fprintf(stderr,
+                 "{\"file\": \"%s\", \"input_bytes\": %llu, \"scan_kernel_ms\": %.4f, \"fold_kernel_ms\": %.4f, "
+                 "\"scan_launches\": %llu, \"scan_GBps\": %.1f, \"hbm_peak_GBps\": 8000, \"roofline_frac\": %.4f}\n",
+                 fastq.c_str(), (unsigned long long)c.input_bytes, t.scan_kernel_ms, t.fold_kernel_ms,
+                 (unsigned long long)t.scan_launches, gbs, gbs / 8000.0);
+  }
+}
+
+int main(int argc, char** argv) {
+  signal(SIGPIPE, SIG_IGN);   // sc.nim:45-46
+  std::vector<std::string> params(argv + 1, argv + argc);
+  if (stdin_is_fifo())        // sc.nim:274-284
+    for (auto& p : params)
+      if (p == "-") { p = "STDIN"; break; }
+  if (params.empty() || params[0] == "-h" || params[0] == "--help") { help_top(stdout); return 0; }
+  if (params[0] == "-v" || params[0] == "--version") { std::printf("%s\n", kVersion); return 0; }
+  if (params[0] != "fq-count") {
+    help_top(stdout);
+    quit_error("Unknown command: " + params[0] + " (this build provides the fq-count path only)", 1);
+  }
+  if (params.size() == 1) { help_fq_count(stdout); return 0; }   // sc.nim:288-290: len <= 1 -> "-h"
+
+  bool header = false, basename = false, absolute = false, stats = false;
+  std::vector<std::string> files;
+  std::vector<int32_t> devices;
+  uint32_t flags = 0;
+  bool only_positional = false;
+  for (size_t i = 1; i < params.size(); ++i) {
+    const std::string& a = params[i];
+    if (only_positional || a.empty() || a[0] != '-' || a == "-") { files.push_back(a); continue; }
+    if (a == "--") { only_positional = true; continue; }
+    if (a == "-h" || a == "--help") { help_fq_count(stdout); return 0; }
+    if (a == "--header") header = true;
+    else if (a == "--basename") basename = true;
+    else if (a == "--absolute") absolute = true;
+    else if (a == "--debug") {}
+    else if (a == "--struct-check") flags |= SCFQ_STRUCT_CHECK;
+    else if (a == "--qual-hist") flags |= SCFQ_QUAL_HIST;
+    else if (a == "--stats") { stats = true; flags |= SCFQ_TIMING; }
+    else if (a.rfind("--devices=", 0) == 0) {
+      const std::string list = a.substr(10);
+      size_t p = 0;
+      while (p < list.size()) {
+        size_t q = list.find(',', p);
+        if (q == std::string::npos) q = list.size();
+        devices.push_back(std::atoi(list.substr(p, q - p).c_str()));
+        p = q + 1;
+      }
+    } else if (a.size() >= 2 && a[1] != '-') {
+      for (size_t k = 1; k < a.size(); ++k) {   // combined short flags: -tb
+        if (a[k] == 't') header = true;
+        else if (a[k] == 'b') basename = true;
+        else if (a[k] == 'a') absolute = true;
+        else if (a[k] == 'h') { help_fq_count(stdout); return 0; }
+        else { help_fq_count(stdout); quit_error(std::string("Error: Unknown option: -") + a[k], 1); }
+      }
+    } else {
+      help_fq_count(stdout);
+      quit_error("Error: Unknown option: " + a, 1);   // UsageError funnel, sc.nim:294-298
+    }
+  }
+
+  scfq_opts opts;
+  std::memset(&opts, 0, sizeof opts);
+  opts.struct_size = sizeof opts;
+  opts.flags = flags;
+  opts.n_devices = (int32_t)devices.size();
+  opts.device_ids = devices.empty() ? nullptr : devices.data();
+  if (const char* e = std::getenv("SC_GPU_CHUNK")) opts.chunk_bytes = std::strtoull(e, nullptr, 10);
+
+  if (header) std::printf("%s\n", output_header(kHeader, basename, absolute).c_str());   // sc.nim:110-111
+  else if (files.empty()) quit_error("No FASTQ specified", 3);                           // sc.nim:112-113
+  for (const auto& f : files) fq_count(f, basename, absolute, opts, stats);             // sc.nim:114-116
+  scfq_shutdown();
+  return 0;
+}

@@ -271,7 +271,7 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
     t_gc += popc64(GC & below) << sh;
     t_nn += popc64(NN & below) << sh;
     if (STRUCT) {
-      const uint64_t ls = LS & below;
+      const uint64_t ls = LS & upto;      // a line start may itself be the newline (empty line)
       t_st += popc64(ls) << sh;
       t_fat += popc64(ls & m.at) << sh;
       t_fpl += popc64(ls & m.pl) << sh;
