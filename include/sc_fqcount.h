@@ -158,6 +158,9 @@ typedef struct scfq_synth_info {
 
 /* Smallest record count whose total length is >= min_bytes (and its exact length). */
 int scfq_synth_plan(int kind, uint64_t seed, uint64_t first_record, uint64_t min_bytes, scfq_synth_info* info);
+/* Locate byte `offset` of the record stream that starts at record 0: writes the index of the record
+ * containing that byte and the stream offset at which that record starts. */
+int scfq_synth_locate(int kind, uint64_t seed, uint64_t offset, uint64_t* record, uint64_t* record_start);
 /* Generate records [first_record, first_record+records) into host memory (cap >= info->bytes). */
 int scfq_synth_host(int kind, uint64_t seed, uint64_t first_record, uint64_t records,
                     void* dst, uint64_t cap, scfq_synth_info* info);

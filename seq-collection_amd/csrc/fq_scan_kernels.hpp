@@ -166,6 +166,44 @@ __device__ __forceinline__ void masks32(const uint32_t* d, uint32_t& nl, uint32_
   nl = ~wnl; gc = ~wgc; nn = ~wnn; at = ~wat; pl = ~wpl;
 }
 
+// ---- hand-scheduled ASCII form (the VALU-bound hot path; every op here is paid 64 x per tile) ------
+// v_xad_u32 fuses the xor with the carry-generating add; v_and_or_b32 fuses mask + merge:
+//   '\n', 'N' : xad, lshr, and_or            = 3 VALU per dword
+//   G|C       : bitop3 (xor,and), add, lshr, and_or = 4 VALU per dword
+__device__ __forceinline__ uint32_t v_xad(uint32_t x, uint32_t c, uint32_t k) {
+  uint32_t r;
+  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(k));
+  return r;
+}
+__device__ __forceinline__ uint32_t v_and_or(uint32_t a, uint32_t m, uint32_t c) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(c));
+  return r;
+}
+
+__device__ __forceinline__ void masks32_ascii(const uint32_t* d, uint32_t k7f, uint32_t& nl, uint32_t& gc, uint32_t& nn) {
+  uint32_t x[8];
+  transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
+  transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
+  uint32_t wnl = 0, wgc = 0, wnn = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t sel = 0x01010101u << j;
+    const uint32_t v = x[j];
+    uint32_t e;
+    e = v_xad(v, 0x0A0A0A0Au, k7f);
+    if (j != 7) e >>= (7 - j);
+    wnl = (j == 0) ? (e & sel) : v_and_or(e, sel, wnl);
+    e = ((v ^ 0x43434343u) & 0xFBFBFBFBu) + 0x7F7F7F7Fu;      // (b ^ 'C') & ~4 == 0  <=>  b in {'C','G'}
+    if (j != 7) e >>= (7 - j);
+    wgc = (j == 0) ? (e & sel) : v_and_or(e, sel, wgc);
+    e = v_xad(v, 0x4E4E4E4Eu, k7f);
+    if (j != 7) e >>= (7 - j);
+    wnn = (j == 0) ? (e & sel) : v_and_or(e, sel, wnn);
+  }
+  nl = ~wnl; gc = ~wgc; nn = ~wnn;
+}
+
 struct Masks {
   uint64_t nl, gc, nn, at, pl;
 };
@@ -290,7 +328,8 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
     // the '\r' of a "\r\n" line end is not part of the line: look one byte behind the newline
     const int q = (int)popc64(below);                 // lane-local index of the newline (64 if none)
     int idx = lane_base + q - 1;
-    int pb = slot[idx < 0 ? 0 : idx];
+    // lanes without a newline read a dummy, bank-spread address (lane*4) instead of 64 B-strided ones
+    int pb = slot[has_nl ? (idx < 0 ? 0 : idx) : lane * 4];
     if (idx < 0) pb = st.prev_last;
     if (EDGE) { if ((int64_t)(lane_base + q) == first_valid_pos) pb = prev_byte_param; }
     t_crlf += ((has_nl && pb == '\r') ? 1u : 0u) << sh;
@@ -307,6 +346,94 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
   st.len.add_tile8(t_len);
   st.crlf.add_tile8(t_crlf);
   if (STRUCT) { st.starts.add_tile8(t_st); st.fat.add_tile8(t_fat); st.fplus.add_tile8(t_fpl); }
+  st.phase = (st.phase + total) & 3u;
+  st.nl_total += total;
+  st.prev_last = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)d[15], 63) >> 24);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Interior tile of the default variant (no EDGE / STRUCT / HIST): the same arithmetic as
+// process_tile with the segment loop restructured so that the common FASTQ shapes (0, 1 or 2
+// newlines in a lane's 64 bytes) cost one straight-line "first segment" block, one "last segment"
+// block and at most one pass of the middle loop.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st) {
+  const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
+  const uint4 q0v = p[0], q1v = p[1], q2v = p[2], q3v = p[3];
+  uint32_t d[16] = {q0v.x, q0v.y, q0v.z, q0v.w, q1v.x, q1v.y, q1v.z, q1v.w,
+                    q2v.x, q2v.y, q2v.z, q2v.w, q3v.x, q3v.y, q3v.z, q3v.w};
+  const uint32_t hb = (d[0] | d[1] | d[2]) | (d[3] | d[4] | d[5]) | (d[6] | d[7] | d[8]) |
+                      (d[9] | d[10] | d[11]) | (d[12] | d[13] | d[14]) | d[15];
+  uint64_t NL, GC, NN;
+  if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0) {
+    uint32_t a0, a1, a2, b0, b1, b2;
+    uint32_t k7f = 0x7F7F7F7Fu;
+    asm("" : "+v"(k7f));   // keep the constant in a VGPR (the VOP3 forms take one SGPR source only)
+    masks32_ascii(d, k7f, a0, a1, a2);
+    masks32_ascii(d + 8, k7f, b0, b1, b2);
+    NL = (uint64_t)a0 | ((uint64_t)b0 << 32);
+    GC = (uint64_t)a1 | ((uint64_t)b1 << 32);
+    NN = (uint64_t)a2 | ((uint64_t)b2 << 32);
+  } else {
+    const Masks m = masks64<false, false>(d);
+    NL = m.nl; GC = m.gc; NN = m.nn;
+  }
+
+  const uint32_t cnt = popc64(NL);
+  const uint32_t incl = wave_inclusive_scan(cnt);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  const uint32_t sh0 = ((st.phase + incl - cnt) & 3u) * 8u;
+
+  // first segment: everything below the first newline (the whole lane when there is none)
+  const uint64_t xm1 = NL - 1;
+  const uint64_t below = ~NL & xm1;
+  const uint32_t q0 = popc64(below);
+  uint32_t t_len = q0 << sh0;
+  uint32_t t_gc = popc64(GC & below) << sh0;
+  uint32_t t_nn = popc64(NN & below) << sh0;
+  uint32_t t_crlf = 0;
+
+  if (total != 0) {   // wave-uniform: some lane of this tile holds a newline
+    const int lane_base = lane * 64;
+    const bool has1 = (NL != 0);
+    {   // '\r' directly before the first newline?
+      const int idx = lane_base + (int)q0 - 1;
+      int pb = slot[has1 ? (idx < 0 ? 0 : idx) : lane * 4];   // newline-free lanes read a bank-spread dummy
+      if (idx < 0) pb = st.prev_last;
+      t_crlf = ((has1 && pb == '\r') ? 1u : 0u) << sh0;
+    }
+    // last segment: bits above the highest newline (empty for newline-free lanes: "& ~below")
+    const uint64_t xr = __builtin_bitreverse64(NL);
+    const uint64_t above = __builtin_bitreverse64(~xr & (xr - 1)) & ~below;
+    const uint32_t shl = (sh0 + cnt * 8u) & 31u;
+    t_len += popc64(above) << shl;
+    t_gc += popc64(GC & above) << shl;
+    t_nn += popc64(NN & above) << shl;
+    // middle segments: between consecutive newlines of one lane
+    uint64_t xc = NL, xcm1 = xm1;
+    uint32_t sh = sh0;
+    for (;;) {
+      const uint64_t x1 = xc & xcm1;               // drop the lowest remaining newline
+      const bool has2 = (x1 != 0);
+      if (__builtin_amdgcn_ballot_w64(has2) == 0) break;
+      const uint64_t x1m1 = x1 - 1;
+      const uint64_t below1 = ~x1 & x1m1;
+      const uint64_t seg = below1 & ~(xc ^ xcm1) & ~above;   // "& ~above" empties lanes whose next segment is their last
+      sh = (sh + 8u) & 31u;
+      t_len += popc64(seg) << sh;
+      t_gc += popc64(GC & seg) << sh;
+      t_nn += popc64(NN & seg) << sh;
+      const int idx = lane_base + (int)popc64(below1) - 1;     // >= 0: the second newline of a lane is never at bit 0
+      const int pb = slot[has2 ? idx : lane * 4];
+      t_crlf += ((has2 && pb == '\r') ? 1u : 0u) << sh;
+      xc = x1; xcm1 = x1m1;
+    }
+  }
+
+  st.gc.add_tile8(t_gc);
+  st.nn.add_tile8(t_nn);
+  st.len.add_tile8(t_len);
+  st.crlf.add_tile8(t_crlf);
   st.phase = (st.phase + total) & 3u;
   st.nl_total += total;
   st.prev_last = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)d[15], 63) >> 24);
@@ -346,13 +473,18 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
   uint64_t t_end = t_begin + a.tiles_per_range;
   if (t_end > NT) t_end = NT;
 
+  // Both halo bytes are fetched and pinned into SGPRs BEFORE the first LDS-DMA is issued: a
+  // compiler-visible load whose first use sat inside the tile loop made hipcc emit s_waitcnt vmcnt(0)
+  // there, draining the whole DMA ring on every pass.
   int32_t prev_param = a.prev_byte;
   if (prev_param == -2) prev_param = a.base[-1];
+  prev_param = __builtin_amdgcn_readfirstlane(prev_param);
 
   WaveState st = {};
   // byte before this range's first tile: from memory when it belongs to the input, else the caller's halo
   st.prev_last = prev_param;
   if (A0 + t_begin * kTile > B) st.prev_last = *reinterpret_cast<const uint8_t*>(A0 + t_begin * kTile - 1);
+  st.prev_last = __builtin_amdgcn_readfirstlane(st.prev_last);
 
   const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;   // LDS byte address of slot 0 (wave-uniform)
 
@@ -390,7 +522,8 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
     const uint8_t* sl = ring + slot * kTile;
     const uint64_t ts = A0 + t * kTile;
     if (ts >= B && ts + kTile <= E) {
-      process_tile<false, STRUCT, HIST>(sl, lane, ~0ull, 0, prev_param, st, hist_lds);
+      if (!STRUCT && !HIST) process_tile_fast(sl, lane, st);
+      else process_tile<false, STRUCT, HIST>(sl, lane, ~0ull, 0, prev_param, st, hist_lds);
     } else {
       // valid bytes of this lane: absolute [ts + 64*lane, +64) intersected with [B, E)
       const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);
@@ -457,7 +590,42 @@ __device__ __forceinline__ void partial_combine(uint64_t* acc, const uint64_t* b
 }
 
 constexpr int kFoldThreads = 256;
+constexpr int kFold1 = 128;   // ranges folded per level-1 block
 
+// K2a: level-1 fold, one block per kFold1 consecutive ranges (coalesced load into LDS, ordered tree).
+// rel_phase[r] (optional) = newlines of the earlier ranges of the same block, mod 4.
+__global__ __launch_bounds__(kFold1) void fq_fold_level1(const uint64_t* partials, uint64_t n_ranges,
+                                                          uint64_t* block_out, uint8_t* rel_phase) {
+  __shared__ uint64_t sh[kFold1][W_BYTES + 1];
+  const int tid = threadIdx.x;
+  const uint64_t r0 = (uint64_t)blockIdx.x * kFold1;
+  const uint64_t cnt = (n_ranges - r0 < (uint64_t)kFold1) ? n_ranges - r0 : (uint64_t)kFold1;
+  const uint64_t* src = partials + r0 * kPartialWords;
+  for (int idx = tid; idx < kFold1 * kPartialWords; idx += kFold1) {
+    const int r = idx / kPartialWords, w = idx % kPartialWords;
+    if (w < W_BYTES) sh[r][w] = ((uint64_t)r < cnt) ? src[idx] : 0;
+  }
+  __syncthreads();
+  if (rel_phase && tid == 0) {
+    uint32_t ph = 0;
+    for (uint64_t r = 0; r < cnt; ++r) { rel_phase[r0 + r] = (uint8_t)ph; ph = (ph + (uint32_t)sh[r][W_NL]) & 3u; }
+  }
+  __syncthreads();
+  for (int s = 1; s < kFold1; s <<= 1) {
+    if ((tid & (2 * s - 1)) == 0) {
+      uint64_t a2[W_BYTES], b2[W_BYTES];
+#pragma unroll
+      for (int k = 0; k < W_BYTES; ++k) { a2[k] = sh[tid][k]; b2[k] = sh[tid + s][k]; }
+      partial_combine(a2, b2);
+#pragma unroll
+      for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = a2[k];
+    }
+    __syncthreads();
+  }
+  if (tid < kPartialWords) block_out[(uint64_t)blockIdx.x * kPartialWords + tid] = (tid < W_BYTES) ? sh[0][tid] : 0;
+}
+
+// K2b: final fold over the level-1 block partials into the running state (carry-in for streaming).
 __global__ __launch_bounds__(kFoldThreads) void fq_fold_partials(const uint64_t* partials, uint64_t n_ranges,
                                                                  uint64_t* state, uint8_t* range_phase,
                                                                  const uint8_t* base, uint64_t n) {
@@ -515,14 +683,14 @@ __global__ __launch_bounds__(kFoldThreads) void fq_fold_partials(const uint64_t*
   }
 }
 
-// K3 fold: state_hist[c][b] += sum_r hist_r[(c - phase_r) & 3][b]
-__global__ __launch_bounds__(256) void fq_fold_hist(const uint32_t* hist_partials, const uint8_t* range_phase,
-                                                    uint64_t n_ranges, uint64_t* state_hist) {
+// K3 fold: state_hist[c][b] += sum_r hist_r[(c - phase_r) & 3][b],  phase_r = block_phase[r / kFold1] + rel_phase[r]
+__global__ __launch_bounds__(256) void fq_fold_hist(const uint32_t* hist_partials, const uint8_t* rel_phase,
+                                                    const uint8_t* block_phase, uint64_t n_ranges, uint64_t* state_hist) {
   const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1023 : c*256 + b
   const uint32_t c = idx >> 8, b = idx & 255;
   uint64_t acc = 0;
   for (uint64_t r = 0; r < n_ranges; ++r) {
-    const uint32_t src = (c - range_phase[r]) & 3u;
+    const uint32_t src = (c - (uint32_t)block_phase[r / kFold1] - (uint32_t)rel_phase[r]) & 3u;
     // u32 partials are modular too (the "\r\n" take-back may wrap): sign-extend the wrap
     acc += (uint64_t)(int64_t)(int32_t)hist_partials[r * 1024 + src * 256 + b];
   }

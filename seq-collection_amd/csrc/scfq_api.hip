@@ -51,8 +51,10 @@ struct Ctx {
   uint64_t* d_partials = nullptr;
   uint64_t cap_ranges = 0;
   uint32_t* d_hist_partials = nullptr;
-  uint8_t* d_range_phase = nullptr;
+  uint8_t* d_range_phase = nullptr;   // [cap] rel phase per range, then [cap] start phase per level-1 block
   uint64_t cap_hist_ranges = 0;
+  uint64_t* d_block_partials = nullptr;   // level-1 fold output
+  uint64_t cap_blocks = 0;
   uint64_t* d_state = nullptr;   // [32 partial words][1024 hist words]
   uint64_t* h_state = nullptr;   // pinned mirror
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
@@ -103,6 +105,10 @@ int ensure_partials(Ctx* c, uint64_t n_ranges, bool hist) {
     uint64_t cap = std::max<uint64_t>(n_ranges + n_ranges / 4, 4096);
     HIPCHK(hipMalloc(&c->d_partials, cap * scfq::kPartialWords * sizeof(uint64_t)));
     c->cap_ranges = cap;
+    if (c->d_block_partials) HIPCHK(hipFree(c->d_block_partials));
+    c->d_block_partials = nullptr;
+    c->cap_blocks = cap / scfq::kFold1 + 2;
+    HIPCHK(hipMalloc(&c->d_block_partials, c->cap_blocks * scfq::kPartialWords * sizeof(uint64_t)));
   }
   if (hist && n_ranges > c->cap_hist_ranges) {
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -112,7 +118,7 @@ int ensure_partials(Ctx* c, uint64_t n_ranges, bool hist) {
     c->d_range_phase = nullptr;
     uint64_t cap = std::max<uint64_t>(n_ranges + n_ranges / 4, 4096);
     HIPCHK(hipMalloc(&c->d_hist_partials, cap * 1024 * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&c->d_range_phase, cap));
+    HIPCHK(hipMalloc(&c->d_range_phase, 2 * cap));
     c->cap_hist_ranges = cap;
   }
   return SCFQ_OK;
@@ -186,13 +192,21 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
   else launch_scan<false, false>(a, blocks, lds, c->compute);
   HIPCHK(hipGetLastError());
   if (timing) HIPCHK(hipEventRecord(c->ev_t1, c->compute));
-  hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_partials,
-                     n_ranges, c->d_state, hist ? c->d_range_phase : nullptr, dptr, n);
-  HIPCHK(hipGetLastError());
-  if (hist) {
-    hipLaunchKernelGGL(scfq::fq_fold_hist, dim3(4), dim3(256), 0, c->compute, c->d_hist_partials, c->d_range_phase,
-                       n_ranges, c->d_state + SCFQ_PARTIAL_WORDS);
+  {
+    const uint64_t n_blocks = (n_ranges + scfq::kFold1 - 1) / scfq::kFold1;
+    uint8_t* rel_phase = hist ? c->d_range_phase : nullptr;
+    uint8_t* block_phase = hist ? c->d_range_phase + c->cap_hist_ranges : nullptr;
+    hipLaunchKernelGGL(scfq::fq_fold_level1, dim3((unsigned)n_blocks), dim3(scfq::kFold1), 0, c->compute, c->d_partials,
+                       n_ranges, c->d_block_partials, rel_phase);
     HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_block_partials,
+                       n_blocks, c->d_state, block_phase, dptr, n);
+    HIPCHK(hipGetLastError());
+    if (hist) {
+      hipLaunchKernelGGL(scfq::fq_fold_hist, dim3(4), dim3(256), 0, c->compute, c->d_hist_partials, rel_phase,
+                         block_phase, n_ranges, c->d_state + SCFQ_PARTIAL_WORDS);
+      HIPCHK(hipGetLastError());
+    }
   }
   if (timing) {
     HIPCHK(hipEventRecord(c->ev_t2, c->compute));
@@ -527,6 +541,7 @@ int scfq_shutdown(void) {
       if (c->ev_scanned[b]) (void)hipEventDestroy(c->ev_scanned[b]);
     }
     if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_block_partials) (void)hipFree(c->d_block_partials);
     if (c->d_hist_partials) (void)hipFree(c->d_hist_partials);
     if (c->d_range_phase) (void)hipFree(c->d_range_phase);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -556,8 +571,12 @@ int scfq_debug_partial_simple(const void* dptr, uint64_t n, int prev_byte, scfq_
     hipLaunchKernelGGL(scfq::fq_scan_simple, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, c->compute,
                        static_cast<const uint8_t*>(dptr), n, prev_byte, chunks, c->d_partials);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_partials,
-                       chunks, c->d_state, (uint8_t*)nullptr, static_cast<const uint8_t*>(dptr), n);
+    const uint64_t n_blocks = (chunks + scfq::kFold1 - 1) / scfq::kFold1;
+    hipLaunchKernelGGL(scfq::fq_fold_level1, dim3((unsigned)n_blocks), dim3(scfq::kFold1), 0, c->compute, c->d_partials,
+                       chunks, c->d_block_partials, (uint8_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_block_partials,
+                       n_blocks, c->d_state, (uint8_t*)nullptr, static_cast<const uint8_t*>(dptr), n);
     HIPCHK(hipGetLastError());
   }
   return end_session(c, false, out, nullptr);

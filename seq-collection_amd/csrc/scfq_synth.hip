@@ -215,6 +215,20 @@ int scfq_synth_plan(int kind, uint64_t seed, uint64_t first_record, uint64_t min
   return SCFQ_OK;
 }
 
+int scfq_synth_locate(int kind, uint64_t seed, uint64_t offset, uint64_t* record, uint64_t* record_start) {
+  if (!record || !record_start || (kind != 0 && kind != 1)) return SCFQ_EARG;
+  uint64_t pos = 0, i = 0;
+  for (;;) {
+    const uint64_t len = synth::record_bytes(synth::header(kind, seed, i, nullptr));
+    if (offset < pos + len) break;
+    pos += len;
+    ++i;
+  }
+  *record = i;
+  *record_start = pos;
+  return SCFQ_OK;
+}
+
 int scfq_synth_host(int kind, uint64_t seed, uint64_t first_record, uint64_t records, void* dst, uint64_t cap,
                     scfq_synth_info* info) {
   if (!info || info->struct_size != sizeof(scfq_synth_info) || (kind != 0 && kind != 1)) return SCFQ_EARG;

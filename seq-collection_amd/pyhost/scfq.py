@@ -28,7 +28,7 @@ EXPORTS = [
     "scfq_count_file", "scfq_count_buffer", "scfq_partial_buffer", "scfq_partial_identity",
     "scfq_partial_combine", "scfq_partial_finalize", "scfq_format_tsv", "scfq_strerror",
     "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
-    "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device",
+    "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
 ]
 
 
@@ -109,6 +109,8 @@ def lib():
         for name in ("scfq_synth_host", "scfq_synth_device"):
             getattr(L, name).argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                          ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SynthInfo)]
+        L.scfq_synth_locate.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
+                                        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         _lib = L
     return _lib
 
@@ -238,6 +240,12 @@ def synth_plan(kind, seed, min_bytes, first_record=0):
     info.struct_size = ctypes.sizeof(SynthInfo)
     _check(lib().scfq_synth_plan(kind, seed, first_record, min_bytes, ctypes.byref(info)), "scfq_synth_plan")
     return info
+
+
+def synth_locate(kind, seed, offset):
+    rec, start = ctypes.c_uint64(), ctypes.c_uint64()
+    _check(lib().scfq_synth_locate(kind, seed, offset, ctypes.byref(rec), ctypes.byref(start)), "scfq_synth_locate")
+    return rec.value, start.value
 
 
 def synth_host(kind, seed, records, first_record=0):
