@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes-per-gpu", type=float, default=10e9, help="bytes of FASTQ resident per GPU")
     ap.add_argument("--workload", choices=["illumina", "nanopore"], default="illumina")
-    ap.add_argument("--cpu-sample-bytes", type=float, default=6e9)
+    ap.add_argument("--cpu-sample-bytes", type=float, default=10.1e9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra SCFQ_* flags (1 = qual hist, 2 = struct check)")
     args = ap.parse_args()
@@ -57,6 +57,7 @@ def main():
     import torch
     import torch.distributed as dist
     import scfq
+    import scfq_dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,12 +100,7 @@ def main():
         """C1: rank-ordered fold of all shard partials (ordered monoid, identical result on every rank)."""
         if world == 1:
             return scfq.finalize(p)
-        mine = torch.tensor([x if x < 2**63 else x - 2**64 for x in p.words()], dtype=torch.int64, device=dev)
-        allp = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allp, mine)                      # RCCL over xGMI: world x 256 B, latency-bound
-        acc = scfq.identity()
-        for t in allp:
-            scfq.combine(acc, scfq.Partial.from_words(t.tolist()))
+        acc, _ = scfq_dist.exchange_partials(p, device=dev)   # RCCL all_gather over xGMI: world x 256 B
         return scfq.finalize(acc)
 
     def step():
@@ -139,18 +135,17 @@ def main():
     if world > 1:
         dist.all_reduce(tallies)
     exact = None
-    if world == 1 or True:
-        # records fully generated per rank overlap at cut points, so exact totals are only comparable at N=1;
-        # at N>1 the check is that every rank derived the same folded counters (all_gather + ordered fold)
-        if world == 1:
-            exact = (counts.gc_bases, counts.n_bases, counts.bases, counts.reads) == tuple(tallies.tolist())
-            assert exact, ("scan disagrees with generator tallies", counts.gc_bases, counts.n_bases, counts.bases,
-                           counts.reads, tallies.tolist())
-        else:
-            sig = torch.tensor([counts.reads, counts.gc_bases, counts.n_bases, counts.bases], dtype=torch.int64, device=dev)
-            sigs = [torch.empty_like(sig) for _ in range(world)]
-            dist.all_gather(sigs, sig)
-            assert all(torch.equal(s, sigs[0]) for s in sigs)
+    if world == 1:
+        exact = (counts.gc_bases, counts.n_bases, counts.bases, counts.reads) == tuple(tallies.tolist())
+        assert exact, ("scan disagrees with generator tallies", counts.gc_bases, counts.n_bases, counts.bases,
+                       counts.reads, tallies.tolist())
+    else:
+        # the records generated per rank overlap at the (unaligned) cut points, so generator totals are only
+        # comparable at N=1; at N>1 check that every rank derived the same folded counters
+        sig = torch.tensor([counts.reads, counts.gc_bases, counts.n_bases, counts.bases], dtype=torch.int64, device=dev)
+        sigs = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        assert all(torch.equal(s, sigs[0]) for s in sigs)
 
     total_bases = counts.bases   # bases of the WHOLE job (all ranks' shards folded)
     value = total_bases * args.steps / elapsed / 1e9

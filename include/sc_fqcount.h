@@ -96,6 +96,9 @@ typedef struct scfq_timing {
   double fold_kernel_ms;  /* device time of the partial fold */
   uint64_t scan_bytes;    /* bytes those scan launches covered */
   uint64_t scan_launches;
+  double host_fill_ms;    /* host time spent producing chunks (pread / zlib inflate) during the last ingest */
+  double ingest_wall_ms;  /* wall time of the last chunked ingest (fill + copy + scan, overlapped) */
+  uint64_t h2d_bytes;     /* bytes moved host -> HBM by the last ingest */
 } scfq_timing;
 
 /* ---- whole-input entry points (what a host binds) ---------------------------------------- */

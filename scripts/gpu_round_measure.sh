@@ -1,0 +1,14 @@
+#!/bin/bash
+# Full measurement pass on the GPU box: all -m gpu tests, bench (with cpu baseline), variants, ingest paths, rocprofv3.
+TAG=${1:-r01}
+mkdir -p gpurun_out/$TAG
+python -m pytest tests -q -m gpu 2>&1 | tail -5 | tee gpurun_out/$TAG/pytest_gpu.txt
+python bench.py --steps 30 --warmup 3 2>gpurun_out/$TAG/bench.err | tail -1 | tee gpurun_out/$TAG/bench_n1.json | cut -c1-400
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline --flags 2 2>/dev/null | tail -1 > gpurun_out/$TAG/bench_struct.json
+python bench.py --steps 5 --warmup 1 --no-cpu-baseline --flags 1 2>/dev/null | tail -1 > gpurun_out/$TAG/bench_hist.json
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload nanopore 2>/dev/null | tail -1 > gpurun_out/$TAG/bench_nanopore.json
+python scripts/measure_ingest.py 2e9 /tmp > gpurun_out/$TAG/ingest.jsonl 2>gpurun_out/$TAG/ingest.err
+for f in struct hist nanopore; do python -c "import json;d=json.load(open('gpurun_out/$TAG/bench_$f.json'));print('$f',d['value'],d['roofline'])"; done
+cat gpurun_out/$TAG/ingest.jsonl
+bash scripts/gpu_profile.sh $TAG > gpurun_out/$TAG/profile_summary.txt 2>&1
+grep -E "fq_scan_tiles" gpurun_out/$TAG/profile_summary.txt | head -40

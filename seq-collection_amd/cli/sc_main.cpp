@@ -167,9 +167,11 @@ static void fq_count(const std::string& fastq, bool basename, bool absolute, con
     const double gbs = t.scan_kernel_ms > 0 ? (double)t.scan_bytes / (t.scan_kernel_ms * 1e-3) / 1e9 : 0.0;
     std::fprintf(stderr,
                  "{\"file\": \"%s\", \"input_bytes\": %llu, \"scan_kernel_ms\": %.4f, \"fold_kernel_ms\": %.4f, "
-                 "\"scan_launches\": %llu, \"scan_GBps\": %.1f, \"hbm_peak_GBps\": 8000, \"roofline_frac\": %.4f}\n",
+                 "\"scan_launches\": %llu, \"scan_GBps\": %.1f, \"hbm_peak_GBps\": 8000, \"roofline_frac\": %.4f, "
+                 "\"host_fill_ms\": %.2f, \"ingest_wall_ms\": %.2f, \"h2d_bytes\": %llu}\n",
                  fastq.c_str(), (unsigned long long)c.input_bytes, t.scan_kernel_ms, t.fold_kernel_ms,
-                 (unsigned long long)t.scan_launches, gbs, gbs / 8000.0);
+                 (unsigned long long)t.scan_launches, gbs, gbs / 8000.0, t.host_fill_ms, t.ingest_wall_ms,
+                 (unsigned long long)t.h2d_bytes);
   }
 }
 

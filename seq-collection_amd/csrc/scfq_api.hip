@@ -17,6 +17,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,13 @@ struct Ctx {
   uint64_t stage_cap = 0;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
   scfq_timing timing{};
+  std::mutex mu;   // one counting session at a time per device context
+};
+
+// Serialises sessions that target the same device (e.g. --devices=0,0); distinct devices run concurrently.
+struct SessionLock {
+  std::unique_lock<std::mutex> lk;
+  void acquire(Ctx* c) { lk = std::unique_lock<std::mutex>(c->mu); }
 };
 
 std::mutex g_mu;
@@ -309,12 +317,22 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
   int rc = ensure_staging(c, chunk, true);
   if (rc) return rc;
   int prev = prev_byte;
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
+  double fill_ms = 0;
+  struct Fin {   // record wall time on every exit path
+    Ctx* c; clk::time_point t0; double* fill;
+    ~Fin() { c->timing.host_fill_ms += *fill; c->timing.ingest_wall_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+  } fin{c, t_begin, &fill_ms};
   for (unsigned it = 0;; ++it) {
     const int b = it & 1;
     if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));   // pinned buffer b is free again
+    const auto tf = clk::now();
     int64_t got = src.fill(c->h_pin[b], chunk);
+    fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     if (got < 0) return (int)got;
     if (got == 0) break;
+    c->timing.h2d_bytes += (uint64_t)got;
     if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));   // device buffer b consumed
     HIPCHK(hipMemcpyAsync(c->d_stage[b], c->h_pin[b], (size_t)got, hipMemcpyHostToDevice, c->copy));
     HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
@@ -337,6 +355,8 @@ int partial_on_current_device(const void* ptr, uint64_t n, int is_device, int pr
   if (rc) return rc;
   const uint32_t flags = opt_flags(opts);
   const bool timing = flags & SCFQ_TIMING;
+  SessionLock sl;
+  sl.acquire(c);
   rc = begin_session(c);
   if (rc) return rc;
   if (is_device) {
@@ -447,8 +467,9 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
     gzbuffer(f, 1u << 20);
     if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { gzclose(f); return SCFQ_EHIP; }
     Ctx* c = nullptr;
+    SessionLock sl;
     rc = get_ctx(&c);
-    if (!rc) rc = begin_session(c);
+    if (!rc) { sl.acquire(c); rc = begin_session(c); }
     if (!rc) {
       GzSource src(f);
       rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
@@ -478,8 +499,9 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
         int prev = -1;
         if (lo) { uint8_t pb; if (pread(fd, &pb, 1, (off_t)(lo - 1)) != 1) { rcs[d] = SCFQ_EIO; return; } prev = pb; }
         Ctx* c = nullptr;
+        SessionLock sl;
         int r = get_ctx(&c);
-        if (!r) r = begin_session(c);
+        if (!r) { sl.acquire(c); r = begin_session(c); }
         if (!r) { FdSource src(fd, lo, hi); r = ingest(c, src, prev, o.flags, opt_chunk(&o), timing); }
         if (!r) r = end_session(c, want_hist, &parts[d], want_hist ? hists[d].data() : nullptr);
         rcs[d] = r;
@@ -495,8 +517,9 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
   }
   if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { close(fd); return SCFQ_EHIP; }
   Ctx* c = nullptr;
+  SessionLock sl;
   rc = get_ctx(&c);
-  if (!rc) rc = begin_session(c);
+  if (!rc) { sl.acquire(c); rc = begin_session(c); }
   if (!rc) {
     if (regular) {
       FdSource src(fd, 0, size);
@@ -562,6 +585,8 @@ int scfq_debug_partial_simple(const void* dptr, uint64_t n, int prev_byte, scfq_
   Ctx* c = nullptr;
   int rc = get_ctx(&c);
   if (rc) return rc;
+  SessionLock sl;
+  sl.acquire(c);
   rc = begin_session(c);
   if (rc) return rc;
   if (n) {

@@ -1,0 +1,53 @@
+"""C1 — the cross-rank exchange of shard partials (one process per GPU, torch.distributed; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference is single-process and has no collective; the exchange exists because the input
+is byte-range sharded across GPUs.  The shard combine is ORDERED and non-commutative (the class rotation by the
+left operand's newline count, include/sc_fqcount.h), so a sum-allreduce of final counters would be wrong:
+every rank all_gathers the 32-word partials and performs the same rank-ordered fold.
+Payload: world x 256 B (+ world x 8 KiB with the quality histogram) — latency-bound.
+"""
+import torch
+import torch.distributed as dist
+
+import scfq
+
+_MASK = (1 << 64) - 1
+
+
+def _to_i64(words):
+    return [w - (1 << 64) if w >= (1 << 63) else w for w in words]
+
+
+def _from_i64(vals):
+    return [int(v) & _MASK for v in vals]
+
+
+def shard_bounds(total_bytes, world, rank):
+    """Byte range of `rank`: contiguous, arbitrary (unaligned) cut points, SURVEY.md §8(e)."""
+    return total_bytes * rank // world, total_bytes * (rank + 1) // world
+
+
+def exchange_partials(partial, device=None, group=None, hist=None):
+    """all_gather every rank's partial (and optional [4][256] histogram), fold in rank order.
+
+    Returns (folded Partial, folded hist or None); identical on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return partial, hist
+    mine = torch.tensor(_to_i64(partial.words()), dtype=torch.int64, device=device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    hists = None
+    if hist is not None:
+        hm = torch.tensor(_to_i64(list(hist)), dtype=torch.int64, device=device)
+        hists = [torch.empty_like(hm) for _ in range(world)]
+        dist.all_gather(hists, hm, group=group)
+    acc = scfq.identity()
+    import ctypes
+    acc_h = (ctypes.c_uint64 * scfq.HIST_WORDS)() if hist is not None else None
+    for r in range(world):
+        p = scfq.Partial.from_words(_from_i64(gathered[r].tolist()))
+        h = (ctypes.c_uint64 * scfq.HIST_WORDS)(*_from_i64(hists[r].tolist())) if hist is not None else None
+        scfq.combine(acc, p, acc_h, h)
+    return acc, acc_h

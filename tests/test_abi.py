@@ -1,0 +1,110 @@
+"""The C-ABI library loads, exports every symbol include/*.h declares, and its host-side logic (partial monoid,
+finalisation, formatting, synthetic generator) is exact.  No device compute is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_rows
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "sc_fqcount.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(scfq_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_exports_every_declared_symbol(scfq):
+    L = scfq.lib()
+    names = declared_functions()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(names) == set(scfq.EXPORTS)
+
+
+def test_struct_layouts(scfq):
+    assert ctypes.sizeof(scfq.Counts) == 8 * (11 + 256)
+    assert ctypes.sizeof(scfq.Partial) == 8 * 32
+    assert ctypes.sizeof(scfq.Opts) == 40
+    assert scfq.Partial.gc.offset == 8 and scfq.Partial.len.offset == 72 and scfq.Partial.bytes.offset == 200
+
+
+def test_no_gpu_means_loud_failure(scfq):
+    """the product has no CPU fallback: without a device the counting entry points return SCFQ_EHIP"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(scfq.ScfqError) as e:
+        scfq.count_host(b"@a\nACGT\n+\nIIII\n")
+    assert e.value.rc == scfq.SCFQ_EHIP
+    with pytest.raises(scfq.ScfqError) as e:
+        scfq.count_file(os.path.join(ROOT, "tests", "golden", "dup.fq"))
+    assert e.value.rc == scfq.SCFQ_EHIP
+
+
+def test_open_errors_and_arg_checks(scfq, tmp_path):
+    with pytest.raises(scfq.ScfqError) as e:
+        scfq.count_file(str(tmp_path / "nope.fq"))
+    assert e.value.rc == scfq.SCFQ_EOPEN
+    with pytest.raises(scfq.ScfqError) as e:
+        scfq.count_file(str(tmp_path / "nope.fq.gz"))
+    assert e.value.rc == scfq.SCFQ_EOPEN
+    c = scfq.Counts()   # struct_size not set
+    rc = scfq.lib().scfq_count_buffer(None, 0, 0, None, ctypes.byref(c))
+    assert rc == scfq.SCFQ_EARG
+    assert scfq.strerror(scfq.SCFQ_EOPEN) == "unable to open file"
+
+
+def test_host_fold_matches_oracle(scfq, oracle):
+    """scfq_partial_combine / scfq_partial_finalize / scfq_format_tsv (product host code) on oracle shard partials"""
+    rng = np.random.default_rng(9)
+    alphabet = np.frombuffer(b"ACGTN@+I\r\n\n", dtype=np.uint8)
+    for trial in range(100):
+        n = int(rng.integers(0, 2000))
+        data = rng.choice(alphabet, n).astype(np.uint8)
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, 5)]))
+        acc = scfq.identity()
+        hacc = (ctypes.c_uint64 * scfq.HIST_WORDS)()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            w, h = oracle.partial(data[a:b], int(data[a - 1]) if a else -1, want_hist=True)
+            scfq.combine(acc, scfq.Partial.from_words(w + [0] * 5), hacc, (ctypes.c_uint64 * scfq.HIST_WORDS)(*h))
+        c = scfq.finalize(acc, hacc)
+        oc = oracle.count(data, "bytes")
+        for f in ("reads", "gc_bases", "n_bases", "bases", "lines", "newlines", "input_bytes", "bad_at", "bad_plus"):
+            assert getattr(c, f) == getattr(oc, f), (trial, f)
+        assert list(c.qual_hist) == list(oc.qual_hist)
+        assert scfq.format_tsv(c) == oracle.tsv(oc)
+
+
+def test_format_rule_against_golden_table(scfq):
+    """gc_content text: Nim 1.0.6 `$float` = "%.16g" + ".0" rule, "nan" for 0/0 (src/fq_count.nim:48)"""
+    for row in golden_rows():
+        c = scfq.Counts()
+        c.struct_size = ctypes.sizeof(scfq.Counts)
+        c.reads, c.gc_bases, c.n_bases, c.bases = row["reads"], row["gc_bases"], row["n_bases"], row["bases"]
+        assert scfq.format_tsv(c) == "%d\t%s\t%d\t%d\t%d" % (row["reads"], row["gc_content"], row["gc_bases"], row["n_bases"], row["bases"])
+
+
+def test_synthetic_generator_host(scfq, oracle):
+    for kind, seed in ((0, 20260101), (1, 20260103)):
+        plan = scfq.synth_plan(kind, seed, 2_000_000)
+        data, info = scfq.synth_host(kind, seed, plan.records)
+        assert info.bytes == plan.bytes == data.size and plan.bytes >= 2_000_000
+        oc = oracle.count(data, "lines")
+        assert (oc.reads, oc.gc_bases, oc.n_bases, oc.bases) == (plan.records, info.gc_bases, info.n_bases, info.bases)
+        ob = oracle.count(data, "bytes")
+        assert ob.bad_at == 0 and ob.bad_plus == 0
+        # any slice of the stream can be produced independently and located by byte offset
+        rec, start = scfq.synth_locate(kind, seed, plan.bytes // 2)
+        part, pinfo = scfq.synth_host(kind, seed, 3, first_record=rec)
+        assert np.array_equal(part, data[start:start + part.size])
+    # Illumina shape: 150 bp reads, mean record ~359.5 B, N fraction ~0.002, GC ~0.41
+    plan = scfq.synth_plan(0, 20260101, 4_000_000)
+    data, info = scfq.synth_host(0, 20260101, plan.records)
+    assert info.bases == 150 * plan.records
+    assert 359.0 < plan.bytes / plan.records < 360.0
+    assert 0.0015 < info.n_bases / info.bases < 0.0025
+    assert 0.40 < info.gc_bases / info.bases < 0.42

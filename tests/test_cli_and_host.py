@@ -1,0 +1,86 @@
+"""Host side above the C ABI: the C++ `sc fq-count` CLI and the Python mirror of the reference operator
+(sc.nim:103-116, src/fq_count.nim:14-53, src/utils/helpers.nim:29-34,200-224)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, PKG, golden_rows
+
+SC = os.path.join(PKG, "sc")
+HEADER = "reads\tgc_content\tgc_bases\tn_bases\tbases"
+
+
+def run(*args, cwd=None):
+    return subprocess.run([SC] + list(args), capture_output=True, text=True, cwd=cwd, stdin=subprocess.DEVNULL)
+
+
+def test_header_only_modes():
+    assert os.path.exists(SC), "build the CLI first: make -C seq-collection_amd"
+    r = run("fq-count", "-t")
+    assert (r.returncode, r.stdout) == (0, HEADER + "\n")           # sc.nim:110-111: header, no "No FASTQ" error
+    assert run("fq-count", "--header", "-b").stdout == HEADER + "\tbasename\n"
+    assert run("fq-count", "-t", "-a").stdout == HEADER + "\tabsolute\n"
+    assert run("fq-count", "-tba").stdout == HEADER + "\tbasename\tabsolute\n"
+
+
+def test_error_paths():
+    r = run("fq-count", "-b")
+    assert r.returncode == 3 and r.stderr == "\x1b[31mError 3: No FASTQ specified\x1b[0m\n"   # sc.nim:112-113
+    r = run("fq-count", "does_not_exist.fq")
+    assert r.returncode == 2 and r.stderr == "\x1b[31mError 2: Unable to open file: does_not_exist.fq\x1b[0m\n"
+    assert r.stdout == ""
+    r = run("fq-count", "missing.fq.gz")
+    assert r.returncode == 1 and "missing.fq.gz" in r.stderr      # .gz constructor raises -> generic funnel, exit 1
+    r = run("fq-count", "ab")
+    assert r.returncode == 1                                        # fastq[^3 .. ^1] on a 2-char path
+    r = run("fq-count", "--bogus")
+    assert r.returncode == 1 and "Unknown option" in r.stderr
+    r = run("fq-count", "-h")
+    assert r.returncode == 0 and "Counts lines in a FASTQ" in r.stdout and "[fastq ...]      Input FASTQ" in r.stdout
+    assert run("fq-count").stdout.startswith("Counts lines in a FASTQ")    # sc.nim:288-290
+    assert run().returncode == 0
+
+
+def test_python_mirror_helpers(scfq, tmp_path, monkeypatch):
+    assert scfq.fq_count_header == HEADER
+    assert scfq.output_header(HEADER, True, True) == HEADER + "\tbasename\tabsolute"
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "d").mkdir()
+    f = tmp_path / "d" / "x.fq"
+    f.write_bytes(b"@a\nAC\n+\nII\n")
+    assert scfq.output_w_fnames("row", "d/x.fq", True, False) == "row\tx.fq"
+    assert scfq.output_w_fnames("row", "d/x.fq", True, True) == "row\tx.fq\t" + str(f)
+    assert scfq.output_w_fnames("row", str(f), False, True) == "row\t" + str(f)
+    os.symlink("d/x.fq", tmp_path / "ln.fq")
+    assert scfq.get_absolute("ln.fq") == str(f)                     # helpers.nim:210-213
+    assert scfq.last_path_part("a/b/") == "b"
+    with pytest.raises(SystemExit) as e:
+        scfq.fq_count(str(tmp_path / "nope.fq"))
+    assert e.value.code == 2
+    with pytest.raises(IndexError):
+        scfq.fq_count("ab")
+
+
+@pytest.mark.gpu
+def test_cli_rows_match_reference_table(gpu):
+    """`sc fq-count --header -b <all fixtures>` reproduces the reference's docs/fq-count.md table"""
+    rows = [r for r in golden_rows() if r["source"].startswith("reference:")]
+    files = [r["name"] for r in rows]
+    r = run("fq-count", "--header", "-b", *files, cwd=GOLDEN)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.rstrip("\n").split("\n")
+    assert lines[0] == HEADER + "\tbasename"
+    for row, line in zip(rows, lines[1:]):
+        assert line == "%d\t%s\t%d\t%d\t%d\t%s" % (row["reads"], row["gc_content"], row["gc_bases"], row["n_bases"], row["bases"], row["name"])
+    r = run("fq-count", "-a", "--struct-check", "--qual-hist", "--stats", "sra.fq", cwd=GOLDEN)
+    assert r.stdout == "2\t0.4305555555555556\t62\t0\t144\t" + os.path.join(GOLDEN, "sra.fq") + "\n"
+    assert "bad_at=0\tbad_plus=0" in r.stderr and "scan_kernel_ms" in r.stderr
+
+
+@pytest.mark.gpu
+def test_python_mirror_fq_count(gpu, scfq, capsys):
+    for row in golden_rows():
+        scfq.fq_count(os.path.join(GOLDEN, row["name"]), basename=True)
+        out = capsys.readouterr().out
+        assert out == "%d\t%s\t%d\t%d\t%d\t%s\n" % (row["reads"], row["gc_content"], row["gc_bases"], row["n_bases"], row["bases"], os.path.basename(row["name"]))
