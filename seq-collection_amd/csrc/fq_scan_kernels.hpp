@@ -27,7 +27,7 @@ namespace scfq {
 
 constexpr int kTile = 4096;          // bytes per wave-iteration (64 lanes x 64 B)
 constexpr int kWavesPerBlock = 4;
-constexpr int kRing = 3;             // LDS ring slots per wave (1 consumed + 2 in flight)
+constexpr int kRing = 2;             // default LDS ring slots per wave (1 being consumed + 1 in flight)
 constexpr int kPartialWords = 32;    // == SCFQ_PARTIAL_WORDS
 constexpr uint32_t kMaxTilesPerRange = 960;  // 16-bit per-lane class fields: 64 B/tile * 960 < 65536
 
@@ -72,21 +72,38 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {
 // loads are invisible to its bookkeeping and are retired by our own counted s_waitcnt vmcnt(N).
 // The leading lgkmcnt(0) retires this wave's earlier ds_reads of the slot being overwritten.
 // ------------------------------------------------------------------------------------------------
+template <bool NT>
 __device__ __forceinline__ void glds_tile(const uint8_t* lane_src, uint32_t lds_slot_addr) {
   uint32_t keep;
-  asm volatile(
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(lane_src), "s"(lds_slot_addr)
-      : "memory");
+  if (NT) {   // non-temporal: the stream is read exactly once
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024 nt\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048 nt\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_src), "s"(lds_slot_addr)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_src), "s"(lds_slot_addr)
+        : "memory");
+  }
 }
 
 // edge tiles: every piece has its own (clamped) source address; still exactly 4 VMEM ops
@@ -166,42 +183,48 @@ __device__ __forceinline__ void masks32(const uint32_t* d, uint32_t& nl, uint32_
   nl = ~wnl; gc = ~wgc; nn = ~wnn; at = ~wat; pl = ~wpl;
 }
 
-// ---- hand-scheduled ASCII form (the VALU-bound hot path; every op here is paid 64 x per tile) ------
-// v_xad_u32 fuses the xor with the carry-generating add; v_and_or_b32 fuses mask + merge:
-//   '\n', 'N' : xad, lshr, and_or            = 3 VALU per dword
-//   G|C       : bitop3 (xor,and), add, lshr, and_or = 4 VALU per dword
+// ---- hand-scheduled ASCII form (the hot path; every op here is paid 64 x per tile) ---------------
+// Classifier: v_perm_b32 used as a byte-wise zero test.  A selector byte of 12 yields 0x00 and one
+// >= 13 yields 0xFF, so with t = b ^ c (<= 0x7F for ASCII) the selector t + 12 gives 0x00 exactly when
+// b == c and 0xFF otherwise: one v_xad_u32 (xor + add) and one v_perm_b32 per dword, and because
+// the result bytes are clean 0x00 / 0xFF no shift is needed to drop the flag of dword j onto
+// mask bit j: a v_bfi_b32 chain does it (7 per 8 dwords).  For G|C the selector is t = (b ^ 'C') & ~4
+// itself: 0 only for 'C'/'G' (-> source byte 0 = 0x00), never 12 (bit 2 is cleared), everything
+// else reads 0xFF (source bytes 1..7, their sign bits for 8..11, fixed 0xFF for >= 13).
+// Masks come out INVERTED (bit set = no match); consumers fold the complement into their bit ops.
 __device__ __forceinline__ uint32_t v_xad(uint32_t x, uint32_t c, uint32_t k) {
   uint32_t r;
   asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(k));
   return r;
 }
-__device__ __forceinline__ uint32_t v_and_or(uint32_t a, uint32_t m, uint32_t c) {
+__device__ __forceinline__ uint32_t v_bfi(uint32_t mask, uint32_t a, uint32_t b) {   // (a & mask) | (b & ~mask)
   uint32_t r;
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(c));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ uint32_t byte_nonzero_ff(uint32_t sel) {
+  return __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFF00u, sel);
+}
 
-__device__ __forceinline__ void masks32_ascii(const uint32_t* d, uint32_t k7f, uint32_t& nl, uint32_t& gc, uint32_t& nn) {
+__device__ __forceinline__ void masks32_ascii(const uint32_t* d, uint32_t k12, uint32_t& wnl, uint32_t& wgc, uint32_t& wnn) {
   uint32_t x[8];
   transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
   transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
-  uint32_t wnl = 0, wgc = 0, wnn = 0;
+  wnl = byte_nonzero_ff(v_xad(x[7], 0x0A0A0A0Au, k12));
+  wgc = byte_nonzero_ff((x[7] ^ 0x43434343u) & 0xFBFBFBFBu);
+  wnn = byte_nonzero_ff(v_xad(x[7], 0x4E4E4E4Eu, k12));
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 6; j >= 0; --j) {
     const uint32_t sel = 0x01010101u << j;
     const uint32_t v = x[j];
-    uint32_t e;
-    e = v_xad(v, 0x0A0A0A0Au, k7f);
-    if (j != 7) e >>= (7 - j);
-    wnl = (j == 0) ? (e & sel) : v_and_or(e, sel, wnl);
-    e = ((v ^ 0x43434343u) & 0xFBFBFBFBu) + 0x7F7F7F7Fu;      // (b ^ 'C') & ~4 == 0  <=>  b in {'C','G'}
-    if (j != 7) e >>= (7 - j);
-    wgc = (j == 0) ? (e & sel) : v_and_or(e, sel, wgc);
-    e = v_xad(v, 0x4E4E4E4Eu, k7f);
-    if (j != 7) e >>= (7 - j);
-    wnn = (j == 0) ? (e & sel) : v_and_or(e, sel, wnn);
+    uint32_t r;
+    r = byte_nonzero_ff(v_xad(v, 0x0A0A0A0Au, k12));
+    wnl = v_bfi(sel, r, wnl);
+    r = byte_nonzero_ff((v ^ 0x43434343u) & 0xFBFBFBFBu);
+    wgc = v_bfi(sel, r, wgc);
+    r = byte_nonzero_ff(v_xad(v, 0x4E4E4E4Eu, k12));
+    wnn = v_bfi(sel, r, wnn);
   }
-  nl = ~wnl; gc = ~wgc; nn = ~wnn;
 }
 
 struct Masks {
@@ -236,10 +259,22 @@ struct Acc16 {
 
 struct WaveState {
   Acc16 gc, nn, len, crlf, starts, fat, fplus;
+  uint32_t p_gc, p_nn, p_len, p_crlf;   // 8-bit x 4-class fields of up to 3 tiles, not yet widened
+  uint32_t pending;                     // wave-uniform: tiles accumulated in p_*
   uint32_t phase;      // wave-uniform: newlines seen so far in this range, mod 4
   uint32_t nl_total;   // wave-uniform: newlines seen so far in this range
   int32_t prev_last;   // wave-uniform: byte before the next tile (-1: none / start of input)
 };
+
+// widen the pending 8-bit fields into the 16-bit per-lane accumulators (at most every 3rd tile: 3 x 64 < 256)
+__device__ __forceinline__ void flush_pending(WaveState& st) {
+  st.gc.add_tile8(st.p_gc);
+  st.nn.add_tile8(st.p_nn);
+  st.len.add_tile8(st.p_len);
+  st.crlf.add_tile8(st.p_crlf);
+  st.p_gc = st.p_nn = st.p_len = st.p_crlf = 0;
+  st.pending = 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // one 4 KiB tile, already resident in this wave's LDS slot
@@ -341,10 +376,8 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
     if (__builtin_amdgcn_ballot_w64(has_nl) == 0) break;   // every lane has consumed its last segment
   }
 
-  st.gc.add_tile8(t_gc);
-  st.nn.add_tile8(t_nn);
-  st.len.add_tile8(t_len);
-  st.crlf.add_tile8(t_crlf);
+  st.p_gc += t_gc; st.p_nn += t_nn; st.p_len += t_len; st.p_crlf += t_crlf;
+  if (++st.pending == 3) flush_pending(st);
   if (STRUCT) { st.starts.add_tile8(t_st); st.fat.add_tile8(t_fat); st.fplus.add_tile8(t_fpl); }
   st.phase = (st.phase + total) & 3u;
   st.nl_total += total;
@@ -364,20 +397,21 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
                     q2v.x, q2v.y, q2v.z, q2v.w, q3v.x, q3v.y, q3v.z, q3v.w};
   const uint32_t hb = (d[0] | d[1] | d[2]) | (d[3] | d[4] | d[5]) | (d[6] | d[7] | d[8]) |
                       (d[9] | d[10] | d[11]) | (d[12] | d[13] | d[14]) | d[15];
-  uint64_t NL, GC, NN;
+  uint64_t WNL, WGC, WNN;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N'
   if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0) {
     uint32_t a0, a1, a2, b0, b1, b2;
-    uint32_t k7f = 0x7F7F7F7Fu;
-    asm("" : "+v"(k7f));   // keep the constant in a VGPR (the VOP3 forms take one SGPR source only)
-    masks32_ascii(d, k7f, a0, a1, a2);
-    masks32_ascii(d + 8, k7f, b0, b1, b2);
-    NL = (uint64_t)a0 | ((uint64_t)b0 << 32);
-    GC = (uint64_t)a1 | ((uint64_t)b1 << 32);
-    NN = (uint64_t)a2 | ((uint64_t)b2 << 32);
+    uint32_t k12 = 0x0C0C0C0Cu;
+    asm("" : "+v"(k12));   // keep the constant in a VGPR (v_xad_u32 takes a single SGPR source)
+    masks32_ascii(d, k12, a0, a1, a2);
+    masks32_ascii(d + 8, k12, b0, b1, b2);
+    WNL = (uint64_t)a0 | ((uint64_t)b0 << 32);
+    WGC = (uint64_t)a1 | ((uint64_t)b1 << 32);
+    WNN = (uint64_t)a2 | ((uint64_t)b2 << 32);
   } else {
     const Masks m = masks64<false, false>(d);
-    NL = m.nl; GC = m.gc; NN = m.nn;
+    WNL = ~m.nl; WGC = ~m.gc; WNN = ~m.nn;
   }
+  const uint64_t NL = ~WNL;
 
   const uint32_t cnt = popc64(NL);
   const uint32_t incl = wave_inclusive_scan(cnt);
@@ -386,29 +420,24 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
 
   // first segment: everything below the first newline (the whole lane when there is none)
   const uint64_t xm1 = NL - 1;
-  const uint64_t below = ~NL & xm1;
-  const uint32_t q0 = popc64(below);
-  uint32_t t_len = q0 << sh0;
-  uint32_t t_gc = popc64(GC & below) << sh0;
-  uint32_t t_nn = popc64(NN & below) << sh0;
-  uint32_t t_crlf = 0;
+  const uint64_t below = WNL & xm1;
+  uint32_t s_len = popc64(below);                 // running sums over the segments handled so far
+  uint32_t s_gc = popc64(below & ~WGC);
+  uint32_t s_nn = popc64(below & ~WNN);
+  uint32_t t_len = st.p_len + (s_len << sh0);
+  uint32_t t_gc = st.p_gc + (s_gc << sh0);
+  uint32_t t_nn = st.p_nn + (s_nn << sh0);
+  uint32_t t_crlf = st.p_crlf;
 
   if (total != 0) {   // wave-uniform: some lane of this tile holds a newline
     const int lane_base = lane * 64;
     const bool has1 = (NL != 0);
     {   // '\r' directly before the first newline?
-      const int idx = lane_base + (int)q0 - 1;
+      const int idx = lane_base + (int)s_len - 1;
       int pb = slot[has1 ? (idx < 0 ? 0 : idx) : lane * 4];   // newline-free lanes read a bank-spread dummy
       if (idx < 0) pb = st.prev_last;
-      t_crlf = ((has1 && pb == '\r') ? 1u : 0u) << sh0;
+      t_crlf += ((has1 && pb == '\r') ? 1u : 0u) << sh0;
     }
-    // last segment: bits above the highest newline (empty for newline-free lanes: "& ~below")
-    const uint64_t xr = __builtin_bitreverse64(NL);
-    const uint64_t above = __builtin_bitreverse64(~xr & (xr - 1)) & ~below;
-    const uint32_t shl = (sh0 + cnt * 8u) & 31u;
-    t_len += popc64(above) << shl;
-    t_gc += popc64(GC & above) << shl;
-    t_nn += popc64(NN & above) << shl;
     // middle segments: between consecutive newlines of one lane
     uint64_t xc = NL, xcm1 = xm1;
     uint32_t sh = sh0;
@@ -418,22 +447,27 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       if (__builtin_amdgcn_ballot_w64(has2) == 0) break;
       const uint64_t x1m1 = x1 - 1;
       const uint64_t below1 = ~x1 & x1m1;
-      const uint64_t seg = below1 & ~(xc ^ xcm1) & ~above;   // "& ~above" empties lanes whose next segment is their last
+      uint64_t seg = below1 & ~(xc ^ xcm1);        // strictly between the two lowest remaining newlines
+      seg = has2 ? seg : 0;                        // lanes whose next segment is their last one are handled below
       sh = (sh + 8u) & 31u;
-      t_len += popc64(seg) << sh;
-      t_gc += popc64(GC & seg) << sh;
-      t_nn += popc64(NN & seg) << sh;
-      const int idx = lane_base + (int)popc64(below1) - 1;     // >= 0: the second newline of a lane is never at bit 0
+      const uint32_t m_len = popc64(seg), m_gc = popc64(seg & ~WGC), m_nn = popc64(seg & ~WNN);
+      t_len += m_len << sh; t_gc += m_gc << sh; t_nn += m_nn << sh;
+      s_len += m_len; s_gc += m_gc; s_nn += m_nn;
+      const int idx = lane_base + (int)popc64(below1) - 1;     // >= 0: a lane's second newline is never at bit 0
       const int pb = slot[has2 ? idx : lane * 4];
       t_crlf += ((has2 && pb == '\r') ? 1u : 0u) << sh;
       xc = x1; xcm1 = x1m1;
     }
+    // last segment by complement: what lies above the highest newline = lane totals - segments counted so far
+    // (newline-free lanes: totals == first segment, so this adds 0)
+    const uint32_t shl = (sh0 + cnt * 8u) & 31u;
+    t_len += (64u - cnt - s_len) << shl;
+    t_gc += (64u - popc64(WGC) - s_gc) << shl;
+    t_nn += (64u - popc64(WNN) - s_nn) << shl;
   }
 
-  st.gc.add_tile8(t_gc);
-  st.nn.add_tile8(t_nn);
-  st.len.add_tile8(t_len);
-  st.crlf.add_tile8(t_crlf);
+  st.p_len = t_len; st.p_gc = t_gc; st.p_nn = t_nn; st.p_crlf = t_crlf;
+  if (++st.pending == 3) flush_pending(st);
   st.phase = (st.phase + total) & 3u;
   st.nl_total += total;
   st.prev_last = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)d[15], 63) >> 24);
@@ -452,15 +486,17 @@ struct ScanArgs {
   uint32_t* hist_partials; // [n_ranges][4][256] u32, HIST only
 };
 
-template <bool STRUCT, bool HIST>
+// RING = LDS ring slots per wave (1 being consumed + RING-1 in flight); NT = non-temporal DMA loads
+template <bool STRUCT, bool HIST, int RING = kRing, bool NT = true>
 __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
+  static_assert(RING >= 2 && RING <= 4, "ring depth");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t* ring = smem + wave * (kRing * kTile);
+  uint8_t* ring = smem + wave * (RING * kTile);
   uint32_t* hist_lds = nullptr;
   if (HIST) {
-    hist_lds = reinterpret_cast<uint32_t*>(smem + kWavesPerBlock * kRing * kTile) + wave * 1024;
+    hist_lds = reinterpret_cast<uint32_t*>(smem + kWavesPerBlock * RING * kTile) + wave * 1024;
     for (int k = lane; k < 1024; k += 64) hist_lds[k] = 0;
   }
   const uint64_t range = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -468,10 +504,10 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
 
   const uint64_t B = (uint64_t)(uintptr_t)a.base, E = B + a.n;
   const uint64_t A0 = B & ~(uint64_t)(kTile - 1);
-  const uint64_t NT = (E - A0 + kTile - 1) / kTile;
+  const uint64_t n_tiles = (E - A0 + kTile - 1) / kTile;
   const uint64_t t_begin = range * a.tiles_per_range;
   uint64_t t_end = t_begin + a.tiles_per_range;
-  if (t_end > NT) t_end = NT;
+  if (t_end > n_tiles) t_end = n_tiles;
 
   // Both halo bytes are fetched and pinned into SGPRs BEFORE the first LDS-DMA is issued: a
   // compiler-visible load whose first use sat inside the tile loop made hipcc emit s_waitcnt vmcnt(0)
@@ -492,7 +528,7 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
     const uint64_t ts = A0 + t * kTile;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + slot * kTile));
     if (ts >= B && ts + kTile <= E) {
-      glds_tile(reinterpret_cast<const uint8_t*>(ts + (uint64_t)lane * 16), dst);
+      glds_tile<NT>(reinterpret_cast<const uint8_t*>(ts + (uint64_t)lane * 16), dst);
     } else {
       // pieces with no valid byte are redirected to a 16 B piece that is certainly readable
       const uint64_t safe = (B & ~15ull);
@@ -508,15 +544,20 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
     }
   };
 
-  // prologue: two tiles in flight
-  if (t_begin < t_end) issue(t_begin, 0);
-  if (t_begin + 1 < t_end) issue(t_begin + 1, 1);
+  // prologue: RING-1 tiles in flight
+#pragma unroll
+  for (int k = 0; k < RING - 1; ++k)
+    if (t_begin + k < t_end) issue(t_begin + k, k);
 
   uint32_t slot = 0;
   for (uint64_t t = t_begin; t < t_end; ++t) {
-    const uint32_t s2 = (slot >= 1) ? slot - 1 : 2;      // (slot + 2) % 3
-    if (t + 2 < t_end) { issue(t + 2, s2); wait_vmcnt<8>(); }
-    else if (t + 1 < t_end) wait_vmcnt<4>();
+    const uint32_t s2 = (slot >= 1) ? slot - 1 : RING - 1;      // (slot + RING - 1) % RING: the slot consumed last
+    if (t + (RING - 1) < t_end) issue(t + (RING - 1), s2);
+    // retire tile t: everything issued after it may stay in flight (4 DMA instructions per tile)
+    const uint64_t after = t_end - 1 - t;
+    if (after >= (uint64_t)(RING - 1)) wait_vmcnt<4 * (RING - 1)>();
+    else if (RING > 3 && after == 2) wait_vmcnt<8>();
+    else if (RING > 2 && after == 1) wait_vmcnt<4>();
     else wait_vmcnt<0>();
 
     const uint8_t* sl = ring + slot * kTile;
@@ -536,9 +577,10 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
       const int64_t first_valid = (B >= ts) ? (int64_t)(B - ts) : -1;   // tile-local position of input byte 0
       process_tile<true, STRUCT, HIST>(sl, lane, V, first_valid, prev_param, st, hist_lds);
     }
-    slot = (slot == 2) ? 0 : slot + 1;
+    slot = (slot == RING - 1) ? 0 : slot + 1;
   }
 
+  flush_pending(st);
   // ---- range partial: reduce the per-lane 16-bit fields across the wave, lane 0 stores --------
   uint64_t* out = a.partials + range * kPartialWords;
   auto sum4 = [&](const Acc16& acc) {

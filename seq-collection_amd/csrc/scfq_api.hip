@@ -167,9 +167,17 @@ uint32_t pick_tiles_per_range(const Ctx* c, uint64_t n_tiles) {
   return (uint32_t)tpr;
 }
 
-template <bool S, bool H>
-void launch_scan(const scfq::ScanArgs& a, unsigned blocks, unsigned lds, hipStream_t st) {
-  hipLaunchKernelGGL((scfq::fq_scan_tiles<S, H>), dim3(blocks), dim3(256), lds, st, a);
+template <bool S, bool H, int RING, bool NT>
+void launch_scan(const scfq::ScanArgs& a, unsigned blocks, hipStream_t st) {
+  unsigned lds = scfq::kWavesPerBlock * RING * scfq::kTile;
+  if (H) lds += scfq::kWavesPerBlock * 1024 * sizeof(uint32_t);
+  hipLaunchKernelGGL((scfq::fq_scan_tiles<S, H, RING, NT>), dim3(blocks), dim3(256), lds, st, a);
+}
+
+// tuning knobs (defaults are the measured best): SCFQ_RING = 2|3|4 LDS ring slots per wave, SCFQ_NT = 0|1
+int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
 }
 
 // Enqueue scan + fold of one device-resident range onto the compute stream. State accumulates.
@@ -191,13 +199,20 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
   a.partials = c->d_partials;
   a.hist_partials = c->d_hist_partials;
   const unsigned blocks = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
-  unsigned lds = scfq::kWavesPerBlock * scfq::kRing * scfq::kTile;
-  if (hist) lds += scfq::kWavesPerBlock * 1024 * sizeof(uint32_t);
   if (timing) HIPCHK(hipEventRecord(c->ev_t0, c->compute));
-  if (hist && strct) launch_scan<true, true>(a, blocks, lds, c->compute);
-  else if (hist) launch_scan<false, true>(a, blocks, lds, c->compute);
-  else if (strct) launch_scan<true, false>(a, blocks, lds, c->compute);
-  else launch_scan<false, false>(a, blocks, lds, c->compute);
+  if (hist && strct) launch_scan<true, true, 2, true>(a, blocks, c->compute);
+  else if (hist) launch_scan<false, true, 2, true>(a, blocks, c->compute);
+  else if (strct) launch_scan<true, false, 2, true>(a, blocks, c->compute);
+  else {
+    // measured on MI355X (10 GB Illumina): ring 2 + nt 6.36 TB/s, ring 3 + nt 6.23, ring 2 5.91, ring 3 5.87
+    static const int ring = env_int("SCFQ_RING", 2), nt = env_int("SCFQ_NT", 1);
+    if (ring == 2 && nt) launch_scan<false, false, 2, true>(a, blocks, c->compute);
+    else if (ring == 2) launch_scan<false, false, 2, false>(a, blocks, c->compute);
+    else if (ring == 4 && nt) launch_scan<false, false, 4, true>(a, blocks, c->compute);
+    else if (ring == 4) launch_scan<false, false, 4, false>(a, blocks, c->compute);
+    else if (nt) launch_scan<false, false, 3, true>(a, blocks, c->compute);
+    else launch_scan<false, false, 3, false>(a, blocks, c->compute);
+  }
   HIPCHK(hipGetLastError());
   if (timing) HIPCHK(hipEventRecord(c->ev_t1, c->compute));
   {

@@ -12,8 +12,21 @@ sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _ensure_built():
+    """hipcc cross-compiles gfx950 without a GPU: (re)build the product library + CLI when missing or stale."""
+    lib = os.path.join(PKG, "libsc_fqcount_hip.so")
+    srcs = [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc"))] + \
+           [os.path.join(PKG, "cli", "sc_main.cpp"), os.path.join(ROOT, "include", "sc_fqcount.h")]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    for target in (lib, os.path.join(PKG, "sc")):
+        if not os.path.exists(target) or os.path.getmtime(target) < newest:
+            subprocess.check_call(["make", "-C", PKG], stdout=subprocess.DEVNULL)
+            break
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_built()
 
 
 class OracleCounts(ctypes.Structure):
