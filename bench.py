@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--cpu-sample-bytes", type=float, default=10.1e9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra SCFQ_* flags (1 = qual hist, 2 = struct check)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo backend); the number is not a scaling result")
     args = ap.parse_args()
 
     import torch
@@ -65,10 +68,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if args.backend == "nccl" else None     # gloo exchanges CPU tensors
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
     kind = 0 if args.workload == "illumina" else 1
@@ -100,7 +109,7 @@ def main():
         """C1: rank-ordered fold of all shard partials (ordered monoid, identical result on every rank)."""
         if world == 1:
             return scfq.finalize(p)
-        acc, _ = scfq_dist.exchange_partials(p, device=dev)   # RCCL all_gather over xGMI: world x 256 B
+        acc, _ = scfq_dist.exchange_partials(p, device=xdev)   # RCCL all_gather over xGMI: world x 256 B
         return scfq.finalize(acc)
 
     def step():
@@ -126,26 +135,23 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
     # ---- correctness outside the timed region: generator tallies (independent of the scan) -------------
-    tallies = torch.tensor([info.gc_bases, info.n_bases, info.bases, info.records], dtype=torch.int64, device=dev)
+    # a rank owns the records that START inside its byte range; the record straddling its lower cut point
+    # (generated here too, because the shard begins inside it) is tallied by the previous rank
+    own = [info.gc_bases, info.n_bases, info.bases, info.records]
+    if first_start < lo:
+        _, head = scfq.synth_host(kind, seed, 1, first_record=first_rec)
+        own = [own[0] - head.gc_bases, own[1] - head.n_bases, own[2] - head.bases, own[3] - 1]
+    tallies = torch.tensor(own, dtype=torch.int64, device=xdev)
     if world > 1:
         dist.all_reduce(tallies)
-    exact = None
-    if world == 1:
-        exact = (counts.gc_bases, counts.n_bases, counts.bases, counts.reads) == tuple(tallies.tolist())
-        assert exact, ("scan disagrees with generator tallies", counts.gc_bases, counts.n_bases, counts.bases,
-                       counts.reads, tallies.tolist())
-    else:
-        # the records generated per rank overlap at the (unaligned) cut points, so generator totals are only
-        # comparable at N=1; at N>1 check that every rank derived the same folded counters
-        sig = torch.tensor([counts.reads, counts.gc_bases, counts.n_bases, counts.bases], dtype=torch.int64, device=dev)
-        sigs = [torch.empty_like(sig) for _ in range(world)]
-        dist.all_gather(sigs, sig)
-        assert all(torch.equal(s, sigs[0]) for s in sigs)
+    exact = (counts.gc_bases, counts.n_bases, counts.bases, counts.reads) == tuple(tallies.tolist())
+    assert exact, ("scan disagrees with generator tallies", counts.gc_bases, counts.n_bases, counts.bases,
+                   counts.reads, tallies.tolist())
 
     total_bases = counts.bases   # bases of the WHOLE job (all ranks' shards folded)
     value = total_bases * args.steps / elapsed / 1e9
@@ -171,7 +177,7 @@ def main():
                          % (per / 1e9)) if kind == 0 else
                         ("synthetic %.0f GB Nanopore-style 500 bp-50 kb FASTQ per GPU, HBM-resident (BASELINE configs[4])" % (per / 1e9)),
             "bytes_per_gpu": shard_n, "seed": seed, "shards": "byte ranges at arbitrary (unaligned) cut points",
-            "exchange": "none" if world == 1 else "RCCL all_gather of 32 x u64 partials + rank-ordered fold",
+            "exchange": "none" if world == 1 else "%s all_gather of 32 x u64 partials + rank-ordered fold" % ("RCCL" if args.backend == "nccl" else args.backend),
             "flags": args.flags,
         },
         "roofline": {

@@ -634,6 +634,37 @@ __device__ __forceinline__ void partial_combine(uint64_t* acc, const uint64_t* b
 constexpr int kFoldThreads = 256;
 constexpr int kFold1 = 128;   // ranges folded per level-1 block
 
+// Ordered tree fold of `cnt` partials held in LDS rows sh[i][0..W_BYTES), result in row 0.
+// Word-parallel: at each level one thread produces ONE word of ONE pair (A (+) B)[w] =
+// A[w] + B[rotated w], so there are no per-thread partial copies (the first version kept two
+// 25-word partials per thread in registers and spilled to scratch).
+template <int ROWS, int THREADS>
+__device__ __forceinline__ void lds_tree_fold(uint64_t (*sh)[W_BYTES + 1], int tid) {
+  for (int s = 1; s < ROWS; s <<= 1) {
+    const int pairs = ROWS / (2 * s);
+    uint64_t v[(ROWS / 2 * W_BYTES + THREADS - 1) / THREADS];
+    int n = 0;
+    for (int idx = tid; idx < pairs * W_BYTES; idx += THREADS, ++n) {
+      const int pr = idx / W_BYTES, w = idx % W_BYTES;
+      const int ia = pr * 2 * s, ib = ia + s;
+      if (w == W_NL) {
+        v[n] = sh[ia][W_NL] + sh[ib][W_NL];
+      } else {
+        const uint32_t k = (uint32_t)sh[ia][W_NL] & 3u;
+        const int arr = W_GC + ((w - W_GC) & ~3), r = (w - W_GC) & 3;
+        v[n] = sh[ia][w] + sh[ib][arr + ((r - k) & 3u)];
+      }
+    }
+    __syncthreads();
+    n = 0;
+    for (int idx = tid; idx < pairs * W_BYTES; idx += THREADS, ++n) {
+      const int pr = idx / W_BYTES, w = idx % W_BYTES;
+      sh[pr * 2 * s][w] = v[n];
+    }
+    __syncthreads();
+  }
+}
+
 // K2a: level-1 fold, one block per kFold1 consecutive ranges (coalesced load into LDS, ordered tree).
 // rel_phase[r] (optional) = newlines of the earlier ranges of the same block, mod 4.
 __global__ __launch_bounds__(kFold1) void fq_fold_level1(const uint64_t* partials, uint64_t n_ranges,
@@ -653,73 +684,53 @@ __global__ __launch_bounds__(kFold1) void fq_fold_level1(const uint64_t* partial
     for (uint64_t r = 0; r < cnt; ++r) { rel_phase[r0 + r] = (uint8_t)ph; ph = (ph + (uint32_t)sh[r][W_NL]) & 3u; }
   }
   __syncthreads();
-  for (int s = 1; s < kFold1; s <<= 1) {
-    if ((tid & (2 * s - 1)) == 0) {
-      uint64_t a2[W_BYTES], b2[W_BYTES];
-#pragma unroll
-      for (int k = 0; k < W_BYTES; ++k) { a2[k] = sh[tid][k]; b2[k] = sh[tid + s][k]; }
-      partial_combine(a2, b2);
-#pragma unroll
-      for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = a2[k];
-    }
-    __syncthreads();
-  }
+  lds_tree_fold<kFold1, kFold1>(sh, tid);
   if (tid < kPartialWords) block_out[(uint64_t)blockIdx.x * kPartialWords + tid] = (tid < W_BYTES) ? sh[0][tid] : 0;
 }
 
-// K2b: final fold over the level-1 block partials into the running state (carry-in for streaming).
+// K2b: final fold over the level-1 block partials into the running state (carry-in for streaming);
+// also records each level-1 block's starting phase (histogram fold) and finishes bytes / last_byte.
 __global__ __launch_bounds__(kFoldThreads) void fq_fold_partials(const uint64_t* partials, uint64_t n_ranges,
                                                                  uint64_t* state, uint8_t* range_phase,
                                                                  const uint8_t* base, uint64_t n) {
   __shared__ uint64_t sh[kFoldThreads][W_BYTES + 1];
   const int tid = threadIdx.x;
+  // row `tid` <- ordered fold of a contiguous run of inputs (normally 0 or 1 of them: <= 256 block partials)
   const uint64_t per = (n_ranges + kFoldThreads - 1) / kFoldThreads;
   uint64_t lo = (uint64_t)tid * per, hi = lo + per;
   if (lo > n_ranges) lo = n_ranges;
   if (hi > n_ranges) hi = n_ranges;
-  uint64_t acc[W_BYTES];
-#pragma unroll
-  for (int k = 0; k < W_BYTES; ++k) acc[k] = 0;
+  for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = 0;
   for (uint64_t r = lo; r < hi; ++r) {
-    uint64_t b[W_BYTES];
     const uint64_t* src = partials + r * kPartialWords;
-#pragma unroll
-    for (int k = 0; k < W_BYTES; ++k) b[k] = src[k];
-    partial_combine(acc, b);
+    const uint32_t k = (uint32_t)sh[tid][W_NL] & 3u;
+    uint64_t t[W_BYTES];
+    for (int w = W_GC; w < W_BYTES; ++w) {
+      const int arr = W_GC + ((w - W_GC) & ~3), q = (w - W_GC) & 3;
+      t[w] = sh[tid][w] + src[arr + ((q - k) & 3u)];
+    }
+    for (int w = W_GC; w < W_BYTES; ++w) sh[tid][w] = t[w];
+    sh[tid][W_NL] += src[W_NL];
   }
-#pragma unroll
-  for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = acc[k];
   __syncthreads();
-  // ordered tree: element j absorbs element j+s (its right neighbour block)
-  for (int s = 1; s < kFoldThreads; s <<= 1) {
-    if ((tid & (2 * s - 1)) == 0) {
-      uint64_t a2[W_BYTES], b2[W_BYTES];
-#pragma unroll
-      for (int k = 0; k < W_BYTES; ++k) { a2[k] = sh[tid][k]; b2[k] = sh[tid + s][k]; }
-      partial_combine(a2, b2);
-#pragma unroll
-      for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = a2[k];
-    }
-    __syncthreads();
-  }
-  if (range_phase) {
-    // starting phase of every range = (state.nl + newlines of all earlier ranges) mod 4
-    // (second sequential pass by thread 0 over nl only when the histogram fold needs it)
-    if (tid == 0) {
-      uint32_t ph = (uint32_t)state[W_NL] & 3u;
-      for (uint64_t r = 0; r < n_ranges; ++r) {
-        range_phase[r] = (uint8_t)ph;
-        ph = (ph + (uint32_t)partials[r * kPartialWords + W_NL]) & 3u;
-      }
+  if (range_phase && tid == 0) {
+    // starting phase of every input = (state.nl + newlines of all earlier inputs) mod 4
+    uint32_t ph = (uint32_t)state[W_NL] & 3u;
+    for (uint64_t r = 0; r < n_ranges; ++r) {
+      range_phase[r] = (uint8_t)ph;
+      ph = (ph + (uint32_t)partials[r * kPartialWords + W_NL]) & 3u;
     }
   }
+  lds_tree_fold<kFoldThreads, kFoldThreads>(sh, tid);
   if (tid == 0) {
-    uint64_t a2[W_BYTES], b2[W_BYTES];
-#pragma unroll
-    for (int k = 0; k < W_BYTES; ++k) { a2[k] = state[k]; b2[k] = sh[0][k]; }
-    partial_combine(a2, b2);
-#pragma unroll
-    for (int k = 0; k < W_BYTES; ++k) state[k] = a2[k];
+    const uint32_t k = (uint32_t)state[W_NL] & 3u;
+    uint64_t t[W_BYTES];
+    for (int w = W_GC; w < W_BYTES; ++w) {
+      const int arr = W_GC + ((w - W_GC) & ~3), q = (w - W_GC) & 3;
+      t[w] = state[w] + sh[0][arr + ((q - k) & 3u)];
+    }
+    for (int w = W_GC; w < W_BYTES; ++w) state[w] = t[w];
+    state[W_NL] += sh[0][W_NL];
     state[W_BYTES] += n;
     if (n) state[W_LAST] = base[n - 1];
   }
