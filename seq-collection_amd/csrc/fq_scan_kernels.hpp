@@ -206,13 +206,19 @@ __device__ __forceinline__ uint32_t byte_nonzero_ff(uint32_t sel) {
   return __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFF00u, sel);
 }
 
-__device__ __forceinline__ void masks32_ascii(const uint32_t* d, uint32_t k12, uint32_t& wnl, uint32_t& wgc, uint32_t& wnn) {
+template <bool STRUCT>
+__device__ __forceinline__ void masks32_ascii(const uint32_t* d, uint32_t k12, uint32_t& wnl, uint32_t& wgc, uint32_t& wnn,
+                                              uint32_t& wat, uint32_t& wpl) {
   uint32_t x[8];
   transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
   transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
   wnl = byte_nonzero_ff(v_xad(x[7], 0x0A0A0A0Au, k12));
   wgc = byte_nonzero_ff((x[7] ^ 0x43434343u) & 0xFBFBFBFBu);
   wnn = byte_nonzero_ff(v_xad(x[7], 0x4E4E4E4Eu, k12));
+  if (STRUCT) {
+    wat = byte_nonzero_ff(v_xad(x[7], 0x40404040u, k12));
+    wpl = byte_nonzero_ff(v_xad(x[7], 0x2B2B2B2Bu, k12));
+  }
 #pragma unroll
   for (int j = 6; j >= 0; --j) {
     const uint32_t sel = 0x01010101u << j;
@@ -224,6 +230,12 @@ __device__ __forceinline__ void masks32_ascii(const uint32_t* d, uint32_t k12, u
     wgc = v_bfi(sel, r, wgc);
     r = byte_nonzero_ff(v_xad(v, 0x4E4E4E4Eu, k12));
     wnn = v_bfi(sel, r, wnn);
+    if (STRUCT) {
+      r = byte_nonzero_ff(v_xad(v, 0x40404040u, k12));
+      wat = v_bfi(sel, r, wat);
+      r = byte_nonzero_ff(v_xad(v, 0x2B2B2B2Bu, k12));
+      wpl = v_bfi(sel, r, wpl);
+    }
   }
 }
 
@@ -260,6 +272,7 @@ struct Acc16 {
 struct WaveState {
   Acc16 gc, nn, len, crlf, starts, fat, fplus;
   uint32_t p_gc, p_nn, p_len, p_crlf;   // 8-bit x 4-class fields of up to 3 tiles, not yet widened
+  uint32_t p_st, p_fat, p_fpl;          // ... K4 fields (STRUCT only)
   uint32_t pending;                     // wave-uniform: tiles accumulated in p_*
   uint32_t phase;      // wave-uniform: newlines seen so far in this range, mod 4
   uint32_t nl_total;   // wave-uniform: newlines seen so far in this range
@@ -272,7 +285,10 @@ __device__ __forceinline__ void flush_pending(WaveState& st) {
   st.nn.add_tile8(st.p_nn);
   st.len.add_tile8(st.p_len);
   st.crlf.add_tile8(st.p_crlf);
-  st.p_gc = st.p_nn = st.p_len = st.p_crlf = 0;
+  st.starts.add_tile8(st.p_st);
+  st.fat.add_tile8(st.p_fat);
+  st.fplus.add_tile8(st.p_fpl);
+  st.p_gc = st.p_nn = st.p_len = st.p_crlf = st.p_st = st.p_fat = st.p_fpl = 0;
   st.pending = 0;
 }
 
@@ -377,8 +393,8 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
   }
 
   st.p_gc += t_gc; st.p_nn += t_nn; st.p_len += t_len; st.p_crlf += t_crlf;
+  if (STRUCT) { st.p_st += t_st; st.p_fat += t_fat; st.p_fpl += t_fpl; }
   if (++st.pending == 3) flush_pending(st);
-  if (STRUCT) { st.starts.add_tile8(t_st); st.fat.add_tile8(t_fat); st.fplus.add_tile8(t_fpl); }
   st.phase = (st.phase + total) & 3u;
   st.nl_total += total;
   st.prev_last = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)d[15], 63) >> 24);
@@ -390,6 +406,7 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
 // newlines in a lane's 64 bytes) cost one straight-line "first segment" block, one "last segment"
 // block and at most one pass of the middle loop.
 // ------------------------------------------------------------------------------------------------
+template <bool STRUCT>
 __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st) {
   const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
   const uint4 q0v = p[0], q1v = p[1], q2v = p[2], q3v = p[3];
@@ -397,19 +414,20 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
                     q2v.x, q2v.y, q2v.z, q2v.w, q3v.x, q3v.y, q3v.z, q3v.w};
   const uint32_t hb = (d[0] | d[1] | d[2]) | (d[3] | d[4] | d[5]) | (d[6] | d[7] | d[8]) |
                       (d[9] | d[10] | d[11]) | (d[12] | d[13] | d[14]) | d[15];
-  uint64_t WNL, WGC, WNN;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N'
+  uint64_t WNL, WGC, WNN, WAT = 0, WPL = 0;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N' / '@' / '+'
   if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0) {
-    uint32_t a0, a1, a2, b0, b1, b2;
+    uint32_t a0, a1, a2, a3 = 0, a4 = 0, b0, b1, b2, b3 = 0, b4 = 0;
     uint32_t k12 = 0x0C0C0C0Cu;
     asm("" : "+v"(k12));   // keep the constant in a VGPR (v_xad_u32 takes a single SGPR source)
-    masks32_ascii(d, k12, a0, a1, a2);
-    masks32_ascii(d + 8, k12, b0, b1, b2);
+    masks32_ascii<STRUCT>(d, k12, a0, a1, a2, a3, a4);
+    masks32_ascii<STRUCT>(d + 8, k12, b0, b1, b2, b3, b4);
     WNL = (uint64_t)a0 | ((uint64_t)b0 << 32);
     WGC = (uint64_t)a1 | ((uint64_t)b1 << 32);
     WNN = (uint64_t)a2 | ((uint64_t)b2 << 32);
+    if (STRUCT) { WAT = (uint64_t)a3 | ((uint64_t)b3 << 32); WPL = (uint64_t)a4 | ((uint64_t)b4 << 32); }
   } else {
-    const Masks m = masks64<false, false>(d);
-    WNL = ~m.nl; WGC = ~m.gc; WNN = ~m.nn;
+    const Masks m = masks64<false, STRUCT>(d);
+    WNL = ~m.nl; WGC = ~m.gc; WNN = ~m.nn; WAT = ~m.at; WPL = ~m.pl;
   }
   const uint64_t NL = ~WNL;
 
@@ -417,6 +435,13 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint32_t incl = wave_inclusive_scan(cnt);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const uint32_t sh0 = ((st.phase + incl - cnt) & 3u) * 8u;
+
+  // K4: line-start bytes = the byte after a '\n' (bit 0: previous lane's / previous tile's last byte)
+  uint64_t LS = 0;
+  if (STRUCT) {
+    const uint32_t carry0 = (st.prev_last == '\n' || st.prev_last == -1) ? 1u : 0u;
+    LS = (NL << 1) | wave_shr1((uint32_t)(NL >> 63), carry0);
+  }
 
   // first segment: everything below the first newline (the whole lane when there is none)
   const uint64_t xm1 = NL - 1;
@@ -428,6 +453,13 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   uint32_t t_gc = st.p_gc + (s_gc << sh0);
   uint32_t t_nn = st.p_nn + (s_nn << sh0);
   uint32_t t_crlf = st.p_crlf;
+  uint32_t s_st = 0, s_fat = 0, s_fpl = 0, t_st = 0, t_fat = 0, t_fpl = 0;
+  if (STRUCT) {
+    // a line start may be the newline itself (empty line): its segment includes the newline bit
+    const uint64_t ls0 = LS & (NL ^ xm1);
+    s_st = popc64(ls0); s_fat = popc64(ls0 & ~WAT); s_fpl = popc64(ls0 & ~WPL);
+    t_st = st.p_st + (s_st << sh0); t_fat = st.p_fat + (s_fat << sh0); t_fpl = st.p_fpl + (s_fpl << sh0);
+  }
 
   if (total != 0) {   // wave-uniform: some lane of this tile holds a newline
     const int lane_base = lane * 64;
@@ -447,12 +479,20 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       if (__builtin_amdgcn_ballot_w64(has2) == 0) break;
       const uint64_t x1m1 = x1 - 1;
       const uint64_t below1 = ~x1 & x1m1;
-      uint64_t seg = below1 & ~(xc ^ xcm1);        // strictly between the two lowest remaining newlines
+      const uint64_t upto0 = xc ^ xcm1;
+      uint64_t seg = below1 & ~upto0;              // strictly between the two lowest remaining newlines
       seg = has2 ? seg : 0;                        // lanes whose next segment is their last one are handled below
       sh = (sh + 8u) & 31u;
       const uint32_t m_len = popc64(seg), m_gc = popc64(seg & ~WGC), m_nn = popc64(seg & ~WNN);
       t_len += m_len << sh; t_gc += m_gc << sh; t_nn += m_nn << sh;
       s_len += m_len; s_gc += m_gc; s_nn += m_nn;
+      if (STRUCT) {
+        uint64_t lsm = LS & (x1 ^ x1m1) & ~upto0;  // the segment plus its terminating newline
+        lsm = has2 ? lsm : 0;
+        const uint32_t m_st = popc64(lsm), m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
+        t_st += m_st << sh; t_fat += m_fat << sh; t_fpl += m_fpl << sh;
+        s_st += m_st; s_fat += m_fat; s_fpl += m_fpl;
+      }
       const int idx = lane_base + (int)popc64(below1) - 1;     // >= 0: a lane's second newline is never at bit 0
       const int pb = slot[has2 ? idx : lane * 4];
       t_crlf += ((has2 && pb == '\r') ? 1u : 0u) << sh;
@@ -464,9 +504,15 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
     t_len += (64u - cnt - s_len) << shl;
     t_gc += (64u - popc64(WGC) - s_gc) << shl;
     t_nn += (64u - popc64(WNN) - s_nn) << shl;
+    if (STRUCT) {
+      t_st += (popc64(LS) - s_st) << shl;
+      t_fat += (popc64(LS & ~WAT) - s_fat) << shl;
+      t_fpl += (popc64(LS & ~WPL) - s_fpl) << shl;
+    }
   }
 
   st.p_len = t_len; st.p_gc = t_gc; st.p_nn = t_nn; st.p_crlf = t_crlf;
+  if (STRUCT) { st.p_st = t_st; st.p_fat = t_fat; st.p_fpl = t_fpl; }
   if (++st.pending == 3) flush_pending(st);
   st.phase = (st.phase + total) & 3u;
   st.nl_total += total;
@@ -563,7 +609,7 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
     const uint8_t* sl = ring + slot * kTile;
     const uint64_t ts = A0 + t * kTile;
     if (ts >= B && ts + kTile <= E) {
-      if (!STRUCT && !HIST) process_tile_fast(sl, lane, st);
+      if (!HIST) process_tile_fast<STRUCT>(sl, lane, st);
       else process_tile<false, STRUCT, HIST>(sl, lane, ~0ull, 0, prev_param, st, hist_lds);
     } else {
       // valid bytes of this lane: absolute [ts + 64*lane, +64) intersected with [B, E)
