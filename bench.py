@@ -192,7 +192,7 @@ def main():
     }
     # PMC traffic measured offline with rocprofv3 (separate --pmc pass), if committed for this workload
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.flags == 0 and kind == 0:
         try:
             with open(pmc) as f:
                 j = json.load(f)

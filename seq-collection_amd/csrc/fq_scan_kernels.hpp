@@ -36,6 +36,13 @@ enum : int { W_NL = 0, W_GC = 1, W_N = 5, W_LEN = 9, W_STARTS = 13, W_FAT = 17, 
 
 constexpr uint32_t F_QUAL_HIST = 1u, F_STRUCT = 2u;
 
+// K3: per-wave LDS histogram, replicated kHistRep x (copy = lane % kHistRep) so that the skewed byte
+// distributions of FASTQ (one quality value = 90 % of a line) do not serialise 64 lanes on one address.
+// Layout: u32 bin[(byte * 4 + class) * kHistRep + copy]  -> 16 KiB per wave.
+constexpr int kHistRep = 4;
+constexpr int kHistWords = 256 * 4 * kHistRep;
+constexpr int kHistWaves = 2;   // waves per block in the histogram variant (LDS: 2 x (ring + 16 KiB))
+
 // ------------------------------------------------------------------------------------------------
 // cross-lane helpers (wave64, DPP)
 // ------------------------------------------------------------------------------------------------
@@ -366,14 +373,15 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
       t_fpl += popc64(ls & m.pl) << sh;
     }
     if (HIST) {
-      // K3 (opt-in): every non-newline byte of this segment into hist[class][byte]
-      uint64_t s = seg;
+      // K3 (edge tiles only; interior tiles use hist_tile_full): every valid byte of this segment INCLUDING its
+      // newline goes to bin[class][byte]; newline and "\r\n" bytes are taken back once per range
+      uint64_t s = upto & VR;
       const uint32_t cls = sh >> 3;
       while (s) {
         const int k = __builtin_ctzll(s);
         s &= s - 1;
         const uint32_t byte = slot[lane_base + k];
-        atomicAdd(&hist_lds[cls * 256 + byte], 1u);
+        atomicAdd(&hist_lds[(byte * 4 + cls) * kHistRep + (lane & (kHistRep - 1))], 1u);
       }
     }
     // the '\r' of a "\r\n" line end is not part of the line: look one byte behind the newline
@@ -384,7 +392,6 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
     if (idx < 0) pb = st.prev_last;
     if (EDGE) { if ((int64_t)(lane_base + q) == first_valid_pos) pb = prev_byte_param; }
     t_crlf += ((has_nl && pb == '\r') ? 1u : 0u) << sh;
-    if (HIST) { if (has_nl && pb == '\r') atomicAdd(&hist_lds[(sh >> 3) * 256 + '\r'], 0xFFFFFFFFu); }
 
     GC &= ~upto; NN &= ~upto; VR &= ~upto; x &= ~upto;
     if (STRUCT) LS &= ~upto;
@@ -400,14 +407,26 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
   st.prev_last = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)d[15], 63) >> 24);
 }
 
+// K3, interior tiles: all 64 bytes of the lane, fully unrolled. cls0 = class of the lane's first byte.
+__device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist_lds, int lane, uint32_t cls0) {
+  uint32_t cls = cls0;
+  uint32_t* lane_bins = hist_lds + (lane & (kHistRep - 1));
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    const uint32_t byte = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+    __hip_atomic_fetch_add(&lane_bins[(byte * 4 + (cls & 3u)) * kHistRep], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cls += (byte == 10u) ? 1u : 0u;      // a newline belongs to the line it ends
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Interior tile of the default variant (no EDGE / STRUCT / HIST): the same arithmetic as
 // process_tile with the segment loop restructured so that the common FASTQ shapes (0, 1 or 2
 // newlines in a lane's 64 bytes) cost one straight-line "first segment" block, one "last segment"
 // block and at most one pass of the middle loop.
 // ------------------------------------------------------------------------------------------------
-template <bool STRUCT>
-__device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st) {
+template <bool STRUCT, bool HIST>
+__device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st, uint32_t* hist_lds) {
   const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
   const uint4 q0v = p[0], q1v = p[1], q2v = p[2], q3v = p[3];
   uint32_t d[16] = {q0v.x, q0v.y, q0v.z, q0v.w, q1v.x, q1v.y, q1v.z, q1v.w,
@@ -435,6 +454,7 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint32_t incl = wave_inclusive_scan(cnt);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const uint32_t sh0 = ((st.phase + incl - cnt) & 3u) * 8u;
+  if (HIST) hist_tile_full(d, hist_lds, lane, sh0 >> 3);
 
   // K4: line-start bytes = the byte after a '\n' (bit 0: previous lane's / previous tile's last byte)
   uint64_t LS = 0;
@@ -534,7 +554,8 @@ struct ScanArgs {
 
 // RING = LDS ring slots per wave (1 being consumed + RING-1 in flight); NT = non-temporal DMA loads
 template <bool STRUCT, bool HIST, int RING = kRing, bool NT = true>
-__global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
+__global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void fq_scan_tiles(ScanArgs a) {
+  constexpr int WAVES = HIST ? kHistWaves : kWavesPerBlock;
   static_assert(RING >= 2 && RING <= 4, "ring depth");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
@@ -542,10 +563,10 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
   uint8_t* ring = smem + wave * (RING * kTile);
   uint32_t* hist_lds = nullptr;
   if (HIST) {
-    hist_lds = reinterpret_cast<uint32_t*>(smem + kWavesPerBlock * RING * kTile) + wave * 1024;
-    for (int k = lane; k < 1024; k += 64) hist_lds[k] = 0;
+    hist_lds = reinterpret_cast<uint32_t*>(smem + WAVES * RING * kTile) + wave * kHistWords;
+    for (int k = lane; k < kHistWords; k += 64) hist_lds[k] = 0;
   }
-  const uint64_t range = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  const uint64_t range = (uint64_t)blockIdx.x * WAVES + wave;
   if (range >= a.n_ranges) return;
 
   const uint64_t B = (uint64_t)(uintptr_t)a.base, E = B + a.n;
@@ -609,8 +630,7 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
     const uint8_t* sl = ring + slot * kTile;
     const uint64_t ts = A0 + t * kTile;
     if (ts >= B && ts + kTile <= E) {
-      if (!HIST) process_tile_fast<STRUCT>(sl, lane, st);
-      else process_tile<false, STRUCT, HIST>(sl, lane, ~0ull, 0, prev_param, st, hist_lds);
+      process_tile_fast<STRUCT, HIST>(sl, lane, st, hist_lds);
     } else {
       // valid bytes of this lane: absolute [ts + 64*lane, +64) intersected with [B, E)
       const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);
@@ -655,8 +675,20 @@ __global__ __launch_bounds__(256) void fq_scan_tiles(ScanArgs a) {
     for (int k = W_BYTES; k < kPartialWords; ++k) out[k] = 0;
   }
   if (HIST) {
+    // per-range histogram partial [class][byte] (u32): sum the lane-keyed copies, then take back the bytes that
+    // are not part of any line: newline j of the range ended a line of class j mod 4, and the '\r' of every
+    // "\r\n" (per-class counts in cr4; u32 modular like len when that '\r' lies in the previous range)
     uint32_t* hp = a.hist_partials + range * 1024;
-    for (int k = lane; k < 1024; k += 64) hp[k] = hist_lds[k];
+    for (int k = lane; k < 1024; k += 64) {
+      const uint32_t c = (uint32_t)k >> 8, b = (uint32_t)k & 255u;
+      const uint32_t* src = hist_lds + (b * 4 + c) * kHistRep;
+      uint32_t v = 0;
+#pragma unroll
+      for (int r = 0; r < kHistRep; ++r) v += src[r];
+      if (b == 10u) v -= (st.nl_total + 3u - c) >> 2;
+      if (b == 13u) v -= (c == 0 ? cr4.x : c == 1 ? cr4.y : c == 2 ? cr4.z : cr4.w);
+      hp[k] = v;
+    }
   }
 }
 
@@ -782,18 +814,25 @@ __global__ __launch_bounds__(kFoldThreads) void fq_fold_partials(const uint64_t*
   }
 }
 
-// K3 fold: state_hist[c][b] += sum_r hist_r[(c - phase_r) & 3][b],  phase_r = block_phase[r / kFold1] + rel_phase[r]
+// K3 fold: state_hist[c][b] += sum_r hist_r[(c - phase_r) & 3][b],  phase_r = block_phase[r / kFold1] + rel_phase[r].
+// One block per kFold1 ranges; thread t owns byte values t (4 classes each), reads are coalesced over t.
 __global__ __launch_bounds__(256) void fq_fold_hist(const uint32_t* hist_partials, const uint8_t* rel_phase,
-                                                    const uint8_t* block_phase, uint64_t n_ranges, uint64_t* state_hist) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;   // 0..1023 : c*256 + b
-  const uint32_t c = idx >> 8, b = idx & 255;
-  uint64_t acc = 0;
-  for (uint64_t r = 0; r < n_ranges; ++r) {
-    const uint32_t src = (c - (uint32_t)block_phase[r / kFold1] - (uint32_t)rel_phase[r]) & 3u;
-    // u32 partials are modular too (the "\r\n" take-back may wrap): sign-extend the wrap
-    acc += (uint64_t)(int64_t)(int32_t)hist_partials[r * 1024 + src * 256 + b];
+                                                    const uint8_t* block_phase, uint64_t n_ranges,
+                                                    unsigned long long* state_hist) {
+  const uint32_t b = threadIdx.x;
+  const uint64_t r0 = (uint64_t)blockIdx.x * kFold1;
+  const uint64_t r1 = (r0 + kFold1 < n_ranges) ? r0 + kFold1 : n_ranges;
+  const uint32_t bp = block_phase[blockIdx.x];
+  uint64_t acc[4] = {0, 0, 0, 0};
+  for (uint64_t r = r0; r < r1; ++r) {
+    const uint32_t ph = (bp + rel_phase[r]) & 3u;
+    const uint32_t* src = hist_partials + r * 1024 + b;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c)   // u32 partials are modular (take-backs may wrap): sign-extend
+      acc[(c + ph) & 3u] += (uint64_t)(int64_t)(int32_t)src[c * 256];
   }
-  state_hist[idx] += acc;
+#pragma unroll
+  for (uint32_t c = 0; c < 4; ++c) atomicAdd(&state_hist[c * 256 + b], (unsigned long long)acc[c]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -169,9 +169,12 @@ uint32_t pick_tiles_per_range(const Ctx* c, uint64_t n_tiles) {
 
 template <bool S, bool H, int RING, bool NT>
 void launch_scan(const scfq::ScanArgs& a, unsigned blocks, hipStream_t st) {
-  unsigned lds = scfq::kWavesPerBlock * RING * scfq::kTile;
-  if (H) lds += scfq::kWavesPerBlock * 1024 * sizeof(uint32_t);
-  hipLaunchKernelGGL((scfq::fq_scan_tiles<S, H, RING, NT>), dim3(blocks), dim3(256), lds, st, a);
+  constexpr int waves = H ? scfq::kHistWaves : scfq::kWavesPerBlock;
+  unsigned lds = waves * RING * scfq::kTile;
+  if (H) lds += waves * scfq::kHistWords * sizeof(uint32_t);
+  (void)blocks;
+  const unsigned grid = (unsigned)((a.n_ranges + waves - 1) / waves);
+  hipLaunchKernelGGL((scfq::fq_scan_tiles<S, H, RING, NT>), dim3(grid), dim3(64 * waves), lds, st, a);
 }
 
 // tuning knobs (defaults are the measured best): SCFQ_RING = 2|3|4 LDS ring slots per wave, SCFQ_NT = 0|1
@@ -226,8 +229,8 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
                        n_blocks, c->d_state, block_phase, dptr, n);
     HIPCHK(hipGetLastError());
     if (hist) {
-      hipLaunchKernelGGL(scfq::fq_fold_hist, dim3(4), dim3(256), 0, c->compute, c->d_hist_partials, rel_phase,
-                         block_phase, n_ranges, c->d_state + SCFQ_PARTIAL_WORDS);
+      hipLaunchKernelGGL(scfq::fq_fold_hist, dim3((unsigned)n_blocks), dim3(256), 0, c->compute, c->d_hist_partials,
+                         rel_phase, block_phase, n_ranges, (unsigned long long*)(c->d_state + SCFQ_PARTIAL_WORDS));
       HIPCHK(hipGetLastError());
     }
   }
