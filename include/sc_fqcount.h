@@ -145,6 +145,9 @@ int  scfq_shutdown(void);            /* frees streams, pinned and device scratch
 /* Diagnostic only (used by the parity tests as a second, independent device implementation):
  * byte-serial HIP kernel, one thread per 256 bytes. Never called by the counting entry points. */
 int  scfq_debug_partial_simple(const void* device_ptr, uint64_t n, int prev_byte, scfq_partial* out);
+/* Diagnostic only: the byte stream scfq_count_file() would scan for `path` (plain pread, BGZF block-parallel
+ * inflate, or serial gzread), produced on the host without any device. Returns bytes written or a negative code. */
+int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk_bytes);
 
 /* ---- synthetic workloads of SURVEY.md §8(d) / BASELINE.json configs ------------------------
  * Counter-based generator: record i of a workload is a pure function of (seed, i), so host and

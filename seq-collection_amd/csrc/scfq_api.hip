@@ -10,6 +10,7 @@
 // SCFQ_EHIP.
 #include "../../include/sc_fqcount.h"
 #include "fq_scan_kernels.hpp"
+#include "scfq_bgzf.hpp"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -281,17 +282,43 @@ int check_opts(const scfq_opts* o) {
 
 // A source of bytes for the chunked ingest loop: fills dst with up to cap bytes, returns count,
 // 0 at end, negative SCFQ_* on error.
+int env_int(const char* name, int dflt);
+
 struct Source {
   virtual ~Source() {}
   virtual int64_t fill(uint8_t* dst, uint64_t cap) = 0;
 };
 
+// Host-side copies into the pinned ring are split over a few threads: one core moves ~10-15 GB/s out of the page
+// cache / pageable memory, well below what PCIe Gen5 x16 takes (SCFQ_IO_THREADS, default 8).
+int io_threads() {
+  static const int n = std::max(1, std::min(64, env_int("SCFQ_IO_THREADS", 8)));
+  return n;
+}
+
+template <typename F>
+int parallel_pieces(uint64_t total, F&& piece /* int(uint64_t off, uint64_t len) */) {
+  const uint64_t kMinPiece = 4ull << 20;
+  int nt = (int)std::min<uint64_t>((uint64_t)io_threads(), (total + kMinPiece - 1) / kMinPiece);
+  if (nt <= 1) return piece(0, total);
+  std::vector<int> rcs(nt, 0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) {
+    const uint64_t lo = total * (uint64_t)t / nt, hi = total * (uint64_t)(t + 1) / nt;
+    th.emplace_back([&, t, lo, hi] { rcs[t] = piece(lo, hi - lo); });
+  }
+  for (auto& x : th) x.join();
+  for (int r : rcs) if (r) return r;
+  return 0;
+}
+
 struct MemSource : Source {
   const uint8_t* p; uint64_t n, off = 0;
   MemSource(const uint8_t* p_, uint64_t n_) : p(p_), n(n_) {}
   int64_t fill(uint8_t* dst, uint64_t cap) override {
-    uint64_t k = std::min(cap, n - off);
-    std::memcpy(dst, p + off, k);
+    const uint64_t k = std::min(cap, n - off);
+    const uint8_t* src = p + off;
+    parallel_pieces(k, [&](uint64_t o, uint64_t len) { std::memcpy(dst + o, src + o, len); return 0; });
     off += k;
     return (int64_t)k;
   }
@@ -301,13 +328,23 @@ struct FdSource : Source {
   int fd; uint64_t off, end;
   FdSource(int fd_, uint64_t off_, uint64_t end_) : fd(fd_), off(off_), end(end_) {}
   int64_t fill(uint8_t* dst, uint64_t cap) override {
-    uint64_t want = std::min(cap, end - off), got = 0;
-    while (got < want) {
-      ssize_t r = pread(fd, dst + got, want - got, (off_t)(off + got));
-      if (r < 0) return SCFQ_EIO;
-      if (r == 0) break;
-      got += (uint64_t)r;
-    }
+    const uint64_t want = std::min(cap, end - off);
+    const uint64_t base = off;
+    std::vector<uint64_t> short_at;   // a piece that hit EOF early (file shrank): report the contiguous prefix
+    std::mutex mu;
+    const int rc = parallel_pieces(want, [&](uint64_t o, uint64_t len) {
+      uint64_t got = 0;
+      while (got < len) {
+        ssize_t r = pread(fd, dst + o + got, len - got, (off_t)(base + o + got));
+        if (r < 0) return (int)SCFQ_EIO;
+        if (r == 0) { std::lock_guard<std::mutex> lk(mu); short_at.push_back(o + got); break; }
+        got += (uint64_t)r;
+      }
+      return 0;
+    });
+    if (rc) return rc;
+    uint64_t got = want;
+    for (uint64_t v : short_at) got = std::min(got, v);
     off += got;
     return (int64_t)got;
   }
@@ -326,6 +363,107 @@ struct GzSource : Source {
       got += (unsigned)r;
     }
     return (int64_t)got;
+  }
+};
+
+// BGZF input: block-parallel inflate straight into the pinned chunk (same bytes as gzread would produce).
+struct BgzfSource : Source {
+  int fd;
+  uint64_t pos = 0, fsize;
+  std::vector<uint8_t> cbuf, carry;
+  uint64_t carry_off = 0;
+  gzFile fallback = nullptr;   // serial zlib from the first non-BGZF member on
+  bool done = false;
+  BgzfSource(int fd_, uint64_t size) : fd(fd_), fsize(size) {}
+  ~BgzfSource() override { if (fallback) gzclose(fallback); }
+
+  int64_t serial_fill(uint8_t* dst, uint64_t cap) {
+    uint64_t got = 0;
+    while (got < cap) {
+      int r = gzread(fallback, dst + got, (unsigned)std::min<uint64_t>(cap - got, 1u << 30));
+      if (r < 0) return SCFQ_EGZ;
+      if (r == 0) break;
+      got += (unsigned)r;
+    }
+    return (int64_t)got;
+  }
+
+  int64_t fill(uint8_t* dst, uint64_t cap) override {
+    if (fallback) return serial_fill(dst, cap);
+    if (carry_off < carry.size()) {   // leftover of a block larger than an earlier (tiny) chunk
+      const uint64_t k = std::min<uint64_t>(cap, carry.size() - carry_off);
+      std::memcpy(dst, carry.data() + carry_off, k);
+      carry_off += k;
+      return (int64_t)k;
+    }
+    if (done || pos >= fsize) return 0;
+    // compressed window: BGZF blocks are <= 64 KiB in and out, so `cap` compressed bytes cover >= `cap` output in
+    // all but pathological (stored) cases; a short window only means a shorter chunk
+    const uint64_t want = std::min<uint64_t>(fsize - pos, std::max<uint64_t>(cap, 1u << 20));
+    cbuf.resize(want);
+    uint64_t avail = 0;
+    while (avail < want) {
+      ssize_t r = pread(fd, cbuf.data() + avail, want - avail, (off_t)(pos + avail));
+      if (r < 0) return SCFQ_EIO;
+      if (r == 0) break;
+      avail += (uint64_t)r;
+    }
+    std::vector<scfq_bgzf::Block> blocks;
+    uint64_t p = 0, out = 0;
+    bool to_serial = false;
+    while (p < avail) {
+      uint32_t hl = 0;
+      const uint32_t bs = scfq_bgzf::block_size(cbuf.data() + p, avail - p, &hl);
+      if (!bs) {
+        const bool tail_short = (avail - p < 18) && (pos + avail < fsize);
+        if (tail_short) break;                                   // header split by the window: next fill
+        if (avail - p >= 2 && cbuf[p] == 0x1f && cbuf[p + 1] == 0x8b) to_serial = true;   // ordinary gzip member
+        else done = true;                                        // trailing garbage after a gzip stream: ignored, as zlib does
+        break;
+      }
+      if (p + bs > avail) {
+        if (pos + avail >= fsize) return SCFQ_EGZ;               // truncated final block
+        break;                                                   // block split by the window: next fill
+      }
+      const uint32_t isize = scfq_bgzf::rd32(cbuf.data() + p + bs - 4);
+      if (out + isize > cap) {
+        if (!blocks.empty()) break;
+        // a single block larger than the chunk: inflate it aside and serve it in pieces
+        std::vector<scfq_bgzf::Block> one{{p, bs, hl, isize, scfq_bgzf::rd32(cbuf.data() + p + bs - 8), 0}};
+        carry.assign(isize, 0);
+        if (scfq_bgzf::inflate_blocks(cbuf.data(), one, 0, 1, carry.data())) return SCFQ_EGZ;
+        pos += p + bs;
+        carry_off = std::min<uint64_t>(cap, carry.size());
+        std::memcpy(dst, carry.data(), carry_off);
+        return (int64_t)carry_off;
+      }
+      blocks.push_back({p, bs, hl, isize, scfq_bgzf::rd32(cbuf.data() + p + bs - 8), out});
+      out += isize;
+      p += bs;
+    }
+    if (!blocks.empty()) {
+      static const int nthr = std::max(1, std::min(64, env_int("SCFQ_INFLATE_THREADS",
+                                                               (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())))));
+      const int nt = (int)std::min<size_t>((size_t)nthr, (blocks.size() + 7) / 8);
+      std::vector<int> rcs(nt, 0);
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; ++t)
+        th.emplace_back([&, t] { rcs[t] = scfq_bgzf::inflate_blocks(cbuf.data(), blocks, blocks.size() * t / nt, blocks.size() * (t + 1) / nt, dst); });
+      rcs[0] = scfq_bgzf::inflate_blocks(cbuf.data(), blocks, 0, blocks.size() / nt, dst);
+      for (auto& x : th) x.join();
+      for (int r : rcs) if (r) return SCFQ_EGZ;
+    }
+    pos += p;
+    if (to_serial) {
+      const int fd2 = dup(fd);
+      if (fd2 < 0 || lseek(fd2, (off_t)pos, SEEK_SET) < 0) return SCFQ_EIO;
+      fallback = gzdopen(fd2, "rb");
+      if (!fallback) { close(fd2); return SCFQ_EGZ; }
+      gzbuffer(fallback, 1u << 20);
+      if (out == 0) return serial_fill(dst, cap);
+    }
+    if (out == 0 && !done && pos < fsize && blocks.empty() && !to_serial) return SCFQ_EGZ;   // no progress possible
+    return (int64_t)out;
   }
 };
 
@@ -480,6 +618,27 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
   // fastq[^3 .. ^1] == ".gz"      src/fq_count.nim:31 (case-sensitive, last three bytes)
   const bool is_gz = plen >= 3 && std::memcmp(path + plen - 3, ".gz", 3) == 0;
   if (is_gz) {
+    {   // BGZF (bgzip) files: block-parallel inflate; every other gzip layout: serial gzread below
+      const int bfd = open(path, O_RDONLY);
+      struct stat bsb;
+      if (bfd >= 0 && fstat(bfd, &bsb) == 0 && S_ISREG(bsb.st_mode) && !std::getenv("SCFQ_NO_BGZF") && scfq_bgzf::probe(bfd)) {
+        if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { close(bfd); return SCFQ_EHIP; }
+        Ctx* c = nullptr;
+        SessionLock sl;
+        rc = get_ctx(&c);
+        if (!rc) { sl.acquire(c); rc = begin_session(c); }
+        if (!rc) {
+          BgzfSource src(bfd, (uint64_t)bsb.st_size);
+          rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
+        }
+        close(bfd);
+        if (rc) return rc;
+        rc = end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
+        if (rc) return rc;
+        return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+      }
+      if (bfd >= 0) close(bfd);
+    }
     gzFile f = gzopen(path, "rb");
     if (!f) return SCFQ_EOPEN;
     gzbuffer(f, 1u << 20);
@@ -595,6 +754,52 @@ int scfq_shutdown(void) {
   }
   g_ctx.clear();
   return SCFQ_OK;
+}
+
+// ---- diagnostic: run the host-side source selection (plain pread / BGZF parallel inflate / serial gzread) of
+// scfq_count_file without any device, writing the byte stream the scan would see into dst. Returns the byte
+// count, or a negative SCFQ_* code; SCFQ_EARG when the stream is longer than cap.
+int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk) {
+  if (!path || (!dst && cap)) return SCFQ_EARG;
+  if (chunk == 0) chunk = kDefaultChunk;
+  const size_t plen = std::strlen(path);
+  const bool is_gz = plen >= 3 && std::memcmp(path + plen - 3, ".gz", 3) == 0;
+  std::unique_ptr<Source> src;
+  int fd = -1;
+  gzFile gz = nullptr;
+  if (is_gz) {
+    fd = open(path, O_RDONLY);
+    struct stat sb;
+    if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && !std::getenv("SCFQ_NO_BGZF") && scfq_bgzf::probe(fd)) {
+      src.reset(new BgzfSource(fd, (uint64_t)sb.st_size));
+    } else {
+      if (fd >= 0) close(fd);
+      fd = -1;
+      gz = gzopen(path, "rb");
+      if (!gz) return SCFQ_EOPEN;
+      src.reset(new GzSource(gz));
+    }
+  } else {
+    fd = open(path, O_RDONLY);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { if (fd >= 0) close(fd); return SCFQ_EOPEN; }
+    src.reset(new FdSource(fd, 0, (uint64_t)sb.st_size));
+  }
+  std::vector<uint8_t> buf(chunk);
+  uint64_t total = 0;
+  int64_t rc = 0;
+  for (;;) {
+    const int64_t got = src->fill(buf.data(), chunk);
+    if (got < 0) { rc = got; break; }
+    if (got == 0) break;
+    if (total + (uint64_t)got > cap) { rc = SCFQ_EARG; break; }
+    std::memcpy(static_cast<uint8_t*>(dst) + total, buf.data(), (size_t)got);
+    total += (uint64_t)got;
+  }
+  src.reset();
+  if (gz) gzclose(gz);
+  if (fd >= 0) close(fd);
+  return rc < 0 ? rc : (int64_t)total;
 }
 
 // ---- diagnostic: independent byte-serial device kernel (tests only; not used by any counting path) ----

@@ -29,6 +29,7 @@ EXPORTS = [
     "scfq_partial_combine", "scfq_partial_finalize", "scfq_format_tsv", "scfq_strerror",
     "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
+    "scfq_debug_read_file",
 ]
 
 
@@ -110,6 +111,8 @@ def lib():
         for name in ("scfq_synth_host", "scfq_synth_device"):
             getattr(L, name).argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                          ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SynthInfo)]
+        L.scfq_debug_read_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        L.scfq_debug_read_file.restype = ctypes.c_int64
         L.scfq_synth_locate.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         _lib = L
@@ -201,6 +204,15 @@ def partial_simple_device(dev_ptr, n, prev_byte=-1):
     _check(lib().scfq_debug_partial_simple(ctypes.c_void_p(dev_ptr), n, prev_byte, ctypes.byref(p)),
            "scfq_debug_partial_simple")
     return p
+
+
+def debug_read_file(path, cap, chunk_bytes=0):
+    """host-only: the byte stream count_file would scan (plain / BGZF parallel inflate / serial gzread)"""
+    buf = (ctypes.c_uint8 * max(cap, 1))()
+    n = lib().scfq_debug_read_file(os.fsencode(path), buf, cap, chunk_bytes)
+    if n < 0:
+        raise ScfqError(int(n), "scfq_debug_read_file", lib().scfq_last_error_detail().decode())
+    return bytes(buf[:n])
 
 
 def combine(acc, b, hist_acc=None, hist_b=None):
