@@ -143,3 +143,69 @@ def test_synthetic_workloads_match_oracle_and_generator(gpu, scfq, oracle):
             assert getattr(c, f) == getattr(oc, f), (kind, f)
         assert (c.reads, c.gc_bases, c.n_bases, c.bases) == (plan.records, info.gc_bases, info.n_bases, info.bases)
         assert c.bad_at == 0 and c.bad_plus == 0
+
+
+def test_full_size_config_properties(gpu, scfq, oracle):
+    """BASELINE configs[1] at full size (10 GB Illumina, HBM-resident): size-independent properties.
+    exact generator tallies, shard additivity at arbitrary cut points, idempotence, structure and histogram sums."""
+    torch = gpu
+    kind, seed = 0, 20260101
+    plan = scfq.synth_plan(kind, seed, 10_000_000_000)
+    buf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda")
+    info = scfq.synth_device(kind, seed, plan.records, buf.data_ptr(), plan.bytes)
+    assert info.bytes == plan.bytes
+    ptr, n = buf.data_ptr(), plan.bytes
+    whole = scfq.partial_device(ptr, n, -1)
+    c = scfq.finalize(whole)
+    assert (c.reads, c.gc_bases, c.n_bases, c.bases) == (plan.records, info.gc_bases, info.n_bases, info.bases)
+    assert c.lines == 4 * plan.records and c.newlines == c.lines and c.input_bytes == n
+    assert scfq.partial_device(ptr, n, -1).words() == whole.words()                     # idempotent
+    # shard additivity: 8 shards at arbitrary (odd, unaligned) cut points, halo read from memory
+    rng = np.random.default_rng(3)
+    cuts = [0] + sorted(int(x) for x in rng.integers(1, n, 7)) + [n]
+    acc = scfq.identity()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        flags = scfq.SCFQ_PREV_IN_MEMORY if a else 0
+        scfq.combine(acc, scfq.partial_device(ptr + a, b - a, -1, flags=flags))
+    assert acc.words()[:27] == whole.words()[:27]
+    # the first 64 MiB against the CPU oracle, bit-exact
+    m = 64 << 20
+    host = buf[:m].cpu().numpy()
+    assert scfq.partial_device(ptr, m, -1).words()[:13] == [int(x) for x in oracle.partial(host, -1)[:13]]
+    # structure check + histogram variants at full size
+    cs = scfq.count_device(ptr, n, flags=scfq.SCFQ_STRUCT_CHECK | scfq.SCFQ_QUAL_HIST)
+    assert (cs.reads, cs.gc_bases, cs.n_bases, cs.bases, cs.bad_at, cs.bad_plus) == (c.reads, c.gc_bases, c.n_bases, c.bases, 0, 0)
+    hist = list(cs.qual_hist)
+    assert sum(hist) == c.bases                                                         # every quality line is as long as its read
+    assert {v for v in range(256) if hist[v]} == {ord("F"), ord(":"), ord(","), ord("#")}
+    assert abs(hist[ord("F")] / c.bases - 0.90) < 0.001
+
+
+def test_long_read_workload(gpu, scfq, oracle):
+    """BASELINE configs[4]: Nanopore-style 500 bp..50 kb reads (lines far longer than a 4 KiB tile)"""
+    torch = gpu
+    kind, seed = 1, 20260103
+    plan = scfq.synth_plan(kind, seed, 1_000_000_000)
+    buf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda")
+    info = scfq.synth_device(kind, seed, plan.records, buf.data_ptr(), plan.bytes)
+    c = scfq.count_device(buf.data_ptr(), plan.bytes, flags=scfq.SCFQ_STRUCT_CHECK | scfq.SCFQ_QUAL_HIST)
+    assert (c.reads, c.gc_bases, c.n_bases, c.bases, c.bad_at, c.bad_plus) == (plan.records, info.gc_bases, info.n_bases, info.bases, 0, 0)
+    hist = list(c.qual_hist)
+    assert sum(hist) == c.bases and {v for v in range(256) if hist[v]} == set(range(34, 74))
+    host = buf[:plan.bytes].cpu().numpy()
+    oc = oracle.count(host, "lines")
+    assert (c.reads, c.gc_bases, c.n_bases, c.bases, c.lines) == (oc.reads, oc.gc_bases, oc.n_bases, oc.bases, oc.lines)
+
+
+def test_worst_case_newline_density(gpu, scfq, oracle):
+    """pathological inputs: only newlines, alternating newline / base, 0x80+ bytes everywhere"""
+    torch = gpu
+    n = 8 << 20
+    for pattern in (b"\n", b"G\n", b"\r\n", b"\n\nN", bytes([0xC7, 0x8A, 10, 0xCE])):
+        a = np.frombuffer((pattern * (n // len(pattern) + 1))[:n], dtype=np.uint8)
+        t, ptr = to_dev(torch, a, 3)
+        for flags in (0, scfq.SCFQ_STRUCT_CHECK):
+            p = scfq.partial_device(ptr, n, -1, flags=flags)
+            ow = oracle.partial(a, -1)
+            want = [int(x) for x in ow[:25]] if flags else [int(x) for x in ow[:13]] + [0] * 12
+            assert p.words()[:25] == want, (pattern, flags)
