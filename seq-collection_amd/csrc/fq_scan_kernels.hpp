@@ -23,6 +23,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef SCFQ_ABLATE
+#define SCFQ_ABLATE 0   // diagnostic timing-only builds (make ablate): 1 = no classifier, 2 = no segment accounting, 3 = neither
+#endif
+
 namespace scfq {
 
 constexpr int kTile = 4096;          // bytes per wave-iteration (64 lanes x 64 B)
@@ -213,35 +217,59 @@ __device__ __forceinline__ uint32_t byte_nonzero_ff(uint32_t sel) {
   return __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFF00u, sel);
 }
 
+// Measured issue cost on MI355X (scripts/ubench/valu_rate.hip, 8 waves/SIMD): plain VOP2 integer ops (and/or/xor/
+// add/shift/not) and v_bitop3_b32 take ~2.2 cycles per wave64 instruction per SIMD, every other VALU op used here
+// (v_perm, v_bfi, v_xad, v_bcnt, v_lshl_add, v_or3, v_and_or, DPP, v_cmp) ~3.7.  So the classifier below is written in
+// the cheap class only: xor, add (carry into bit 7 <=> byte != c, ASCII bytes only), shift, and a v_bitop3 merge
+// ((e & sel) | w, truth table 0xEA) = 4 cheap ops per dword and symbol; masks come out INVERTED (bit set = no match).
+// Operands matter too: the same VOP2 / v_bitop3 instruction drops to the slow class when one source is an SGPR
+// (literal and inline constants are fine).  hipcc hoists repeated constants into SGPRs, so the classifier's constants
+// are pinned in VGPRs once per kernel (MaskConsts) and passed down.
+struct MaskConsts {
+  uint32_t nl, nn, c43, fb, k7f, at, pl, sel[7];
+  __device__ __forceinline__ void init() {
+    nl = 0x0A0A0A0Au; nn = 0x4E4E4E4Eu; c43 = 0x43434343u; fb = 0xFBFBFBFBu; k7f = 0x7F7F7F7Fu;
+    at = 0x40404040u; pl = 0x2B2B2B2Bu;
+    asm volatile("" : "+v"(nl), "+v"(nn), "+v"(c43), "+v"(fb), "+v"(k7f), "+v"(at), "+v"(pl));
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { sel[j] = 0x01010101u << j; asm volatile("" : "+v"(sel[j])); }
+  }
+};
+
+__device__ __forceinline__ uint32_t v_and_or_fast(uint32_t e, uint32_t sel, uint32_t w) {   // (e & sel) | w, all VGPR
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(e), "v"(sel), "v"(w));
+  return r;
+}
+__device__ __forceinline__ uint32_t v_xor_and_fast(uint32_t x, uint32_t c, uint32_t m) {   // (x ^ c) & m, all VGPR
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(r) : "v"(x), "v"(c), "v"(m));
+  return r;
+}
+
 template <bool STRUCT>
-__device__ __forceinline__ void masks32_ascii(const uint32_t* d, uint32_t k12, uint32_t& wnl, uint32_t& wgc, uint32_t& wnn,
+__device__ __forceinline__ void masks32_ascii(const uint32_t* d, const MaskConsts& mc, uint32_t& wnl, uint32_t& wgc, uint32_t& wnn,
                                               uint32_t& wat, uint32_t& wpl) {
   uint32_t x[8];
   transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
   transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
-  wnl = byte_nonzero_ff(v_xad(x[7], 0x0A0A0A0Au, k12));
-  wgc = byte_nonzero_ff((x[7] ^ 0x43434343u) & 0xFBFBFBFBu);
-  wnn = byte_nonzero_ff(v_xad(x[7], 0x4E4E4E4Eu, k12));
+  // dword 7 needs no shift and keeps bit 7 of every byte
+  wnl = ((x[7] ^ mc.nl) + mc.k7f) & 0x80808080u;
+  wgc = (v_xor_and_fast(x[7], mc.c43, mc.fb) + mc.k7f) & 0x80808080u;
+  wnn = ((x[7] ^ mc.nn) + mc.k7f) & 0x80808080u;
   if (STRUCT) {
-    wat = byte_nonzero_ff(v_xad(x[7], 0x40404040u, k12));
-    wpl = byte_nonzero_ff(v_xad(x[7], 0x2B2B2B2Bu, k12));
+    wat = ((x[7] ^ mc.at) + mc.k7f) & 0x80808080u;
+    wpl = ((x[7] ^ mc.pl) + mc.k7f) & 0x80808080u;
   }
 #pragma unroll
   for (int j = 6; j >= 0; --j) {
-    const uint32_t sel = 0x01010101u << j;
     const uint32_t v = x[j];
-    uint32_t r;
-    r = byte_nonzero_ff(v_xad(v, 0x0A0A0A0Au, k12));
-    wnl = v_bfi(sel, r, wnl);
-    r = byte_nonzero_ff((v ^ 0x43434343u) & 0xFBFBFBFBu);
-    wgc = v_bfi(sel, r, wgc);
-    r = byte_nonzero_ff(v_xad(v, 0x4E4E4E4Eu, k12));
-    wnn = v_bfi(sel, r, wnn);
+    wnl = v_and_or_fast(((v ^ mc.nl) + mc.k7f) >> (7 - j), mc.sel[j], wnl);
+    wgc = v_and_or_fast((v_xor_and_fast(v, mc.c43, mc.fb) + mc.k7f) >> (7 - j), mc.sel[j], wgc);
+    wnn = v_and_or_fast(((v ^ mc.nn) + mc.k7f) >> (7 - j), mc.sel[j], wnn);
     if (STRUCT) {
-      r = byte_nonzero_ff(v_xad(v, 0x40404040u, k12));
-      wat = v_bfi(sel, r, wat);
-      r = byte_nonzero_ff(v_xad(v, 0x2B2B2B2Bu, k12));
-      wpl = v_bfi(sel, r, wpl);
+      wat = v_and_or_fast(((v ^ mc.at) + mc.k7f) >> (7 - j), mc.sel[j], wat);
+      wpl = v_and_or_fast(((v ^ mc.pl) + mc.k7f) >> (7 - j), mc.sel[j], wpl);
     }
   }
 }
@@ -426,7 +454,8 @@ __device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist
 // block and at most one pass of the middle loop.
 // ------------------------------------------------------------------------------------------------
 template <bool STRUCT, bool HIST>
-__device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st, uint32_t* hist_lds) {
+__device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st, uint32_t* hist_lds,
+                                                  const MaskConsts& mc) {
   const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
   const uint4 q0v = p[0], q1v = p[1], q2v = p[2], q3v = p[3];
   uint32_t d[16] = {q0v.x, q0v.y, q0v.z, q0v.w, q1v.x, q1v.y, q1v.z, q1v.w,
@@ -434,12 +463,14 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint32_t hb = (d[0] | d[1] | d[2]) | (d[3] | d[4] | d[5]) | (d[6] | d[7] | d[8]) |
                       (d[9] | d[10] | d[11]) | (d[12] | d[13] | d[14]) | d[15];
   uint64_t WNL, WGC, WNN, WAT = 0, WPL = 0;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N' / '@' / '+'
-  if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0) {
+  if (SCFQ_ABLATE == 1 || SCFQ_ABLATE == 3) {   // timing-only: masks are a cheap function of the data
+    WNL = ~((uint64_t)(d[0] & d[5] & 0x01010101u) | ((uint64_t)(d[9] & d[13] & 0x00010100u) << 32));
+    WGC = ((uint64_t)d[1] << 32) | d[2];
+    WNN = ((uint64_t)d[3] << 32) | d[4] | d[6] | d[7] | d[8] | d[10] | d[11] | d[12] | d[14] | d[15];
+  } else if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0) {
     uint32_t a0, a1, a2, a3 = 0, a4 = 0, b0, b1, b2, b3 = 0, b4 = 0;
-    uint32_t k12 = 0x0C0C0C0Cu;
-    asm("" : "+v"(k12));   // keep the constant in a VGPR (v_xad_u32 takes a single SGPR source)
-    masks32_ascii<STRUCT>(d, k12, a0, a1, a2, a3, a4);
-    masks32_ascii<STRUCT>(d + 8, k12, b0, b1, b2, b3, b4);
+    masks32_ascii<STRUCT>(d, mc, a0, a1, a2, a3, a4);
+    masks32_ascii<STRUCT>(d + 8, mc, b0, b1, b2, b3, b4);
     WNL = (uint64_t)a0 | ((uint64_t)b0 << 32);
     WGC = (uint64_t)a1 | ((uint64_t)b1 << 32);
     WNN = (uint64_t)a2 | ((uint64_t)b2 << 32);
@@ -481,7 +512,7 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
     t_st = st.p_st + (s_st << sh0); t_fat = st.p_fat + (s_fat << sh0); t_fpl = st.p_fpl + (s_fpl << sh0);
   }
 
-  if (total != 0) {   // wave-uniform: some lane of this tile holds a newline
+  if (total != 0 && SCFQ_ABLATE < 2) {   // wave-uniform: some lane of this tile holds a newline
     const int lane_base = lane * 64;
     const bool has1 = (NL != 0);
     {   // '\r' directly before the first newline?
@@ -583,6 +614,8 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
   if (prev_param == -2) prev_param = a.base[-1];
   prev_param = __builtin_amdgcn_readfirstlane(prev_param);
 
+  MaskConsts mc;
+  mc.init();
   WaveState st = {};
   // byte before this range's first tile: from memory when it belongs to the input, else the caller's halo
   st.prev_last = prev_param;
@@ -630,7 +663,7 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
     const uint8_t* sl = ring + slot * kTile;
     const uint64_t ts = A0 + t * kTile;
     if (ts >= B && ts + kTile <= E) {
-      process_tile_fast<STRUCT, HIST>(sl, lane, st, hist_lds);
+      process_tile_fast<STRUCT, HIST>(sl, lane, st, hist_lds, mc);
     } else {
       // valid bytes of this lane: absolute [ts + 64*lane, +64) intersected with [B, E)
       const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);

@@ -14,7 +14,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libsc_fqcount_hip.so")
+LIB_PATH = os.environ.get("SCFQ_LIB_OVERRIDE") or os.path.join(os.path.dirname(_HERE), "libsc_fqcount_hip.so")
 
 SCFQ_QUAL_HIST = 0x1
 SCFQ_STRUCT_CHECK = 0x2
