@@ -129,10 +129,12 @@ def main():
     t_start = time.perf_counter()
     kern_ms = 0.0
     fold_ms = 0.0
+    seen = set()
     for _ in range(args.steps):
         counts, t = step()
         kern_ms += t.scan_kernel_ms
         fold_ms += t.fold_kernel_ms
+        seen.add((counts.reads, counts.gc_bases, counts.n_bases, counts.bases, counts.lines))
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -140,6 +142,7 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    assert len(seen) == 1, ("steps disagree with each other", seen)   # every timed step produced the same counters
     # ---- correctness outside the timed region: generator tallies (independent of the scan) -------------
     # a rank owns the records that START inside its byte range; the record straddling its lower cut point
     # (generated here too, because the shard begins inside it) is tallied by the previous rank

@@ -7,15 +7,16 @@
 // decided by the ordered fold of the per-range partials (K2).
 //
 // K1 fq_scan_tiles : one wave = one contiguous "range" of 4 KiB tiles. Tiles are streamed
-//      HBM -> LDS with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB coalesced per
-//      instruction, 4 per tile, a 3-slot ring per wave => 8 KiB in flight per wave, no VGPR
-//      staging, no barriers: a wave only ever reads LDS bytes it loaded itself).  Each lane then
-//      owns 64 contiguous bytes of the tile (4 x ds_read_b128), turns them into three 64-bit
-//      match masks ('\n', G|C, N) with byte-transposed SWAR compares, gets its line phase from a
-//      DPP wave prefix-sum of newline counts, and adds per-segment popcounts into 8-bit packed
-//      per-class fields (4 classes in one VGPR; the class index is a shift amount, never a
-//      register index).  No MFMA: this is an HBM-bound byte reduction.
-// K2 fq_fold_partials : ordered (non-commutative) fold of the per-range partials.
+//      HBM -> LDS with non-temporal LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB coalesced
+//      per instruction, 4 per tile, a 2-slot ring per wave, no VGPR staging, no barriers: a wave only
+//      ever reads LDS bytes it loaded itself).  Each lane then owns 64 contiguous bytes of the tile
+//      (4 x ds_read_b128), turns them into 64-bit match masks ('\n', G|C, N [, '@', '+']) with
+//      byte-transposed carry-SWAR compares, gets its line phase from a DPP wave prefix-sum of newline
+//      counts, and adds per-segment popcounts into 8-bit packed per-class fields (4 classes in one
+//      VGPR; the class index is a shift amount, never a register index).  No MFMA: this is an
+//      HBM-bound byte reduction.
+// K2 fq_fold_fused : ordered (non-commutative) fold of the per-range partials, one launch.
+// K3 / K4          : quality-byte histogram / '@','+' structure check, fused variants of K1.
 //
 // Byte semantics follow Nim 1.0.6 readLine as used by the reference: '\n' ends a line, a '\r'
 // directly before that '\n' is not part of the line; G/C/N are case-sensitive (fq_count.nim:43-44).
@@ -195,28 +196,6 @@ __device__ __forceinline__ void masks32(const uint32_t* d, uint32_t& nl, uint32_
 }
 
 // ---- hand-scheduled ASCII form (the hot path; every op here is paid 64 x per tile) ---------------
-// Classifier: v_perm_b32 used as a byte-wise zero test.  A selector byte of 12 yields 0x00 and one
-// >= 13 yields 0xFF, so with t = b ^ c (<= 0x7F for ASCII) the selector t + 12 gives 0x00 exactly when
-// b == c and 0xFF otherwise: one v_xad_u32 (xor + add) and one v_perm_b32 per dword, and because
-// the result bytes are clean 0x00 / 0xFF no shift is needed to drop the flag of dword j onto
-// mask bit j: a v_bfi_b32 chain does it (7 per 8 dwords).  For G|C the selector is t = (b ^ 'C') & ~4
-// itself: 0 only for 'C'/'G' (-> source byte 0 = 0x00), never 12 (bit 2 is cleared), everything
-// else reads 0xFF (source bytes 1..7, their sign bits for 8..11, fixed 0xFF for >= 13).
-// Masks come out INVERTED (bit set = no match); consumers fold the complement into their bit ops.
-__device__ __forceinline__ uint32_t v_xad(uint32_t x, uint32_t c, uint32_t k) {
-  uint32_t r;
-  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(k));
-  return r;
-}
-__device__ __forceinline__ uint32_t v_bfi(uint32_t mask, uint32_t a, uint32_t b) {   // (a & mask) | (b & ~mask)
-  uint32_t r;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ uint32_t byte_nonzero_ff(uint32_t sel) {
-  return __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFF00u, sel);
-}
-
 // Measured issue cost on MI355X (scripts/ubench/valu_rate.hip, 8 waves/SIMD): plain VOP2 integer ops (and/or/xor/
 // add/shift/not) and v_bitop3_b32 take ~2.2 cycles per wave64 instruction per SIMD, every other VALU op used here
 // (v_perm, v_bfi, v_xad, v_bcnt, v_lshl_add, v_or3, v_and_or, DPP, v_cmp) ~3.7.  So the classifier below is written in
@@ -729,121 +708,113 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
 // K2: ordered fold.  state = state (+) P_0 (+) P_1 (+) ... ; also records each range's starting
 // phase (for the histogram fold) and finishes bytes / last_byte.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void partial_combine(uint64_t* acc, const uint64_t* b) {
-  const uint32_t k = (uint32_t)acc[W_NL] & 3u;
-#pragma unroll
-  for (int arr = W_GC; arr < W_BYTES; arr += 4) {
-    uint64_t t[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = acc[arr + r] + b[arr + ((r - k) & 3u)];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[arr + r] = t[r];
-  }
-  acc[W_NL] += b[W_NL];
-}
 
 constexpr int kFoldThreads = 256;
 constexpr int kFold1 = 128;   // ranges folded per level-1 block
 
-// Ordered tree fold of `cnt` partials held in LDS rows sh[i][0..W_BYTES), result in row 0.
-// Word-parallel: at each level one thread produces ONE word of ONE pair (A (+) B)[w] =
-// A[w] + B[rotated w], so there are no per-thread partial copies (the first version kept two
-// 25-word partials per thread in registers and spilled to scratch).
-template <int ROWS, int THREADS>
-__device__ __forceinline__ void lds_tree_fold(uint64_t (*sh)[W_BYTES + 1], int tid) {
-  for (int s = 1; s < ROWS; s <<= 1) {
-    const int pairs = ROWS / (2 * s);
-    uint64_t v[(ROWS / 2 * W_BYTES + THREADS - 1) / THREADS];
-    int n = 0;
-    for (int idx = tid; idx < pairs * W_BYTES; idx += THREADS, ++n) {
-      const int pr = idx / W_BYTES, w = idx % W_BYTES;
-      const int ia = pr * 2 * s, ib = ia + s;
-      if (w == W_NL) {
-        v[n] = sh[ia][W_NL] + sh[ib][W_NL];
-      } else {
-        const uint32_t k = (uint32_t)sh[ia][W_NL] & 3u;
-        const int arr = W_GC + ((w - W_GC) & ~3), r = (w - W_GC) & 3;
-        v[n] = sh[ia][w] + sh[ib][arr + ((r - k) & 3u)];
-      }
-    }
-    __syncthreads();
-    n = 0;
-    for (int idx = tid; idx < pairs * W_BYTES; idx += THREADS, ++n) {
-      const int pr = idx / W_BYTES, w = idx % W_BYTES;
-      sh[pr * 2 * s][w] = v[n];
-    }
-    __syncthreads();
-  }
-}
-
-// K2a: level-1 fold, one block per kFold1 consecutive ranges (coalesced load into LDS, ordered tree).
-// rel_phase[r] (optional) = newlines of the earlier ranges of the same block, mod 4.
-__global__ __launch_bounds__(kFold1) void fq_fold_level1(const uint64_t* partials, uint64_t n_ranges,
-                                                          uint64_t* block_out, uint8_t* rel_phase) {
-  __shared__ uint64_t sh[kFold1][W_BYTES + 1];
-  const int tid = threadIdx.x;
-  const uint64_t r0 = (uint64_t)blockIdx.x * kFold1;
-  const uint64_t cnt = (n_ranges - r0 < (uint64_t)kFold1) ? n_ranges - r0 : (uint64_t)kFold1;
-  const uint64_t* src = partials + r0 * kPartialWords;
-  for (int idx = tid; idx < kFold1 * kPartialWords; idx += kFold1) {
-    const int r = idx / kPartialWords, w = idx % kPartialWords;
-    if (w < W_BYTES) sh[r][w] = ((uint64_t)r < cnt) ? src[idx] : 0;
+// Ordered fold of up to T partials, one per thread, without an ordered tree: only (newline count mod 4) of the
+// predecessors matters, so   fold[c] = sum_t  P_t[(c - phase_t) & 3],  phase_t = (phase_in + sum_{u<t} nl_u) mod 4.
+// One block-wide exclusive scan of nl (wave DPP scan + LDS carry); every thread then writes its 25 words, already
+// rotated, as one row of an LDS matrix, and the columns are summed by (word, quarter-of-rows) threads.
+// lds_acc[0..W_BYTES) must be zero on entry; result in lds_acc.  Returns this thread's starting phase.
+// (A first version let all T threads ds_add_u64 into 25 shared words: 128-way same-address contention, 85 us.)
+template <int T>
+__device__ __forceinline__ uint32_t block_rotate_sum(const uint64_t* mine /*W_BYTES words, zeros if inactive*/,
+                                                     uint32_t phase_in, uint64_t* lds_acc, uint32_t* lds_wave,
+                                                     uint64_t (*rows)[W_BYTES + 1], int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  const uint32_t nl = (uint32_t)mine[W_NL];
+  const uint32_t incl = wave_inclusive_scan(nl);
+  if (lane == 63) lds_wave[w] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int k = 0; k < T / 64; ++k) before += (k < w) ? lds_wave[k] : 0u;
+  const uint32_t phase = (phase_in + before + incl - nl) & 3u;
+  rows[tid][W_NL] = mine[W_NL];
+#pragma unroll
+  for (int arr = W_GC; arr < W_BYTES; arr += 4) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rows[tid][arr + c] = mine[arr + ((c - phase) & 3u)];   // class r lands on (r + phase) & 3
   }
   __syncthreads();
-  if (rel_phase && tid == 0) {
-    uint32_t ph = 0;
-    for (uint64_t r = 0; r < cnt; ++r) { rel_phase[r0 + r] = (uint8_t)ph; ph = (ph + (uint32_t)sh[r][W_NL]) & 3u; }
+  const int word = tid & 31, part = tid >> 5;          // T / 32 row groups per word
+  if (word < W_BYTES) {
+    uint64_t sum = 0;
+    const int r0 = part * 32;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) sum += rows[r0 + r][word];
+    atomicAdd(reinterpret_cast<unsigned long long*>(&lds_acc[word]), (unsigned long long)sum);   // T/32-way only
   }
   __syncthreads();
-  lds_tree_fold<kFold1, kFold1>(sh, tid);
-  if (tid < kPartialWords) block_out[(uint64_t)blockIdx.x * kPartialWords + tid] = (tid < W_BYTES) ? sh[0][tid] : 0;
+  return phase;
 }
 
-// K2b: final fold over the level-1 block partials into the running state (carry-in for streaming);
-// also records each level-1 block's starting phase (histogram fold) and finishes bytes / last_byte.
-__global__ __launch_bounds__(kFoldThreads) void fq_fold_partials(const uint64_t* partials, uint64_t n_ranges,
-                                                                 uint64_t* state, uint8_t* range_phase,
-                                                                 const uint8_t* base, uint64_t n) {
-  __shared__ uint64_t sh[kFoldThreads][W_BYTES + 1];
+// K2 (single launch): every block folds kFold1 consecutive range partials (phase relative to the block start) and
+// publishes its block partial; the LAST block to finish (agent-scope release -> ticket -> acquire, the hand-off
+// recipe of cdna_hip_programming.md Guideline 16 in its counter form) folds the block partials
+// into the running state (carry-in for streaming chunks), finishes bytes / last_byte and re-arms the ticket.
+// rel_phase / block_phase (optional, histogram fold): starting phase of each range inside its block / of each block.
+__global__ __launch_bounds__(kFold1) void fq_fold_fused(const uint64_t* partials, uint64_t n_ranges, uint64_t* block_out,
+                                                         uint32_t* ticket, uint64_t* state, int reset,
+                                                         uint8_t* rel_phase, uint8_t* block_phase,
+                                                         const uint8_t* base, uint64_t n) {
+  __shared__ uint64_t acc[kPartialWords];
+  __shared__ uint32_t wave_tot[kFold1 / 64];
+  __shared__ uint64_t rows[kFold1][W_BYTES + 1];
+  __shared__ uint32_t is_last;
   const int tid = threadIdx.x;
-  // row `tid` <- ordered fold of a contiguous run of inputs (normally 0 or 1 of them: <= 256 block partials)
-  const uint64_t per = (n_ranges + kFoldThreads - 1) / kFoldThreads;
-  uint64_t lo = (uint64_t)tid * per, hi = lo + per;
-  if (lo > n_ranges) lo = n_ranges;
-  if (hi > n_ranges) hi = n_ranges;
-  for (int k = 0; k < W_BYTES; ++k) sh[tid][k] = 0;
-  for (uint64_t r = lo; r < hi; ++r) {
+  const uint32_t n_blocks = gridDim.x;
+  if (tid < kPartialWords) acc[tid] = 0;
+  __syncthreads();
+  {
+    const uint64_t r = (uint64_t)blockIdx.x * kFold1 + tid;
+    uint64_t mine[W_BYTES];
     const uint64_t* src = partials + r * kPartialWords;
-    const uint32_t k = (uint32_t)sh[tid][W_NL] & 3u;
-    uint64_t t[W_BYTES];
-    for (int w = W_GC; w < W_BYTES; ++w) {
-      const int arr = W_GC + ((w - W_GC) & ~3), q = (w - W_GC) & 3;
-      t[w] = sh[tid][w] + src[arr + ((q - k) & 3u)];
+#pragma unroll
+    for (int k = 0; k < W_BYTES; ++k) mine[k] = (r < n_ranges) ? src[k] : 0;
+    const uint32_t ph = block_rotate_sum<kFold1>(mine, 0u, acc, wave_tot, rows, tid);
+    if (rel_phase && r < n_ranges) rel_phase[r] = (uint8_t)ph;
+    if (tid < kPartialWords) block_out[(uint64_t)blockIdx.x * kPartialWords + tid] = (tid < W_BYTES) ? acc[tid] : 0;
+  }
+  // ---- publish, take a ticket --------------------------------------------------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == n_blocks - 1) ? 1u : 0u;
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    for (int w = W_GC; w < W_BYTES; ++w) sh[tid][w] = t[w];
-    sh[tid][W_NL] += src[W_NL];
   }
   __syncthreads();
-  if (range_phase && tid == 0) {
-    // starting phase of every input = (state.nl + newlines of all earlier inputs) mod 4
-    uint32_t ph = (uint32_t)state[W_NL] & 3u;
-    for (uint64_t r = 0; r < n_ranges; ++r) {
-      range_phase[r] = (uint8_t)ph;
-      ph = (ph + (uint32_t)partials[r * kPartialWords + W_NL]) & 3u;
-    }
+  if (!is_last) return;
+  // ---- last block: fold the block partials (kFold1 threads, ceil(n_blocks / kFold1) passes of <= kFold1 each) ---
+  uint32_t phase_in = reset ? 0u : ((uint32_t)state[W_NL] & 3u);
+  uint64_t run = 0;        // thread w < W_BYTES keeps word w of the running fold
+  const uint64_t old = (!reset && tid < W_BYTES) ? state[tid] : 0;
+  for (uint32_t b0 = 0; b0 < n_blocks; b0 += kFold1) {
+    if (tid < kPartialWords) acc[tid] = 0;
+    __syncthreads();
+    const uint32_t b = b0 + tid;
+    uint64_t mine[W_BYTES];
+    const uint64_t* src = block_out + (uint64_t)b * kPartialWords;
+#pragma unroll
+    for (int k = 0; k < W_BYTES; ++k) mine[k] = (b < n_blocks) ? src[k] : 0;
+    const uint32_t ph = block_rotate_sum<kFold1>(mine, phase_in, acc, wave_tot, rows, tid);
+    if (block_phase && b < n_blocks) block_phase[b] = (uint8_t)ph;
+    if (tid < W_BYTES) run += acc[tid];
+    phase_in = (phase_in + (uint32_t)acc[W_NL]) & 3u;
+    __syncthreads();
   }
-  lds_tree_fold<kFoldThreads, kFoldThreads>(sh, tid);
+  if (tid < W_BYTES) state[tid] = old + run;   // class words were already rotated by the carried-in phase
   if (tid == 0) {
-    const uint32_t k = (uint32_t)state[W_NL] & 3u;
-    uint64_t t[W_BYTES];
-    for (int w = W_GC; w < W_BYTES; ++w) {
-      const int arr = W_GC + ((w - W_GC) & ~3), q = (w - W_GC) & 3;
-      t[w] = state[w] + sh[0][arr + ((q - k) & 3u)];
-    }
-    for (int w = W_GC; w < W_BYTES; ++w) state[w] = t[w];
-    state[W_NL] += sh[0][W_NL];
-    state[W_BYTES] += n;
-    if (n) state[W_LAST] = base[n - 1];
+    state[W_BYTES] = (reset ? 0 : state[W_BYTES]) + n;
+    if (n) state[W_LAST] = base[n - 1]; else if (reset) state[W_LAST] = 0;
+    *ticket = 0;   // re-arm for the next launch (stream order makes this visible to it)
   }
 }
 

@@ -59,7 +59,11 @@ struct Ctx {
   uint64_t cap_blocks = 0;
   uint64_t* d_state = nullptr;   // [32 partial words][1024 hist words]
   uint64_t* h_state = nullptr;   // pinned mirror
-  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
+  std::vector<hipEvent_t> ev_pool;     // timing events, 3 per scan launch of the current session
+  size_t ev_used = 0;
+  std::vector<uint64_t> ev_bytes;      // bytes of each timed launch
+  uint32_t* d_ticket = nullptr;        // arrival counter of the fused fold (re-armed by the kernel)
+  bool fresh = true;                   // no scan folded into d_state yet in this session
   // staging (host buffers / files)
   uint8_t* d_stage[2] = {nullptr, nullptr};
   uint8_t* h_pin[2] = {nullptr, nullptr};
@@ -94,9 +98,8 @@ int get_ctx(Ctx** out) {
   HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&c->d_state, kStateWords * sizeof(uint64_t)));
   HIPCHK(hipHostMalloc(&c->h_state, kStateWords * sizeof(uint64_t), hipHostMallocDefault));
-  HIPCHK(hipEventCreate(&c->ev_t0));
-  HIPCHK(hipEventCreate(&c->ev_t1));
-  HIPCHK(hipEventCreate(&c->ev_t2));
+  HIPCHK(hipMalloc(&c->d_ticket, sizeof(uint32_t)));
+  HIPCHK(hipMemset(c->d_ticket, 0, sizeof(uint32_t)));
   for (int b = 0; b < 2; ++b) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_scanned[b], hipEventDisableTiming));
@@ -203,7 +206,14 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
   a.partials = c->d_partials;
   a.hist_partials = c->d_hist_partials;
   const unsigned blocks = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
-  if (timing) HIPCHK(hipEventRecord(c->ev_t0, c->compute));
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  if (timing) {
+    while (c->ev_pool.size() < c->ev_used + 3) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    for (int k = 0; k < 3; ++k) ev[k] = c->ev_pool[c->ev_used + k];
+    c->ev_used += 3;
+    c->ev_bytes.push_back(n);
+    HIPCHK(hipEventRecord(ev[0], c->compute));
+  }
   if (hist && strct) launch_scan<true, true, 2, true>(a, blocks, c->compute);
   else if (hist) launch_scan<false, true, 2, true>(a, blocks, c->compute);
   else if (strct) launch_scan<true, false, 2, true>(a, blocks, c->compute);
@@ -218,48 +228,54 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
     else launch_scan<false, false, 3, false>(a, blocks, c->compute);
   }
   HIPCHK(hipGetLastError());
-  if (timing) HIPCHK(hipEventRecord(c->ev_t1, c->compute));
+  if (timing) HIPCHK(hipEventRecord(ev[1], c->compute));
   {
     const uint64_t n_blocks = (n_ranges + scfq::kFold1 - 1) / scfq::kFold1;
     uint8_t* rel_phase = hist ? c->d_range_phase : nullptr;
     uint8_t* block_phase = hist ? c->d_range_phase + c->cap_hist_ranges : nullptr;
-    hipLaunchKernelGGL(scfq::fq_fold_level1, dim3((unsigned)n_blocks), dim3(scfq::kFold1), 0, c->compute, c->d_partials,
-                       n_ranges, c->d_block_partials, rel_phase);
+    if (hist && c->fresh)
+      HIPCHK(hipMemsetAsync(c->d_state + SCFQ_PARTIAL_WORDS, 0, SCFQ_HIST_WORDS * sizeof(uint64_t), c->compute));
+    hipLaunchKernelGGL(scfq::fq_fold_fused, dim3((unsigned)n_blocks), dim3(scfq::kFold1), 0, c->compute, c->d_partials,
+                       n_ranges, c->d_block_partials, c->d_ticket, c->d_state, c->fresh ? 1 : 0, rel_phase, block_phase,
+                       dptr, n);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_block_partials,
-                       n_blocks, c->d_state, block_phase, dptr, n);
-    HIPCHK(hipGetLastError());
+    c->fresh = false;
     if (hist) {
       hipLaunchKernelGGL(scfq::fq_fold_hist, dim3((unsigned)n_blocks), dim3(256), 0, c->compute, c->d_hist_partials,
                          rel_phase, block_phase, n_ranges, (unsigned long long*)(c->d_state + SCFQ_PARTIAL_WORDS));
       HIPCHK(hipGetLastError());
     }
   }
-  if (timing) {
-    HIPCHK(hipEventRecord(c->ev_t2, c->compute));
-    HIPCHK(hipEventSynchronize(c->ev_t2));
-    float ms1 = 0, ms2 = 0;
-    HIPCHK(hipEventElapsedTime(&ms1, c->ev_t0, c->ev_t1));
-    HIPCHK(hipEventElapsedTime(&ms2, c->ev_t1, c->ev_t2));
-    c->timing.scan_kernel_ms += ms1;
-    c->timing.fold_kernel_ms += ms2;
-    c->timing.scan_bytes += n;
-    c->timing.scan_launches += 1;
-  }
+  if (timing) HIPCHK(hipEventRecord(ev[2], c->compute));   // resolved in end_session, after the one stream sync
   return SCFQ_OK;
 }
 
 int begin_session(Ctx* c) {
   c->timing = scfq_timing{};
   c->timing.struct_size = sizeof(scfq_timing);
-  HIPCHK(hipMemsetAsync(c->d_state, 0, kStateWords * sizeof(uint64_t), c->compute));
+  c->ev_used = 0;
+  c->ev_bytes.clear();
+  c->fresh = true;   // the first fold of the session overwrites d_state (no memset launch)
   return SCFQ_OK;
 }
 
 int end_session(Ctx* c, bool hist, scfq_partial* out, uint64_t* hist_out) {
   const size_t words = hist ? kStateWords : SCFQ_PARTIAL_WORDS;
-  HIPCHK(hipMemcpyAsync(c->h_state, c->d_state, words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
-  HIPCHK(hipStreamSynchronize(c->compute));
+  if (c->fresh) {   // nothing was scanned (empty input)
+    std::memset(c->h_state, 0, words * sizeof(uint64_t));
+  } else {
+    HIPCHK(hipMemcpyAsync(c->h_state, c->d_state, words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+  }
+  for (size_t k = 0; k + 2 < c->ev_used + 0 && k < c->ev_used; k += 3) {
+    float ms1 = 0, ms2 = 0;
+    HIPCHK(hipEventElapsedTime(&ms1, c->ev_pool[k], c->ev_pool[k + 1]));
+    HIPCHK(hipEventElapsedTime(&ms2, c->ev_pool[k + 1], c->ev_pool[k + 2]));
+    c->timing.scan_kernel_ms += ms1;
+    c->timing.fold_kernel_ms += ms2;
+    c->timing.scan_bytes += c->ev_bytes[k / 3];
+    c->timing.scan_launches += 1;
+  }
   std::memcpy(out, c->h_state, sizeof(scfq_partial));
   if (hist && hist_out) std::memcpy(hist_out, c->h_state + SCFQ_PARTIAL_WORDS, SCFQ_HIST_WORDS * sizeof(uint64_t));
   g_last_timing = c->timing;
@@ -746,9 +762,8 @@ int scfq_shutdown(void) {
     if (c->d_range_phase) (void)hipFree(c->d_range_phase);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
-    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
-    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
-    if (c->ev_t2) (void)hipEventDestroy(c->ev_t2);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
   }
@@ -820,12 +835,11 @@ int scfq_debug_partial_simple(const void* dptr, uint64_t n, int prev_byte, scfq_
                        static_cast<const uint8_t*>(dptr), n, prev_byte, chunks, c->d_partials);
     HIPCHK(hipGetLastError());
     const uint64_t n_blocks = (chunks + scfq::kFold1 - 1) / scfq::kFold1;
-    hipLaunchKernelGGL(scfq::fq_fold_level1, dim3((unsigned)n_blocks), dim3(scfq::kFold1), 0, c->compute, c->d_partials,
-                       chunks, c->d_block_partials, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(scfq::fq_fold_fused, dim3((unsigned)n_blocks), dim3(scfq::kFold1), 0, c->compute, c->d_partials,
+                       chunks, c->d_block_partials, c->d_ticket, c->d_state, 1, (uint8_t*)nullptr, (uint8_t*)nullptr,
+                       static_cast<const uint8_t*>(dptr), n);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(scfq::fq_fold_partials, dim3(1), dim3(scfq::kFoldThreads), 0, c->compute, c->d_block_partials,
-                       n_blocks, c->d_state, (uint8_t*)nullptr, static_cast<const uint8_t*>(dptr), n);
-    HIPCHK(hipGetLastError());
+    c->fresh = false;
   }
   return end_session(c, false, out, nullptr);
 }

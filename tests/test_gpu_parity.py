@@ -209,3 +209,21 @@ def test_worst_case_newline_density(gpu, scfq, oracle):
             ow = oracle.partial(a, -1)
             want = [int(x) for x in ow[:25]] if flags else [int(x) for x in ow[:13]] + [0] * 12
             assert p.words()[:25] == want, (pattern, flags)
+
+
+def test_multi_device_option_paths(gpu, scfq, oracle, tmp_path):
+    """scfq_opts.n_devices > 1: byte-range shards at arbitrary cut points, one ingest thread per listed device, host
+    fold in shard order. A 1-GPU box lists device 0 several times (sessions on one device are serialised)."""
+    rng = np.random.default_rng(21)
+    a = random_fastq_like(rng, 9_000_001, "crlf")
+    oc = oracle.count(a)
+    for devs in ([0, 0], [0, 0, 0]):
+        c = scfq.count_host(a, devices=devs, flags=scfq.SCFQ_QUAL_HIST | scfq.SCFQ_STRUCT_CHECK, chunk_bytes=1 << 20)
+        for f in REF_FIELDS + ("bad_at", "bad_plus"):
+            assert getattr(c, f) == getattr(oc, f), (devs, f)
+        assert list(c.qual_hist) == list(oc.qual_hist)
+    p = tmp_path / "big.fq"
+    a.tofile(p)
+    c = scfq.count_file(str(p), devices=[0, 0, 0, 0], chunk_bytes=1 << 20)
+    for f in REF_FIELDS:
+        assert getattr(c, f) == getattr(oc, f), f
