@@ -35,19 +35,23 @@ def exchange_partials(partial, device=None, group=None, hist=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return partial, hist
-    mine = torch.tensor(_to_i64(partial.words()), dtype=torch.int64, device=device)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    hists = None
+    words = _to_i64(partial.words())
     if hist is not None:
-        hm = torch.tensor(_to_i64(list(hist)), dtype=torch.int64, device=device)
-        hists = [torch.empty_like(hm) for _ in range(world)]
-        dist.all_gather(hists, hm, group=group)
+        words = words + _to_i64(list(hist))        # one message per rank: partial (+ histogram)
+    mine = torch.tensor(words, dtype=torch.int64, device=device)
+    out = torch.empty(world * mine.numel(), dtype=torch.int64, device=device)
+    try:
+        dist.all_gather_into_tensor(out, mine, group=group)      # one collective, one contiguous result
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        out = torch.cat(parts)
+    rows = out.view(world, mine.numel()).cpu().tolist()           # a single device->host copy
     acc = scfq.identity()
     import ctypes
     acc_h = (ctypes.c_uint64 * scfq.HIST_WORDS)() if hist is not None else None
     for r in range(world):
-        p = scfq.Partial.from_words(_from_i64(gathered[r].tolist()))
-        h = (ctypes.c_uint64 * scfq.HIST_WORDS)(*_from_i64(hists[r].tolist())) if hist is not None else None
+        p = scfq.Partial.from_words(_from_i64(rows[r][:scfq.PARTIAL_WORDS]))
+        h = (ctypes.c_uint64 * scfq.HIST_WORDS)(*_from_i64(rows[r][scfq.PARTIAL_WORDS:])) if hist is not None else None
         scfq.combine(acc, p, acc_h, h)
     return acc, acc_h
