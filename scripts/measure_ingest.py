@@ -57,6 +57,7 @@ member = 64 << 20
 parts = [data[i:i + member] for i in range(0, data.size, member)]
 with ThreadPoolExecutor(32) as ex:
     blobs = list(ex.map(lambda a: gzip.compress(a.tobytes(), 6), parts))
+blobs_gz = blobs
 gzm = os.path.join(tmp, "scfq_multi_member.fq.gz")
 with open(gzm, "wb") as f:
     for b in blobs: f.write(b)
@@ -88,5 +89,18 @@ os.environ["SCFQ_NO_BGZF"] = "1"
 t = time.time(); c = scfq.count_file(bgz, flags=scfq.SCFQ_TIMING); dt = time.time() - t
 check(c)
 row("same BGZF file through serial gzread (SCFQ_NO_BGZF=1)", inflated_bytes=data.size, wall_s=round(dt, 3), inflated_GBps=round(data.size / dt / 1e9, 3))
-for p in (plain, gz1, gzm, bgz):
+# many files: sequential (the reference's loop, sc.nim:115-116) vs --jobs=8 (8 sessions sharing the GPU)
+import subprocess
+sc = os.path.join(ROOT, "seq-collection_amd", "sc")
+many = []
+for i in range(8):
+    p = os.path.join(tmp, "scfq_many_%d.fq.gz" % i)
+    with open(p, "wb") as f:
+        for k in range(4): f.write(blobs_gz[(4 * i + k) % len(blobs_gz)])
+    many.append(p)
+for jobs in (1, 8):
+    t = time.time(); r = subprocess.run([sc, "fq-count", "--jobs=%d" % jobs] + many, capture_output=True, text=True); dt = time.time() - t
+    assert r.returncode == 0 and len(r.stdout.splitlines()) == 8, r.stderr
+    row("8 gzip files (256 MiB inflated each), sc fq-count --jobs=%d (process start included)" % jobs, wall_s=round(dt, 3), inflated_GBps=round(8 * 4 * (64 << 20) / dt / 1e9, 3))
+for p in [plain, gz1, gzm, bgz] + many:
     os.remove(p)

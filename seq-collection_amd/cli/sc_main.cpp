@@ -16,7 +16,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -111,7 +116,8 @@ static void help_fq_count(FILE* f) {   // docs/fq-count.md:5-19
       "      --devices=LIST         Comma-separated HIP device ids to shard each file across (default: current device)\n"
       "      --struct-check         Report header lines not starting '@' / separator lines not starting '+' on stderr\n"
       "      --qual-hist            Print the quality-byte histogram on stderr\n"
-      "      --stats                Print bytes / device milliseconds / GB/s as JSON on stderr\n",
+      "      --stats                Print bytes / device milliseconds / GB/s as JSON on stderr\n"
+      "      --jobs=N               Keep up to N files in flight (rows still come out in argument order)\n",
       f);
 }
 
@@ -129,9 +135,18 @@ static bool stdin_is_fifo() {   // sc.nim:50-53
   return fstat(0, &st) == 0 && S_ISFIFO(st.st_mode);
 }
 
-// proc fq_count*(fastq: string, basename: bool, absolute: bool)      src/fq_count.nim:14
-static void fq_count(const std::string& fastq, bool basename, bool absolute, const scfq_opts& opts, bool stats) {
-  if (fastq.size() < 3) quit_error("index out of bounds", 1);   // fastq[^3 .. ^1] raises; sc.nim:299-305 -> exit 1
+// One file's outcome: what proc fq_count would have echoed / which error it would have quit with.
+struct FileResult {
+  int exit_code = 0;          // 0, or the quit_error code
+  std::string error;          // message for quit_error
+  std::string row;            // stdout line (without newline)
+  std::string extra;          // stderr lines of the MI355X additions
+};
+
+// proc fq_count*(fastq: string, basename: bool, absolute: bool)      src/fq_count.nim:14  (compute part)
+static FileResult fq_count_compute(const std::string& fastq, bool basename, bool absolute, const scfq_opts& opts, bool stats) {
+  FileResult r;
+  if (fastq.size() < 3) { r.exit_code = 1; r.error = "index out of bounds"; return r; }   // fastq[^3 .. ^1] raises; sc.nim:299-305 -> exit 1
   scfq_counts c;
   std::memset(&c, 0, sizeof c);
   c.struct_size = sizeof c;
@@ -139,25 +154,30 @@ static void fq_count(const std::string& fastq, bool basename, bool absolute, con
   if (rc == SCFQ_EOPEN) {
     const bool gz = fastq.compare(fastq.size() - 3, 3, ".gz") == 0;
     // plain: stream == nil -> quit_error(..., 2) (fq_count.nim:35-36); .gz: the stream constructor raises -> exit 1 (sc.nim:299-305)
-    quit_error("Unable to open file: " + fastq, gz ? 1 : 2);
+    r.exit_code = gz ? 1 : 2;
+    r.error = "Unable to open file: " + fastq;
+    return r;
   }
   if (rc != SCFQ_OK) {
-    std::string m = std::string(scfq_strerror(rc));
+    r.exit_code = 1;
+    r.error = std::string(scfq_strerror(rc));
     const char* d = scfq_last_error_detail();
-    if (d && *d) { m += ": "; m += d; }
-    quit_error(m, 1);
+    if (d && *d) { r.error += ": "; r.error += d; }
+    return r;
   }
   char row[256];
   scfq_format_tsv(&c, row, sizeof row);
-  std::printf("%s\n", output_w_fnames(row, fastq, basename, absolute).c_str());   // echo ...  fq_count.nim:53
-  if (std::fflush(stdout) != 0) { /* EPIPE is swallowed like sc.nim:304 */ }
-  if (opts.flags & SCFQ_STRUCT_CHECK)
-    std::fprintf(stderr, "%s\tbad_at=%llu\tbad_plus=%llu\n", fastq.c_str(), (unsigned long long)c.bad_at, (unsigned long long)c.bad_plus);
+  r.row = output_w_fnames(row, fastq, basename, absolute);
+  char buf[512];
+  if (opts.flags & SCFQ_STRUCT_CHECK) {
+    std::snprintf(buf, sizeof buf, "%s\tbad_at=%llu\tbad_plus=%llu\n", fastq.c_str(), (unsigned long long)c.bad_at, (unsigned long long)c.bad_plus);
+    r.extra += buf;
+  }
   if (opts.flags & SCFQ_QUAL_HIST) {
-    std::fprintf(stderr, "%s\tqual_hist", fastq.c_str());
+    r.extra += fastq + "\tqual_hist";
     for (int v = 0; v < 256; ++v)
-      if (c.qual_hist[v]) std::fprintf(stderr, "\t%d:%llu", v, (unsigned long long)c.qual_hist[v]);
-    std::fprintf(stderr, "\n");
+      if (c.qual_hist[v]) { std::snprintf(buf, sizeof buf, "\t%d:%llu", v, (unsigned long long)c.qual_hist[v]); r.extra += buf; }
+    r.extra += "\n";
   }
   if (stats) {
     scfq_timing t;
@@ -165,14 +185,25 @@ static void fq_count(const std::string& fastq, bool basename, bool absolute, con
     t.struct_size = sizeof t;
     scfq_last_timing(&t);
     const double gbs = t.scan_kernel_ms > 0 ? (double)t.scan_bytes / (t.scan_kernel_ms * 1e-3) / 1e9 : 0.0;
-    std::fprintf(stderr,
-                 "{\"file\": \"%s\", \"input_bytes\": %llu, \"scan_kernel_ms\": %.4f, \"fold_kernel_ms\": %.4f, "
-                 "\"scan_launches\": %llu, \"scan_GBps\": %.1f, \"hbm_peak_GBps\": 8000, \"roofline_frac\": %.4f, "
-                 "\"host_fill_ms\": %.2f, \"ingest_wall_ms\": %.2f, \"h2d_bytes\": %llu}\n",
-                 fastq.c_str(), (unsigned long long)c.input_bytes, t.scan_kernel_ms, t.fold_kernel_ms,
-                 (unsigned long long)t.scan_launches, gbs, gbs / 8000.0, t.host_fill_ms, t.ingest_wall_ms,
-                 (unsigned long long)t.h2d_bytes);
+    char js[1024];
+    std::snprintf(js, sizeof js,
+                  "{\"file\": \"%s\", \"input_bytes\": %llu, \"scan_kernel_ms\": %.4f, \"fold_kernel_ms\": %.4f, "
+                  "\"scan_launches\": %llu, \"scan_GBps\": %.1f, \"hbm_peak_GBps\": 8000, \"roofline_frac\": %.4f, "
+                  "\"host_fill_ms\": %.2f, \"ingest_wall_ms\": %.2f, \"h2d_bytes\": %llu}\n",
+                  fastq.c_str(), (unsigned long long)c.input_bytes, t.scan_kernel_ms, t.fold_kernel_ms,
+                  (unsigned long long)t.scan_launches, gbs, gbs / 8000.0, t.host_fill_ms, t.ingest_wall_ms,
+                  (unsigned long long)t.h2d_bytes);
+    r.extra += js;
   }
+  return r;
+}
+
+// ... and its output part: echo the row (fq_count.nim:53) or quit_error
+static void fq_count_emit(const FileResult& r) {
+  if (r.exit_code) quit_error(r.error, r.exit_code);
+  std::printf("%s\n", r.row.c_str());
+  if (std::fflush(stdout) != 0) { /* EPIPE is swallowed like sc.nim:304 */ }
+  if (!r.extra.empty()) std::fputs(r.extra.c_str(), stderr);
 }
 
 int main(int argc, char** argv) {
@@ -190,6 +221,7 @@ int main(int argc, char** argv) {
   if (params.size() == 1) { help_fq_count(stdout); return 0; }   // sc.nim:288-290: len <= 1 -> "-h"
 
   bool header = false, basename = false, absolute = false, stats = false;
+  int jobs = 1;
   std::vector<std::string> files;
   std::vector<int32_t> devices;
   uint32_t flags = 0;
@@ -206,6 +238,7 @@ int main(int argc, char** argv) {
     else if (a == "--struct-check") flags |= SCFQ_STRUCT_CHECK;
     else if (a == "--qual-hist") flags |= SCFQ_QUAL_HIST;
     else if (a == "--stats") { stats = true; flags |= SCFQ_TIMING; }
+    else if (a.rfind("--jobs=", 0) == 0) jobs = std::max(1, std::atoi(a.substr(7).c_str()));
     else if (a.rfind("--devices=", 0) == 0) {
       const std::string list = a.substr(10);
       size_t p = 0;
@@ -239,7 +272,40 @@ int main(int argc, char** argv) {
 
   if (header) std::printf("%s\n", output_header(kHeader, basename, absolute).c_str());   // sc.nim:110-111
   else if (files.empty()) quit_error("No FASTQ specified", 3);                           // sc.nim:112-113
-  for (const auto& f : files) fq_count(f, basename, absolute, opts, stats);             // sc.nim:114-116
+  if (jobs <= 1 || files.size() <= 1) {
+    for (const auto& f : files) fq_count_emit(fq_count_compute(f, basename, absolute, opts, stats));   // sc.nim:114-116
+  } else {
+    // --jobs=N: up to N files in flight (each a session on its own device context: inflate / read of one file overlaps
+    // the scans of the others); rows are still emitted strictly in argv order, and the first failing file ends the
+    // run with the reference's message and exit code exactly where the sequential loop would have.
+    std::vector<FileResult> results(files.size());
+    std::vector<char> done(files.size(), 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    const size_t nthreads = std::min<size_t>((size_t)jobs, files.size());
+    for (size_t t = 0; t < nthreads; ++t)
+      pool.emplace_back([&] {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= files.size()) return;
+          FileResult r = fq_count_compute(files[i], basename, absolute, opts, stats);
+          { std::lock_guard<std::mutex> lk(mu); results[i] = std::move(r); done[i] = 1; }
+          cv.notify_all();
+        }
+      });
+    for (size_t i = 0; i < files.size(); ++i) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[i] != 0; }); }
+      if (results[i].exit_code) {   // stop handing out files, let the in-flight ones finish, then quit like the sequential loop
+        next.store(files.size());
+        for (auto& th : pool) th.join();
+        scfq_shutdown();
+      }
+      fq_count_emit(results[i]);
+    }
+    for (auto& th : pool) if (th.joinable()) th.join();
+  }
   scfq_shutdown();
   return 0;
 }

@@ -73,22 +73,52 @@ struct Ctx {
   std::mutex mu;   // one counting session at a time per device context
 };
 
-// Serialises sessions that target the same device (e.g. --devices=0,0); distinct devices run concurrently.
+// A session owns one context for its whole life. Every device has a small POOL of contexts (own streams, pinned
+// and device buffers), so several host threads can run sessions on the same GPU concurrently — e.g. `sc fq-count
+// --jobs=8 *.fq.gz` inflates 8 files at once while their scans share the device.
 struct SessionLock {
   std::unique_lock<std::mutex> lk;
-  void acquire(Ctx* c) { lk = std::unique_lock<std::mutex>(c->mu); }
+  void acquire(Ctx*) {}   // the context returned by get_ctx() is already locked into this object
 };
 
+int env_int(const char* name, int dflt);
+
 std::mutex g_mu;
-std::map<int, std::unique_ptr<Ctx>> g_ctx;
+std::map<int, std::vector<std::unique_ptr<Ctx>>> g_ctx;
 thread_local scfq_timing g_last_timing{};
 
-int get_ctx(Ctx** out) {
+int new_ctx(int dev, std::unique_ptr<Ctx>* out);
+
+int get_ctx(Ctx** out, SessionLock& sl) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_ctx.find(dev);
-  if (it != g_ctx.end()) { *out = it->second.get(); return SCFQ_OK; }
+  static const int max_ctx = std::max(1, std::min(64, env_int("SCFQ_MAX_SESSIONS", 16)));
+  Ctx* wait_on = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto& pool = g_ctx[dev];
+    for (auto& c : pool) {
+      std::unique_lock<std::mutex> try_lk(c->mu, std::try_to_lock);
+      if (try_lk.owns_lock()) { sl.lk = std::move(try_lk); *out = c.get(); return SCFQ_OK; }
+    }
+    if ((int)pool.size() < max_ctx) {
+      std::unique_ptr<Ctx> c;
+      int rc = new_ctx(dev, &c);
+      if (rc) return rc;
+      sl.lk = std::unique_lock<std::mutex>(c->mu);
+      *out = c.get();
+      pool.push_back(std::move(c));
+      return SCFQ_OK;
+    }
+    static unsigned rr = 0;
+    wait_on = pool[rr++ % pool.size()].get();
+  }
+  sl.lk = std::unique_lock<std::mutex>(wait_on->mu);   // every context busy: queue behind one of them
+  *out = wait_on;
+  return SCFQ_OK;
+}
+
+int new_ctx(int dev, std::unique_ptr<Ctx>* out) {
   auto c = std::make_unique<Ctx>();
   c->dev = dev;
   hipDeviceProp_t prop;
@@ -104,8 +134,7 @@ int get_ctx(Ctx** out) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_scanned[b], hipEventDisableTiming));
   }
-  *out = c.get();
-  g_ctx[dev] = std::move(c);
+  *out = std::move(c);
   return SCFQ_OK;
 }
 
@@ -523,12 +552,11 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
 int partial_on_current_device(const void* ptr, uint64_t n, int is_device, int prev_byte, const scfq_opts* opts,
                               scfq_partial* out, uint64_t* hist) {
   Ctx* c = nullptr;
-  int rc = get_ctx(&c);
+  SessionLock sl;
+  int rc = get_ctx(&c, sl);
   if (rc) return rc;
   const uint32_t flags = opt_flags(opts);
   const bool timing = flags & SCFQ_TIMING;
-  SessionLock sl;
-  sl.acquire(c);
   rc = begin_session(c);
   if (rc) return rc;
   if (is_device) {
@@ -641,8 +669,8 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
         if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { close(bfd); return SCFQ_EHIP; }
         Ctx* c = nullptr;
         SessionLock sl;
-        rc = get_ctx(&c);
-        if (!rc) { sl.acquire(c); rc = begin_session(c); }
+        rc = get_ctx(&c, sl);
+        if (!rc) rc = begin_session(c);
         if (!rc) {
           BgzfSource src(bfd, (uint64_t)bsb.st_size);
           rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
@@ -661,8 +689,8 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
     if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { gzclose(f); return SCFQ_EHIP; }
     Ctx* c = nullptr;
     SessionLock sl;
-    rc = get_ctx(&c);
-    if (!rc) { sl.acquire(c); rc = begin_session(c); }
+    rc = get_ctx(&c, sl);
+    if (!rc) rc = begin_session(c);
     if (!rc) {
       GzSource src(f);
       rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
@@ -693,8 +721,8 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
         if (lo) { uint8_t pb; if (pread(fd, &pb, 1, (off_t)(lo - 1)) != 1) { rcs[d] = SCFQ_EIO; return; } prev = pb; }
         Ctx* c = nullptr;
         SessionLock sl;
-        int r = get_ctx(&c);
-        if (!r) { sl.acquire(c); r = begin_session(c); }
+        int r = get_ctx(&c, sl);
+        if (!r) r = begin_session(c);
         if (!r) { FdSource src(fd, lo, hi); r = ingest(c, src, prev, o.flags, opt_chunk(&o), timing); }
         if (!r) r = end_session(c, want_hist, &parts[d], want_hist ? hists[d].data() : nullptr);
         rcs[d] = r;
@@ -711,8 +739,8 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
   if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { close(fd); return SCFQ_EHIP; }
   Ctx* c = nullptr;
   SessionLock sl;
-  rc = get_ctx(&c);
-  if (!rc) { sl.acquire(c); rc = begin_session(c); }
+  rc = get_ctx(&c, sl);
+  if (!rc) rc = begin_session(c);
   if (!rc) {
     if (regular) {
       FdSource src(fd, 0, size);
@@ -745,8 +773,9 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
 
 int scfq_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (auto& kv : g_ctx) {
-    Ctx* c = kv.second.get();
+  for (auto& kv : g_ctx)
+   for (auto& up : kv.second) {
+    Ctx* c = up.get();
     (void)hipSetDevice(c->dev);
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
@@ -821,10 +850,9 @@ int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t
 int scfq_debug_partial_simple(const void* dptr, uint64_t n, int prev_byte, scfq_partial* out) {
   if (!out || (!dptr && n)) return SCFQ_EARG;
   Ctx* c = nullptr;
-  int rc = get_ctx(&c);
-  if (rc) return rc;
   SessionLock sl;
-  sl.acquire(c);
+  int rc = get_ctx(&c, sl);
+  if (rc) return rc;
   rc = begin_session(c);
   if (rc) return rc;
   if (n) {

@@ -84,3 +84,18 @@ def test_python_mirror_fq_count(gpu, scfq, capsys):
         scfq.fq_count(os.path.join(GOLDEN, row["name"]), basename=True)
         out = capsys.readouterr().out
         assert out == "%d\t%s\t%d\t%d\t%d\t%s\n" % (row["reads"], row["gc_content"], row["gc_bases"], row["n_bases"], row["bases"], os.path.basename(row["name"]))
+
+
+@pytest.mark.gpu
+def test_cli_jobs_keeps_argv_order_and_error_position(gpu):
+    rows = [r for r in golden_rows() if r["source"].startswith("reference:")]
+    files = [r["name"] for r in rows] * 3
+    seq = run("fq-count", "-b", *files, cwd=GOLDEN)
+    par = run("fq-count", "-b", "--jobs=6", *files, cwd=GOLDEN)
+    assert seq.returncode == 0 and par.returncode == 0
+    assert par.stdout == seq.stdout and len(par.stdout.splitlines()) == len(files)
+    # the first failing file ends the run where the sequential loop would have
+    r = run("fq-count", "--jobs=4", "dup.fq", "nope.fq", "sra.fq", "illumina_1.fq", cwd=GOLDEN)
+    assert r.returncode == 2
+    assert r.stdout == "8\t0.53125\t17\t0\t32\n"
+    assert r.stderr == "\x1b[31mError 2: Unable to open file: nope.fq\x1b[0m\n"
