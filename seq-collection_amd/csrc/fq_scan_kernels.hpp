@@ -253,6 +253,70 @@ __device__ __forceinline__ void masks32_ascii(const uint32_t* d, const MaskConst
   }
 }
 
+// ---- bit-plane classifier (the hot path) -----------------------------------------------------------------------
+// After the byte transpose, dword j of a 32-byte group holds the bytes at positions j, 8+j, 16+j, 24+j.  Three
+// rounds of masked block swaps between register pairs (an 8x8 bit-matrix transpose done on all four byte lanes at
+// once) turn the 8 dwords into 8 BIT PLANES: plane i bit p = bit i of byte p, p = 0..31 in memory order.  A byte
+// compare against a constant c is then one 8-input AND of planes or their complements = 3 + 1 v_bitop3_b32 per 32
+// bytes and symbol, exact for every byte value (no ASCII assumption, no carry tricks, no fallback path).
+// Cost per 64-byte lane: 32 v_perm + 96 cheap ops for the planes, then 8 v_bitop3 per symbol — against
+// 48 (xor/add, shift, merge) ops per symbol for the carry-SWAR form it replaced.
+struct PlaneConsts {
+  uint32_t m1, m1s, m2, m2s, m4, m4s;   // swap masks and their shifted forms, pinned in VGPRs (an SGPR source halves the issue rate)
+  __device__ __forceinline__ void init() {
+    m1 = 0x55555555u; m1s = 0xAAAAAAAAu; m2 = 0x33333333u; m2s = 0xCCCCCCCCu; m4 = 0x0F0F0F0Fu; m4s = 0xF0F0F0F0u;
+    asm volatile("" : "+v"(m1), "+v"(m1s), "+v"(m2), "+v"(m2s), "+v"(m4), "+v"(m4s));
+  }
+};
+
+// (a & mask) | (b & ~mask)
+__device__ __forceinline__ uint32_t bsel(uint32_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA); }
+
+template <int S>
+__device__ __forceinline__ void plane_swap(uint32_t& lo, uint32_t& hi, uint32_t m, uint32_t ms) {
+  // exchange the bits of `lo` selected by (m << S) with the bits of `hi` selected by m
+  const uint32_t nlo = bsel(ms, hi << S, lo);
+  const uint32_t nhi = bsel(m, lo >> S, hi);
+  lo = nlo; hi = nhi;
+}
+
+// x[0..7] (byte-transposed dwords of one 32-byte group) -> bit planes in place
+__device__ __forceinline__ void to_bit_planes(uint32_t* x, const PlaneConsts& pc) {
+  plane_swap<1>(x[0], x[1], pc.m1, pc.m1s); plane_swap<1>(x[2], x[3], pc.m1, pc.m1s);
+  plane_swap<1>(x[4], x[5], pc.m1, pc.m1s); plane_swap<1>(x[6], x[7], pc.m1, pc.m1s);
+  plane_swap<2>(x[0], x[2], pc.m2, pc.m2s); plane_swap<2>(x[1], x[3], pc.m2, pc.m2s);
+  plane_swap<2>(x[4], x[6], pc.m2, pc.m2s); plane_swap<2>(x[5], x[7], pc.m2, pc.m2s);
+  plane_swap<4>(x[0], x[4], pc.m4, pc.m4s); plane_swap<4>(x[1], x[5], pc.m4, pc.m4s);
+  plane_swap<4>(x[2], x[6], pc.m4, pc.m4s); plane_swap<4>(x[3], x[7], pc.m4, pc.m4s);
+}
+
+// minterm selectors for v_bitop3 (truth-table bit index = A<<2 | B<<1 | C)
+constexpr int minterm3(int c, int i0, int i1, int i2) { return 1 << ((((c >> i0) & 1) << 2) | (((c >> i1) & 1) << 1) | ((c >> i2) & 1)); }
+constexpr int minterm2(int c, int i0, int i1) { return 1 << ((((c >> i0) & 1) << 2) | (((c >> i1) & 1) << 1) | ((c >> i1) & 1)); }
+
+// INVERTED match mask (bit set = byte != C) over the 32 positions of one group; DONTCARE2: ignore bit 2 ('C' | 'G')
+template <int C, bool DONTCARE2 = false>
+__device__ __forceinline__ uint32_t plane_ne(const uint32_t* w) {
+  const uint32_t g1 = DONTCARE2 ? __builtin_amdgcn_bitop3_b32(w[0], w[1], w[1], minterm2(C, 0, 1))
+                                : __builtin_amdgcn_bitop3_b32(w[0], w[1], w[2], minterm3(C, 0, 1, 2));
+  const uint32_t g2 = __builtin_amdgcn_bitop3_b32(w[3], w[4], w[5], minterm3(C, 3, 4, 5));
+  const uint32_t g3 = __builtin_amdgcn_bitop3_b32(w[6], w[7], w[7], minterm2(C, 6, 7));
+  return __builtin_amdgcn_bitop3_b32(g1, g2, g3, 0x7F);   // ~(g1 & g2 & g3)
+}
+
+template <bool STRUCT>
+__device__ __forceinline__ void masks32_planes(const uint32_t* d, const PlaneConsts& pc, uint32_t& wnl, uint32_t& wgc,
+                                               uint32_t& wnn, uint32_t& wat, uint32_t& wpl) {
+  uint32_t x[8];
+  transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
+  transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
+  to_bit_planes(x, pc);
+  wnl = plane_ne<0x0A>(x);
+  wgc = plane_ne<0x43, true>(x);
+  wnn = plane_ne<0x4E>(x);
+  if (STRUCT) { wat = plane_ne<0x40>(x); wpl = plane_ne<0x2B>(x); }
+}
+
 struct Masks {
   uint64_t nl, gc, nn, at, pl;
 };
@@ -434,29 +498,24 @@ __device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist
 // ------------------------------------------------------------------------------------------------
 template <bool STRUCT, bool HIST>
 __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st, uint32_t* hist_lds,
-                                                  const MaskConsts& mc) {
+                                                  const PlaneConsts& pc) {
   const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
   const uint4 q0v = p[0], q1v = p[1], q2v = p[2], q3v = p[3];
   uint32_t d[16] = {q0v.x, q0v.y, q0v.z, q0v.w, q1v.x, q1v.y, q1v.z, q1v.w,
                     q2v.x, q2v.y, q2v.z, q2v.w, q3v.x, q3v.y, q3v.z, q3v.w};
-  const uint32_t hb = (d[0] | d[1] | d[2]) | (d[3] | d[4] | d[5]) | (d[6] | d[7] | d[8]) |
-                      (d[9] | d[10] | d[11]) | (d[12] | d[13] | d[14]) | d[15];
   uint64_t WNL, WGC, WNN, WAT = 0, WPL = 0;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N' / '@' / '+'
   if (SCFQ_ABLATE == 1 || SCFQ_ABLATE == 3) {   // timing-only: masks are a cheap function of the data
     WNL = ~((uint64_t)(d[0] & d[5] & 0x01010101u) | ((uint64_t)(d[9] & d[13] & 0x00010100u) << 32));
     WGC = ((uint64_t)d[1] << 32) | d[2];
     WNN = ((uint64_t)d[3] << 32) | d[4] | d[6] | d[7] | d[8] | d[10] | d[11] | d[12] | d[14] | d[15];
-  } else if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0) {
+  } else {
     uint32_t a0, a1, a2, a3 = 0, a4 = 0, b0, b1, b2, b3 = 0, b4 = 0;
-    masks32_ascii<STRUCT>(d, mc, a0, a1, a2, a3, a4);
-    masks32_ascii<STRUCT>(d + 8, mc, b0, b1, b2, b3, b4);
+    masks32_planes<STRUCT>(d, pc, a0, a1, a2, a3, a4);
+    masks32_planes<STRUCT>(d + 8, pc, b0, b1, b2, b3, b4);
     WNL = (uint64_t)a0 | ((uint64_t)b0 << 32);
     WGC = (uint64_t)a1 | ((uint64_t)b1 << 32);
     WNN = (uint64_t)a2 | ((uint64_t)b2 << 32);
     if (STRUCT) { WAT = (uint64_t)a3 | ((uint64_t)b3 << 32); WPL = (uint64_t)a4 | ((uint64_t)b4 << 32); }
-  } else {
-    const Masks m = masks64<false, STRUCT>(d);
-    WNL = ~m.nl; WGC = ~m.gc; WNN = ~m.nn; WAT = ~m.at; WPL = ~m.pl;
   }
   const uint64_t NL = ~WNL;
 
@@ -593,8 +652,8 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
   if (prev_param == -2) prev_param = a.base[-1];
   prev_param = __builtin_amdgcn_readfirstlane(prev_param);
 
-  MaskConsts mc;
-  mc.init();
+  PlaneConsts pc;
+  pc.init();
   WaveState st = {};
   // byte before this range's first tile: from memory when it belongs to the input, else the caller's halo
   st.prev_last = prev_param;
@@ -642,7 +701,7 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
     const uint8_t* sl = ring + slot * kTile;
     const uint64_t ts = A0 + t * kTile;
     if (ts >= B && ts + kTile <= E) {
-      process_tile_fast<STRUCT, HIST>(sl, lane, st, hist_lds, mc);
+      process_tile_fast<STRUCT, HIST>(sl, lane, st, hist_lds, pc);
     } else {
       // valid bytes of this lane: absolute [ts + 64*lane, +64) intersected with [B, E)
       const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);
