@@ -145,13 +145,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ------------------------------------------------------------------------------------------------
 // symbol masks: 64 bytes (16 dwords, memory order) -> three 64-bit masks, bit k <=> byte k
 // ------------------------------------------------------------------------------------------------
-// byte b != 0 -> bit 7 of that byte set.  ASCII form needs every byte of t <= 0x7F.
-template <bool ASCII>
-__device__ __forceinline__ uint32_t nonzero_bit7(uint32_t t) {
-  if (ASCII) return t + 0x7F7F7F7Fu;
-  return (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t);
-}
-
 // 4x4 byte transpose with v_perm_b32: in a,b,c,e (4 dwords) -> o[j] = {a.j, b.j, c.j, e.j}
 __device__ __forceinline__ void transpose4x4(uint32_t a, uint32_t b, uint32_t c, uint32_t e, uint32_t* o) {
   uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u);  // a0 b0 a1 b1
@@ -162,95 +155,6 @@ __device__ __forceinline__ void transpose4x4(uint32_t a, uint32_t b, uint32_t c,
   o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
   o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
   o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-}
-
-// 32 bytes (8 dwords) -> 32-bit NON-match words for '\n', G|C, 'N' (and optionally '@', '+').
-// After the transpose dword j holds the bytes at positions j, 8+j, 16+j, 24+j, so the bit-7
-// flags of dword j land on mask bits j, 8+j, 16+j, 24+j with one shift + one and_or.
-template <bool ASCII, bool STRUCT>
-__device__ __forceinline__ void masks32(const uint32_t* d, uint32_t& nl, uint32_t& gc, uint32_t& nn,
-                                        uint32_t& at, uint32_t& pl) {
-  uint32_t x[8];
-  transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
-  transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
-  uint32_t wnl = 0, wgc = 0, wnn = 0, wat = 0, wpl = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t sel = 0x01010101u << j;
-    const uint32_t v = x[j];
-    uint32_t e;
-    e = nonzero_bit7<ASCII>(v ^ 0x0A0A0A0Au);
-    wnl = ((e >> (7 - j)) & sel) | wnl;
-    e = nonzero_bit7<ASCII>((v & 0xFBFBFBFBu) ^ 0x43434343u);  // (b & 0xFB) == 0x43  <=>  b in {'C','G'}
-    wgc = ((e >> (7 - j)) & sel) | wgc;
-    e = nonzero_bit7<ASCII>(v ^ 0x4E4E4E4Eu);
-    wnn = ((e >> (7 - j)) & sel) | wnn;
-    if (STRUCT) {
-      e = nonzero_bit7<ASCII>(v ^ 0x40404040u);
-      wat = ((e >> (7 - j)) & sel) | wat;
-      e = nonzero_bit7<ASCII>(v ^ 0x2B2B2B2Bu);
-      wpl = ((e >> (7 - j)) & sel) | wpl;
-    }
-  }
-  nl = ~wnl; gc = ~wgc; nn = ~wnn; at = ~wat; pl = ~wpl;
-}
-
-// ---- hand-scheduled ASCII form (the hot path; every op here is paid 64 x per tile) ---------------
-// Measured issue cost on MI355X (scripts/ubench/valu_rate.hip, 8 waves/SIMD): plain VOP2 integer ops (and/or/xor/
-// add/shift/not) and v_bitop3_b32 take ~2.2 cycles per wave64 instruction per SIMD, every other VALU op used here
-// (v_perm, v_bfi, v_xad, v_bcnt, v_lshl_add, v_or3, v_and_or, DPP, v_cmp) ~3.7.  So the classifier below is written in
-// the cheap class only: xor, add (carry into bit 7 <=> byte != c, ASCII bytes only), shift, and a v_bitop3 merge
-// ((e & sel) | w, truth table 0xEA) = 4 cheap ops per dword and symbol; masks come out INVERTED (bit set = no match).
-// Operands matter too: the same VOP2 / v_bitop3 instruction drops to the slow class when one source is an SGPR
-// (literal and inline constants are fine).  hipcc hoists repeated constants into SGPRs, so the classifier's constants
-// are pinned in VGPRs once per kernel (MaskConsts) and passed down.
-struct MaskConsts {
-  uint32_t nl, nn, c43, fb, k7f, at, pl, sel[7];
-  __device__ __forceinline__ void init() {
-    nl = 0x0A0A0A0Au; nn = 0x4E4E4E4Eu; c43 = 0x43434343u; fb = 0xFBFBFBFBu; k7f = 0x7F7F7F7Fu;
-    at = 0x40404040u; pl = 0x2B2B2B2Bu;
-    asm volatile("" : "+v"(nl), "+v"(nn), "+v"(c43), "+v"(fb), "+v"(k7f), "+v"(at), "+v"(pl));
-#pragma unroll
-    for (int j = 0; j < 7; ++j) { sel[j] = 0x01010101u << j; asm volatile("" : "+v"(sel[j])); }
-  }
-};
-
-__device__ __forceinline__ uint32_t v_and_or_fast(uint32_t e, uint32_t sel, uint32_t w) {   // (e & sel) | w, all VGPR
-  uint32_t r;
-  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(e), "v"(sel), "v"(w));
-  return r;
-}
-__device__ __forceinline__ uint32_t v_xor_and_fast(uint32_t x, uint32_t c, uint32_t m) {   // (x ^ c) & m, all VGPR
-  uint32_t r;
-  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(r) : "v"(x), "v"(c), "v"(m));
-  return r;
-}
-
-template <bool STRUCT>
-__device__ __forceinline__ void masks32_ascii(const uint32_t* d, const MaskConsts& mc, uint32_t& wnl, uint32_t& wgc, uint32_t& wnn,
-                                              uint32_t& wat, uint32_t& wpl) {
-  uint32_t x[8];
-  transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
-  transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
-  // dword 7 needs no shift and keeps bit 7 of every byte
-  wnl = ((x[7] ^ mc.nl) + mc.k7f) & 0x80808080u;
-  wgc = (v_xor_and_fast(x[7], mc.c43, mc.fb) + mc.k7f) & 0x80808080u;
-  wnn = ((x[7] ^ mc.nn) + mc.k7f) & 0x80808080u;
-  if (STRUCT) {
-    wat = ((x[7] ^ mc.at) + mc.k7f) & 0x80808080u;
-    wpl = ((x[7] ^ mc.pl) + mc.k7f) & 0x80808080u;
-  }
-#pragma unroll
-  for (int j = 6; j >= 0; --j) {
-    const uint32_t v = x[j];
-    wnl = v_and_or_fast(((v ^ mc.nl) + mc.k7f) >> (7 - j), mc.sel[j], wnl);
-    wgc = v_and_or_fast((v_xor_and_fast(v, mc.c43, mc.fb) + mc.k7f) >> (7 - j), mc.sel[j], wgc);
-    wnn = v_and_or_fast(((v ^ mc.nn) + mc.k7f) >> (7 - j), mc.sel[j], wnn);
-    if (STRUCT) {
-      wat = v_and_or_fast(((v ^ mc.at) + mc.k7f) >> (7 - j), mc.sel[j], wat);
-      wpl = v_and_or_fast(((v ^ mc.pl) + mc.k7f) >> (7 - j), mc.sel[j], wpl);
-    }
-  }
 }
 
 // ---- bit-plane classifier (the hot path) -----------------------------------------------------------------------
@@ -321,17 +225,18 @@ struct Masks {
   uint64_t nl, gc, nn, at, pl;
 };
 
-template <bool ASCII, bool STRUCT>
-__device__ __forceinline__ Masks masks64(const uint32_t* d) {
-  uint32_t a[5], b[5];
-  masks32<ASCII, STRUCT>(d, a[0], a[1], a[2], a[3], a[4]);
-  masks32<ASCII, STRUCT>(d + 8, b[0], b[1], b[2], b[3], b[4]);
+// 64 bytes -> match masks (bit k <=> byte k), via the bit-plane classifier; used by the generic (edge-tile) path
+template <bool STRUCT>
+__device__ __forceinline__ Masks masks64(const uint32_t* d, const PlaneConsts& pc) {
+  uint32_t a[5] = {0, 0, 0, ~0u, ~0u}, b[5] = {0, 0, 0, ~0u, ~0u};
+  masks32_planes<STRUCT>(d, pc, a[0], a[1], a[2], a[3], a[4]);
+  masks32_planes<STRUCT>(d + 8, pc, b[0], b[1], b[2], b[3], b[4]);
   Masks m;
-  m.nl = (uint64_t)a[0] | ((uint64_t)b[0] << 32);
-  m.gc = (uint64_t)a[1] | ((uint64_t)b[1] << 32);
-  m.nn = (uint64_t)a[2] | ((uint64_t)b[2] << 32);
-  m.at = (uint64_t)a[3] | ((uint64_t)b[3] << 32);
-  m.pl = (uint64_t)a[4] | ((uint64_t)b[4] << 32);
+  m.nl = ~((uint64_t)a[0] | ((uint64_t)b[0] << 32));
+  m.gc = ~((uint64_t)a[1] | ((uint64_t)b[1] << 32));
+  m.nn = ~((uint64_t)a[2] | ((uint64_t)b[2] << 32));
+  m.at = ~((uint64_t)a[3] | ((uint64_t)b[3] << 32));
+  m.pl = ~((uint64_t)a[4] | ((uint64_t)b[4] << 32));
   return m;
 }
 
@@ -378,19 +283,13 @@ __device__ __forceinline__ void flush_pending(WaveState& st) {
 // ------------------------------------------------------------------------------------------------
 template <bool EDGE, bool STRUCT, bool HIST>
 __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint64_t V, int64_t first_valid_pos,
-                                             int32_t prev_byte_param, WaveState& st, uint32_t* hist_lds) {
+                                             int32_t prev_byte_param, WaveState& st, uint32_t* hist_lds,
+                                             const PlaneConsts& pc) {
   const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
   const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
   uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                     q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-
-  uint32_t hb = (d[0] | d[1] | d[2]) | (d[3] | d[4] | d[5]) | (d[6] | d[7] | d[8]) |
-                (d[9] | d[10] | d[11]) | (d[12] | d[13] | d[14]) | d[15];
-  Masks m;
-  if (__builtin_amdgcn_ballot_w64((hb & 0x80808080u) != 0) == 0)
-    m = masks64<true, STRUCT>(d);     // all 4096 bytes < 0x80: carry-free 1-op zero test
-  else
-    m = masks64<false, STRUCT>(d);    // exact form for arbitrary bytes
+  const Masks m = masks64<STRUCT>(d, pc);
 
   uint64_t NL = m.nl, GC = m.gc, NN = m.nn, VR = ~0ull;
   if (EDGE) { NL &= V; GC &= V; NN &= V; VR = V; }
@@ -638,12 +537,20 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
   const uint64_t range = (uint64_t)blockIdx.x * WAVES + wave;
   if (range >= a.n_ranges) return;
 
+  // everything that steers the tile loop is wave-uniform: pin it in SGPRs so the per-tile bookkeeping runs on the
+  // scalar unit instead of 64-bit VALU compares
+  // Everything that steers the tile loop is wave-uniform and kept in 32-bit SGPR form (tile indices, not addresses):
+  // gfx9 has no ordered 64-bit scalar compare, so 64-bit bookkeeping would run as VALU compares on every tile.
   const uint64_t B = (uint64_t)(uintptr_t)a.base, E = B + a.n;
   const uint64_t A0 = B & ~(uint64_t)(kTile - 1);
-  const uint64_t n_tiles = (E - A0 + kTile - 1) / kTile;
-  const uint64_t t_begin = range * a.tiles_per_range;
-  uint64_t t_end = t_begin + a.tiles_per_range;
+  const uint32_t n_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((E - A0 + kTile - 1) / kTile));
+  const uint32_t t_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(range * a.tiles_per_range));
+  uint32_t t_end = t_begin + a.tiles_per_range;
   if (t_end > n_tiles) t_end = n_tiles;
+  t_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_end);
+  // tiles [full_lo, full_hi) lie entirely inside [B, E); at most the first and the last tile of an input do not
+  const uint32_t full_lo = (uint32_t)__builtin_amdgcn_readfirstlane((A0 < B) ? 1 : 0);
+  const uint32_t full_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A0 + (uint64_t)n_tiles * kTile > E) ? n_tiles - 1 : n_tiles));
 
   // Both halo bytes are fetched and pinned into SGPRs BEFORE the first LDS-DMA is issued: a
   // compiler-visible load whose first use sat inside the tile loop made hipcc emit s_waitcnt vmcnt(0)
@@ -657,15 +564,15 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
   WaveState st = {};
   // byte before this range's first tile: from memory when it belongs to the input, else the caller's halo
   st.prev_last = prev_param;
-  if (A0 + t_begin * kTile > B) st.prev_last = *reinterpret_cast<const uint8_t*>(A0 + t_begin * kTile - 1);
+  if (A0 + (uint64_t)t_begin * kTile > B) st.prev_last = *reinterpret_cast<const uint8_t*>(A0 + (uint64_t)t_begin * kTile - 1);
   st.prev_last = __builtin_amdgcn_readfirstlane(st.prev_last);
 
   const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;   // LDS byte address of slot 0 (wave-uniform)
 
-  auto issue = [&](uint64_t t, uint32_t slot) {
-    const uint64_t ts = A0 + t * kTile;
+  auto issue = [&](uint32_t t, uint32_t slot) {
+    const uint64_t ts = A0 + (uint64_t)t * kTile;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + slot * kTile));
-    if (ts >= B && ts + kTile <= E) {
+    if (t >= full_lo && t < full_hi) {
       glds_tile<NT>(reinterpret_cast<const uint8_t*>(ts + (uint64_t)lane * 16), dst);
     } else {
       // pieces with no valid byte are redirected to a 16 B piece that is certainly readable
@@ -688,19 +595,19 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
     if (t_begin + k < t_end) issue(t_begin + k, k);
 
   uint32_t slot = 0;
-  for (uint64_t t = t_begin; t < t_end; ++t) {
+  for (uint32_t t = t_begin; t < t_end; ++t) {
     const uint32_t s2 = (slot >= 1) ? slot - 1 : RING - 1;      // (slot + RING - 1) % RING: the slot consumed last
     if (t + (RING - 1) < t_end) issue(t + (RING - 1), s2);
     // retire tile t: everything issued after it may stay in flight (4 DMA instructions per tile)
-    const uint64_t after = t_end - 1 - t;
-    if (after >= (uint64_t)(RING - 1)) wait_vmcnt<4 * (RING - 1)>();
+    const uint32_t after = t_end - 1 - t;
+    if (after >= (uint32_t)(RING - 1)) wait_vmcnt<4 * (RING - 1)>();
     else if (RING > 3 && after == 2) wait_vmcnt<8>();
     else if (RING > 2 && after == 1) wait_vmcnt<4>();
     else wait_vmcnt<0>();
 
     const uint8_t* sl = ring + slot * kTile;
-    const uint64_t ts = A0 + t * kTile;
-    if (ts >= B && ts + kTile <= E) {
+    const uint64_t ts = A0 + (uint64_t)t * kTile;
+    if (t >= full_lo && t < full_hi) {
       process_tile_fast<STRUCT, HIST>(sl, lane, st, hist_lds, pc);
     } else {
       // valid bytes of this lane: absolute [ts + 64*lane, +64) intersected with [B, E)
@@ -712,7 +619,7 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
       const uint64_t mlo = (lo >= 64) ? ~0ull : ((1ull << lo) - 1);
       const uint64_t V = mhi & ~mlo;
       const int64_t first_valid = (B >= ts) ? (int64_t)(B - ts) : -1;   // tile-local position of input byte 0
-      process_tile<true, STRUCT, HIST>(sl, lane, V, first_valid, prev_param, st, hist_lds);
+      process_tile<true, STRUCT, HIST>(sl, lane, V, first_valid, prev_param, st, hist_lds, pc);
     }
     slot = (slot == RING - 1) ? 0 : slot + 1;
   }

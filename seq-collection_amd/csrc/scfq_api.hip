@@ -222,6 +222,7 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
   const bool hist = flags & SCFQ_QUAL_HIST, strct = flags & SCFQ_STRUCT_CHECK;
   const uint64_t B = (uint64_t)(uintptr_t)dptr, A0 = B & ~(uint64_t)(scfq::kTile - 1);
   const uint64_t NT = (B + n - A0 + scfq::kTile - 1) / scfq::kTile;
+  if (NT >= (1ull << 32)) { std::snprintf(g_err, sizeof g_err, "a single scan launch covers at most 16 TiB"); return SCFQ_EARG; }
   const uint32_t tpr = pick_tiles_per_range(c, NT);
   const uint64_t n_ranges = (NT + tpr - 1) / tpr;
   int rc = ensure_partials(c, n_ranges, hist);
