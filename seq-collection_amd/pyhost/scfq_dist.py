@@ -28,6 +28,37 @@ def shard_bounds(total_bytes, world, rank):
     return total_bytes * rank // world, total_bytes * (rank + 1) // world
 
 
+class PendingExchange:
+    """An all_gather in flight (start_exchange): lets a host overlap the exchange of shard k with the scan of shard k+1."""
+    def __init__(self, work, out, world, width, with_hist):
+        self.work, self.out, self.world, self.width, self.with_hist = work, out, world, width, with_hist
+
+
+def start_exchange(partial, device=None, group=None, hist=None):
+    world = dist.get_world_size(group)
+    words = _to_i64(partial.words())
+    if hist is not None:
+        words = words + _to_i64(list(hist))
+    mine = torch.tensor(words, dtype=torch.int64, device=device)
+    out = torch.empty(world * mine.numel(), dtype=torch.int64, device=device)
+    work = dist.all_gather_into_tensor(out, mine, group=group, async_op=True)
+    return PendingExchange(work, out, world, mine.numel(), hist is not None)
+
+
+def finish_exchange(pending):
+    """Wait for the all_gather, fold in rank order. Returns (Partial, hist or None), identical on every rank."""
+    import ctypes
+    pending.work.wait()
+    rows = pending.out.view(pending.world, pending.width).cpu().tolist()
+    acc = scfq.identity()
+    acc_h = (ctypes.c_uint64 * scfq.HIST_WORDS)() if pending.with_hist else None
+    for r in range(pending.world):
+        p = scfq.Partial.from_words(_from_i64(rows[r][:scfq.PARTIAL_WORDS]))
+        h = (ctypes.c_uint64 * scfq.HIST_WORDS)(*_from_i64(rows[r][scfq.PARTIAL_WORDS:])) if pending.with_hist else None
+        scfq.combine(acc, p, acc_h, h)
+    return acc, acc_h
+
+
 def exchange_partials(partial, device=None, group=None, hist=None):
     """all_gather every rank's partial (and optional [4][256] histogram), fold in rank order.
 

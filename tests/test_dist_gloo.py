@@ -41,6 +41,11 @@ def _worker(rank, world, port, data_bytes, want_hist, q):
     p = scfq.Partial.from_words(list(w) + [0] * 5)
     acc, acc_h = scfq_dist.exchange_partials(p, hist=h if want_hist else None)
     c = scfq.finalize(acc, acc_h)
+    # the pipelined form (start now, finish later) must give the same fold
+    pend = scfq_dist.start_exchange(p, hist=h if want_hist else None)
+    acc2, acc2_h = scfq_dist.finish_exchange(pend)
+    assert acc2.words() == acc.words()
+    assert (acc2_h is None) == (acc_h is None) and (acc_h is None or list(acc2_h) == list(acc_h))
     q.put((rank, c.reads, c.gc_bases, c.n_bases, c.bases, c.lines, c.bad_at, c.bad_plus, list(c.qual_hist), scfq.format_tsv(c)))
     dist.destroy_process_group()
 
