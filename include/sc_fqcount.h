@@ -99,6 +99,7 @@ typedef struct scfq_timing {
   double host_fill_ms;    /* host time spent producing chunks (pread / zlib inflate) during the last ingest */
   double ingest_wall_ms;  /* wall time of the last chunked ingest (fill + copy + scan, overlapped) */
   uint64_t h2d_bytes;     /* bytes moved host -> HBM by the last ingest */
+  double h2d_ms;          /* device time of those copies on the copy stream (HIP events) */
 } scfq_timing;
 
 /* ---- whole-input entry points (what a host binds) ---------------------------------------- */

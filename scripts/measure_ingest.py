@@ -27,7 +27,7 @@ for it in range(2):
     t = time.time(); c = scfq.count_host(data, flags=scfq.SCFQ_TIMING); dt = time.time() - t
 check(c); tm = scfq.last_timing()
 row("host buffer (pageable memcpy into pinned ring -> H2D -> scan)", bytes=data.size, wall_s=round(dt, 4), GBps=round(data.size / dt / 1e9, 2),
-    scan_kernel_ms=round(tm.scan_kernel_ms, 3), host_fill_ms=round(tm.host_fill_ms, 1), ingest_wall_ms=round(tm.ingest_wall_ms, 1))
+    scan_kernel_ms=round(tm.scan_kernel_ms, 3), host_fill_ms=round(tm.host_fill_ms, 1), h2d_copy_ms=round(tm.h2d_ms, 2), ingest_wall_ms=round(tm.ingest_wall_ms, 1))
 
 plain = os.path.join(tmp, "scfq_synth.fq")
 data.tofile(plain)
@@ -35,7 +35,7 @@ for it in range(2):
     t = time.time(); c = scfq.count_file(plain, flags=scfq.SCFQ_TIMING); dt = time.time() - t
 check(c); tm = scfq.last_timing()
 row("plain file, page cache (pread -> pinned -> H2D -> scan)", bytes=data.size, wall_s=round(dt, 4), GBps=round(data.size / dt / 1e9, 2),
-    scan_kernel_ms=round(tm.scan_kernel_ms, 3), host_fill_ms=round(tm.host_fill_ms, 1), ingest_wall_ms=round(tm.ingest_wall_ms, 1))
+    scan_kernel_ms=round(tm.scan_kernel_ms, 3), host_fill_ms=round(tm.host_fill_ms, 1), h2d_copy_ms=round(tm.h2d_ms, 2), ingest_wall_ms=round(tm.ingest_wall_ms, 1))
 
 # gzip: (i) one member (first 512 MB), (ii) 64 MiB-per-member concatenation of the whole image
 one = data[: min(data.size, 512 << 20)]
@@ -50,7 +50,7 @@ t = time.time(); c = scfq.count_file(gz1, flags=scfq.SCFQ_TIMING); dt = time.tim
 tm = scfq.last_timing()
 assert (c.reads, c.gc_bases, c.n_bases, c.bases) == (oc.reads, oc.gc_bases, oc.n_bases, oc.bases)
 row("gzip -6, one member (host inflate || H2D || scan)", inflated_bytes=one.size, gz_bytes=os.path.getsize(gz1), wall_s=round(dt, 3),
-    inflated_GBps=round(one.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
+    inflated_GBps=round(one.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), h2d_copy_ms=round(tm.h2d_ms, 2), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
     ingest_wall_ms=round(tm.ingest_wall_ms, 1), overlap_efficiency=round(tm.host_fill_ms / tm.ingest_wall_ms, 4))
 
 member = 64 << 20
@@ -64,7 +64,7 @@ with open(gzm, "wb") as f:
 t = time.time(); c = scfq.count_file(gzm, flags=scfq.SCFQ_TIMING); dt = time.time() - t
 check(c); tm = scfq.last_timing()
 row("gzip -6, %d concatenated 64 MiB members" % len(parts), inflated_bytes=data.size, gz_bytes=os.path.getsize(gzm), wall_s=round(dt, 3),
-    inflated_GBps=round(data.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
+    inflated_GBps=round(data.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), h2d_copy_ms=round(tm.h2d_ms, 2), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
     ingest_wall_ms=round(tm.ingest_wall_ms, 1), overlap_efficiency=round(tm.host_fill_ms / tm.ingest_wall_ms, 4))
 # BGZF (what `bgzip` writes): 64 KiB blocks with their compressed size in the header -> block-parallel inflate
 import struct
@@ -83,7 +83,7 @@ for it in range(2):
     t = time.time(); c = scfq.count_file(bgz, flags=scfq.SCFQ_TIMING); dt = time.time() - t
 check(c); tm = scfq.last_timing()
 row("BGZF (bgzip layout), block-parallel host inflate || H2D || scan", inflated_bytes=data.size, gz_bytes=os.path.getsize(bgz), wall_s=round(dt, 3),
-    inflated_GBps=round(data.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
+    inflated_GBps=round(data.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), h2d_copy_ms=round(tm.h2d_ms, 2), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
     ingest_wall_ms=round(tm.ingest_wall_ms, 1), overlap_efficiency=round(tm.host_fill_ms / tm.ingest_wall_ms, 4))
 os.environ["SCFQ_NO_BGZF"] = "1"
 t = time.time(); c = scfq.count_file(bgz, flags=scfq.SCFQ_TIMING); dt = time.time() - t

@@ -62,6 +62,8 @@ struct Ctx {
   std::vector<hipEvent_t> ev_pool;     // timing events, 3 per scan launch of the current session
   size_t ev_used = 0;
   std::vector<uint64_t> ev_bytes;      // bytes of each timed launch
+  std::vector<hipEvent_t> cp_pool;     // timing events around each H2D copy (2 per chunk)
+  size_t cp_used = 0;
   uint32_t* d_ticket = nullptr;        // arrival counter of the fused fold (re-armed by the kernel)
   bool fresh = true;                   // no scan folded into d_state yet in this session
   // staging (host buffers / files)
@@ -284,6 +286,7 @@ int begin_session(Ctx* c) {
   c->timing = scfq_timing{};
   c->timing.struct_size = sizeof(scfq_timing);
   c->ev_used = 0;
+  c->cp_used = 0;
   c->ev_bytes.clear();
   c->fresh = true;   // the first fold of the session overwrites d_state (no memset launch)
   return SCFQ_OK;
@@ -305,6 +308,11 @@ int end_session(Ctx* c, bool hist, scfq_partial* out, uint64_t* hist_out) {
     c->timing.fold_kernel_ms += ms2;
     c->timing.scan_bytes += c->ev_bytes[k / 3];
     c->timing.scan_launches += 1;
+  }
+  for (size_t k = 0; k + 1 < c->cp_used; k += 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->cp_pool[k], c->cp_pool[k + 1]));
+    c->timing.h2d_ms += ms;
   }
   std::memcpy(out, c->h_state, sizeof(scfq_partial));
   if (hist && hist_out) std::memcpy(hist_out, c->h_state + SCFQ_PARTIAL_WORDS, SCFQ_HIST_WORDS * sizeof(uint64_t));
@@ -536,7 +544,12 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
     if (got == 0) break;
     c->timing.h2d_bytes += (uint64_t)got;
     if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));   // device buffer b consumed
+    if (timing) {
+      while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
+      HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
+    }
     HIPCHK(hipMemcpyAsync(c->d_stage[b], c->h_pin[b], (size_t)got, hipMemcpyHostToDevice, c->copy));
+    if (timing) { HIPCHK(hipEventRecord(c->cp_pool[c->cp_used + 1], c->copy)); c->cp_used += 2; }
     HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
     HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));
     rc = scan_async(c, c->d_stage[b], (uint64_t)got, prev, flags & ~SCFQ_PREV_IN_MEMORY, timing);
@@ -793,6 +806,7 @@ int scfq_shutdown(void) {
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->cp_pool) (void)hipEventDestroy(e);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);

@@ -64,7 +64,7 @@ class Timing(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint64), ("scan_kernel_ms", ctypes.c_double),
                 ("fold_kernel_ms", ctypes.c_double), ("scan_bytes", ctypes.c_uint64),
                 ("scan_launches", ctypes.c_uint64), ("host_fill_ms", ctypes.c_double),
-                ("ingest_wall_ms", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64)]
+                ("ingest_wall_ms", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64), ("h2d_ms", ctypes.c_double)]
 
 
 class SynthInfo(ctypes.Structure):
