@@ -108,3 +108,20 @@ def test_synthetic_generator_host(scfq, oracle):
     assert 359.0 < plan.bytes / plan.records < 360.0
     assert 0.0015 < info.n_bases / info.bases < 0.0025
     assert 0.40 < info.gc_bases / info.bases < 0.42
+
+
+def test_header_is_plain_c_and_example_builds(tmp_path):
+    """the boundary must be consumable from C99 (no C++-isms in include/sc_fqcount.h)"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "sc_fqcount.h"\nint main(void){ scfq_counts c; scfq_opts o; scfq_partial p; (void)c; (void)o; (void)p; return (int)sizeof(scfq_timing) == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-fsyntax-only", str(src)])
+    exe = tmp_path / "count_shards"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "count_shards.c"), "-L", os.path.join(ROOT, "seq-collection_amd"),
+                           "-lsc_fqcount_hip", "-Wl,-rpath," + os.path.join(ROOT, "seq-collection_amd"), "-o", str(exe)])
+    import torch
+    if torch.cuda.is_available():
+        r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "sra.fq"), "5"], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == "2\t0.4305555555555556\t62\t0\t144\n"
