@@ -452,25 +452,23 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   if (total != 0 && SCFQ_ABLATE < 2) {   // wave-uniform: some lane of this tile holds a newline
     const int lane_base = lane * 64;
     const bool has1 = (NL != 0);
-    {   // '\r' directly before the first newline?
-      const int idx = lane_base + (int)s_len - 1;
-      int pb = slot[has1 ? (idx < 0 ? 0 : idx) : lane * 4];   // newline-free lanes read a bank-spread dummy
-      if (idx < 0) pb = st.prev_last;
-      t_crlf += ((has1 && pb == '\r') ? 1u : 0u) << sh0;
-    }
-    // middle segments: between consecutive newlines of one lane
-    uint64_t xc = NL, xcm1 = xm1;
-    uint32_t sh = sh0;
-    for (;;) {
-      const uint64_t x1 = xc & xcm1;               // drop the lowest remaining newline
-      const bool has2 = (x1 != 0);
-      if (__builtin_amdgcn_ballot_w64(has2) == 0) break;
-      const uint64_t x1m1 = x1 - 1;
-      const uint64_t below1 = ~x1 & x1m1;
-      const uint64_t upto0 = xc ^ xcm1;
-      uint64_t seg = below1 & ~upto0;              // strictly between the two lowest remaining newlines
-      seg = has2 ? seg : 0;                        // lanes whose next segment is their last one are handled below
-      sh = (sh + 8u) & 31u;
+    // second newline of the lane (every FASTQ shape has at most two per 64 bytes: "...\n+\n...")
+    const uint64_t x1 = NL & xm1, x1m1 = x1 - 1;
+    const uint64_t below1 = ~x1 & x1m1;
+    const bool has2 = (x1 != 0);
+    // '\r' directly before a newline is not part of the line: both look-behind bytes are requested from LDS
+    // before anything consumes them (newline-free lanes read bank-spread dummies)
+    const int idx0 = lane_base + (int)s_len - 1;
+    const int idx1 = lane_base + (int)popc64(below1) - 1;      // >= 0: a lane's second newline is never at bit 0
+    int pb0 = slot[has1 ? (idx0 < 0 ? 0 : idx0) : lane * 4];
+    const int pb1 = slot[has2 ? idx1 : lane * 4 + 256];
+    if (idx0 < 0) pb0 = st.prev_last;
+    t_crlf += ((has1 && pb0 == '\r') ? 1u : 0u) << sh0;
+    uint32_t sh = (sh0 + 8u) & 31u;
+    {   // the segment strictly between the first and the second newline (straight-line: no loop for FASTQ shapes)
+      const uint64_t upto0 = NL ^ xm1;
+      uint64_t seg = below1 & ~upto0;
+      seg = has2 ? seg : 0;                        // a lane whose next segment is its last one is handled below
       const uint32_t m_len = popc64(seg), m_gc = popc64(seg & ~WGC), m_nn = popc64(seg & ~WNN);
       t_len += m_len << sh; t_gc += m_gc << sh; t_nn += m_nn << sh;
       s_len += m_len; s_gc += m_gc; s_nn += m_nn;
@@ -481,10 +479,34 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
         t_st += m_st << sh; t_fat += m_fat << sh; t_fpl += m_fpl << sh;
         s_st += m_st; s_fat += m_fat; s_fpl += m_fpl;
       }
-      const int idx = lane_base + (int)popc64(below1) - 1;     // >= 0: a lane's second newline is never at bit 0
-      const int pb = slot[has2 ? idx : lane * 4];
-      t_crlf += ((has2 && pb == '\r') ? 1u : 0u) << sh;
-      xc = x1; xcm1 = x1m1;
+      t_crlf += ((has2 && pb1 == '\r') ? 1u : 0u) << sh;
+    }
+    // further middle segments: three or more newlines in one lane (blank lines, very short records)
+    uint64_t xc = x1, xcm1 = x1m1;
+    for (;;) {
+      const uint64_t x2 = xc & xcm1;               // drop the lowest remaining newline
+      const bool has3 = (x2 != 0);
+      if (__builtin_amdgcn_ballot_w64(has3) == 0) break;
+      const uint64_t x2m1 = x2 - 1;
+      const uint64_t below2 = ~x2 & x2m1;
+      const uint64_t upto1 = xc ^ xcm1;
+      uint64_t seg = below2 & ~upto1;
+      seg = has3 ? seg : 0;
+      sh = (sh + 8u) & 31u;
+      const uint32_t m_len = popc64(seg), m_gc = popc64(seg & ~WGC), m_nn = popc64(seg & ~WNN);
+      t_len += m_len << sh; t_gc += m_gc << sh; t_nn += m_nn << sh;
+      s_len += m_len; s_gc += m_gc; s_nn += m_nn;
+      if (STRUCT) {
+        uint64_t lsm = LS & (x2 ^ x2m1) & ~upto1;
+        lsm = has3 ? lsm : 0;
+        const uint32_t m_st = popc64(lsm), m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
+        t_st += m_st << sh; t_fat += m_fat << sh; t_fpl += m_fpl << sh;
+        s_st += m_st; s_fat += m_fat; s_fpl += m_fpl;
+      }
+      const int idx = lane_base + (int)popc64(below2) - 1;
+      const int pb = slot[has3 ? idx : lane * 4];
+      t_crlf += ((has3 && pb == '\r') ? 1u : 0u) << sh;
+      xc = x2; xcm1 = x2m1;
     }
     // last segment by complement: what lies above the highest newline = lane totals - segments counted so far
     // (newline-free lanes: totals == first segment, so this adds 0)
