@@ -1,0 +1,44 @@
+#!/bin/bash
+# Soak: repeated parity suites + fold stress (many ranges, concurrent sessions) to catch intermittent failures
+# (inter-workgroup visibility in the fused fold, ring/ticket reuse, context pool).
+set -e
+for i in 1 2 3 4 5; do python -m pytest tests/test_gpu_parity.py tests/test_gpu_variants.py -q -m gpu -x 2>&1 | tail -1; done
+python - <<'PY'
+import os, sys, threading
+sys.path.insert(0, "seq-collection_amd/pyhost")
+import torch, scfq
+plan = scfq.synth_plan(0, 7, 1_000_000_000)
+buf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda")
+info = scfq.synth_device(0, 7, plan.records, buf.data_ptr(), plan.bytes)
+want = (plan.records, info.gc_bases, info.n_bases, info.bases)
+bad = 0
+for rep in range(300):
+    c = scfq.count_device(buf.data_ptr(), plan.bytes)
+    if (c.reads, c.gc_bases, c.n_bases, c.bases) != want: bad += 1
+print("300 repeated 1 GB scans, mismatches:", bad)
+# concurrent sessions from 8 host threads on one device (context pool)
+errs = []
+def worker(k):
+    for rep in range(40):
+        off = 4096 * k
+        c = scfq.count_device(buf.data_ptr(), plan.bytes)
+        if (c.reads, c.gc_bases, c.n_bases, c.bases) != want: errs.append((k, rep))
+ts = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("8 threads x 40 concurrent scans, mismatches:", len(errs))
+assert bad == 0 and not errs
+PY
+for tpr in 1 2 5; do SCFQ_TILES_PER_RANGE=$tpr python - <<'PY'
+import os, sys
+sys.path.insert(0, "seq-collection_amd/pyhost")
+import torch, scfq
+plan = scfq.synth_plan(1, 9, 600_000_000)
+buf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda")
+info = scfq.synth_device(1, 9, plan.records, buf.data_ptr(), plan.bytes)
+for rep in range(20):
+    c = scfq.count_device(buf.data_ptr() , plan.bytes, flags=scfq.SCFQ_STRUCT_CHECK)
+    assert (c.reads, c.gc_bases, c.n_bases, c.bases, c.bad_at, c.bad_plus) == (plan.records, info.gc_bases, info.n_bases, info.bases, 0, 0), rep
+print("tiles_per_range", os.environ["SCFQ_TILES_PER_RANGE"], "ok (", (plan.bytes + 4095) // 4096 // int(os.environ["SCFQ_TILES_PER_RANGE"]), "ranges )")
+PY
+done
+echo SOAK OK
