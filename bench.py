@@ -235,6 +235,15 @@ def main():
                      "bases": counts.bases, "tsv": scfq.format_tsv(counts), "matches_generator_tally": exact},
         "setup_s": round(gen_s, 2),
     }
+    # the same device's read-stream ceiling: the scan kernel's load structure with no compute (diagnostic kernel)
+    al = (-shard_ptr) % 4096
+    if shard_n > al + (1 << 20):
+        sm = scfq.debug_stream_ms(shard_ptr + al, shard_n - al, 5)
+        if sm > 0:
+            sbytes = (shard_n - al) // 4096 * 4096
+            out["roofline"]["stream_ceiling"] = {"GBps": round(sbytes / (sm * 1e-3) / 1e9, 1), "ms": round(sm, 4),
+                                                 "what": "same LDS-DMA ring and ranges, no classification/accounting, same buffer"}
+            out["roofline"]["frac_of_stream_ceiling"] = round(achieved / (sbytes / (sm * 1e-3) / 1e9), 4)
     # PMC traffic measured offline with rocprofv3 (separate --pmc pass), if committed for this workload
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and args.flags == 0 and kind == 0:

@@ -149,6 +149,10 @@ int  scfq_debug_partial_simple(const void* device_ptr, uint64_t n, int prev_byte
 /* Diagnostic only: the byte stream scfq_count_file() would scan for `path` (plain pread, BGZF block-parallel
  * inflate, or serial gzread), produced on the host without any device. Returns bytes written or a negative code. */
 int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk_bytes);
+/* Diagnostic only: milliseconds (best of `reps`) the scan kernel's LOAD STRUCTURE alone (same ranges, same non-temporal
+ * LDS-DMA ring, no classification / accounting) needs for the whole tiles of a 4 KiB-aligned device buffer: the
+ * practical read-stream ceiling on this device, reported next to the roofline by bench.py. Negative on error. */
+double scfq_debug_stream_ms(const void* device_ptr, uint64_t n, int reps);
 
 /* ---- synthetic workloads of SURVEY.md §8(d) / BASELINE.json configs ------------------------
  * Counter-based generator: record i of a workload is a pure function of (seed, i), so host and

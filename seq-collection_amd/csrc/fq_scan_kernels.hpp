@@ -828,6 +828,40 @@ __global__ __launch_bounds__(256) void fq_fold_hist(const uint32_t* hist_partial
 }
 
 // ------------------------------------------------------------------------------------------------
+// Diagnostic (NOT the product path): the load structure of fq_scan_tiles alone -- same ranges, same 2-slot
+// non-temporal LDS-DMA ring, one ds_read per lane and tile, no classification or accounting.  Its time is the
+// practical ceiling the scan kernel is compared with on the same device (bench.py "stream_ceiling").
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_stream_null(const uint8_t* base, uint32_t n_tiles, uint32_t tiles_per_range,
+                                                      uint32_t* sink) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* ring = smem + wave * (2 * kTile);
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
+  const uint32_t range = blockIdx.x * kWavesPerBlock + wave;
+  const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(range * tiles_per_range));
+  uint32_t t1 = t0 + tiles_per_range;
+  if (t1 > n_tiles) t1 = n_tiles;
+  t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t1);
+  if (t0 >= n_tiles) return;
+  uint32_t acc = 0, slot = 0;
+  glds_tile<true>(base + (uint64_t)t0 * kTile + lane * 16, ring_lds);
+  for (uint32_t t = t0; t < t1; ++t) {
+    if (t + 1 < t1) {
+      glds_tile<true>(base + (uint64_t)(t + 1) * kTile + lane * 16,
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + (slot ^ 1u) * kTile)));
+      wait_vmcnt<4>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    acc += *reinterpret_cast<const uint32_t*>(ring + slot * kTile + lane * 64);
+    slot ^= 1u;
+  }
+  if (acc == 0x9E3779B9u) sink[0] = acc;   // keeps the reads alive
+}
+
+// ------------------------------------------------------------------------------------------------
 // Diagnostic cross-check kernel (NOT the product path): one thread scans 256 bytes byte-serially
 // and emits its own partial; used by tests as an independent device implementation.
 // ------------------------------------------------------------------------------------------------

@@ -861,6 +861,34 @@ int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t
   return rc < 0 ? rc : (int64_t)total;
 }
 
+// ---- diagnostic: time of the scan kernel's load structure alone over a device-resident buffer (milliseconds, best of
+// `reps`; < 0 on error). The buffer must be 4 KiB aligned; only whole tiles are streamed.
+double scfq_debug_stream_ms(const void* dptr, uint64_t n, int reps) {
+  Ctx* c = nullptr;
+  SessionLock sl;
+  if (get_ctx(&c, sl) || !dptr || ((uintptr_t)dptr & 4095) || n < (uint64_t)scfq::kTile) return -1.0;
+  const uint32_t n_tiles = (uint32_t)std::min<uint64_t>(n / scfq::kTile, 0xFFFFFFFFull);
+  const uint32_t tpr = pick_tiles_per_range(c, n_tiles);
+  const unsigned ranges = (n_tiles + tpr - 1) / tpr, blocks = (ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock;
+  if (ensure_partials(c, 16, false)) return -1.0;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  float best = -1.0f;
+  for (int r = 0; r < std::max(1, reps) + 1; ++r) {
+    (void)hipEventRecord(e0, c->compute);
+    hipLaunchKernelGGL(scfq::fq_stream_null, dim3(blocks), dim3(256), scfq::kWavesPerBlock * 2 * scfq::kTile, c->compute,
+                       static_cast<const uint8_t*>(dptr), n_tiles, tpr, reinterpret_cast<uint32_t*>(c->d_partials));
+    (void)hipEventRecord(e1, c->compute);
+    if (hipEventSynchronize(e1) != hipSuccess) { best = -1.0f; break; }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0 && (best < 0 || ms < best)) best = ms;   // first launch is a warm-up
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return (double)best;
+}
+
 // ---- diagnostic: independent byte-serial device kernel (tests only; not used by any counting path) ----
 int scfq_debug_partial_simple(const void* dptr, uint64_t n, int prev_byte, scfq_partial* out) {
   if (!out || (!dptr && n)) return SCFQ_EARG;

@@ -29,7 +29,7 @@ EXPORTS = [
     "scfq_partial_combine", "scfq_partial_finalize", "scfq_format_tsv", "scfq_strerror",
     "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
-    "scfq_debug_read_file",
+    "scfq_debug_read_file", "scfq_debug_stream_ms",
 ]
 
 
@@ -113,6 +113,8 @@ def lib():
                                          ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SynthInfo)]
         L.scfq_debug_read_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.scfq_debug_read_file.restype = ctypes.c_int64
+        L.scfq_debug_stream_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
+        L.scfq_debug_stream_ms.restype = ctypes.c_double
         L.scfq_synth_locate.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         _lib = L
@@ -213,6 +215,11 @@ def debug_read_file(path, cap, chunk_bytes=0):
     if n < 0:
         raise ScfqError(int(n), "scfq_debug_read_file", lib().scfq_last_error_detail().decode())
     return bytes(buf[:n])
+
+
+def debug_stream_ms(dev_ptr, n, reps=5):
+    """diagnostic: ms for the scan kernel's load structure alone (4 KiB-aligned device pointer)"""
+    return lib().scfq_debug_stream_ms(ctypes.c_void_p(dev_ptr), n, reps)
 
 
 def combine(acc, b, hist_acc=None, hist_b=None):
