@@ -377,15 +377,24 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
   st.prev_last = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)d[15], 63) >> 24);
 }
 
-// K3, interior tiles: all 64 bytes of the lane, fully unrolled. cls0 = class of the lane's first byte.
-__device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist_lds, int lane, uint32_t cls0) {
-  uint32_t cls = cls0;
-  uint32_t* lane_bins = hist_lds + (lane & (kHistRep - 1));
+// K3, interior tiles: all 64 bytes of the lane, fully unrolled. cls0 = class of the lane's first byte, NL = the lane's
+// newline mask (a newline belongs to the line it ends, the class advances after it).  Written in cheap VOP2 ops
+// only (shift / and / add with literals): the byte's bin offset is ((d >> s) & 0x3FC0) = byte << 6, the class term
+// advances by the newline bit moved to bit 4.  Byte offset of a bin copy: byte << 6 | class << 4 | copy << 2.
+__device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist_lds, int lane, uint32_t cls0, uint64_t NL) {
+  uint8_t* base = reinterpret_cast<uint8_t*>(hist_lds) + ((lane & (kHistRep - 1)) << 2);
+  uint32_t clsterm = cls0 << 4;
+  const uint32_t nl_lo = (uint32_t)NL, nl_hi = (uint32_t)(NL >> 32);
 #pragma unroll
   for (int k = 0; k < 64; ++k) {
-    const uint32_t byte = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-    __hip_atomic_fetch_add(&lane_bins[(byte * 4 + (cls & 3u)) * kHistRep], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    cls += (byte == 10u) ? 1u : 0u;      // a newline belongs to the line it ends
+    const uint32_t w = d[k >> 2];
+    const int b = k & 3;
+    const uint32_t off = (b == 0) ? ((w << 6) & 0x3FC0u) : ((w >> (8 * b - 6)) & 0x3FC0u);
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + off + clsterm), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t m = (k < 32) ? nl_lo : nl_hi;
+    const int j = k & 31;
+    const uint32_t step = (j >= 4) ? ((m >> (j - 4)) & 16u) : ((m << (4 - j)) & 16u);
+    clsterm = (clsterm + step) & 48u;
   }
 }
 
@@ -422,7 +431,7 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint32_t incl = wave_inclusive_scan(cnt);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const uint32_t sh0 = ((st.phase + incl - cnt) & 3u) * 8u;
-  if (HIST) hist_tile_full(d, hist_lds, lane, sh0 >> 3);
+  if (HIST) hist_tile_full(d, hist_lds, lane, sh0 >> 3, NL);
 
   // K4: line-start bytes = the byte after a '\n' (bit 0: previous lane's / previous tile's last byte)
   uint64_t LS = 0;
