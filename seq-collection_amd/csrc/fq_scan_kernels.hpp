@@ -382,19 +382,22 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
 // only (shift / and / add with literals): the byte's bin offset is ((d >> s) & 0x3FC0) = byte << 6, the class term
 // advances by the newline bit moved to bit 4.  Byte offset of a bin copy: byte << 6 | class << 4 | copy << 2.
 __device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist_lds, int lane, uint32_t cls0, uint64_t NL) {
+  constexpr int kLog = (kHistRep == 4) ? 2 : (kHistRep == 2 ? 1 : 0);
+  constexpr int kByteShift = 4 + kLog, kClsShift = 2 + kLog;      // byte offset = byte << kByteShift | class << kClsShift | copy << 2
+  constexpr uint32_t kByteMask = 0xFFu << kByteShift, kClsMask = 3u << kClsShift, kClsOne = 1u << kClsShift;
   uint8_t* base = reinterpret_cast<uint8_t*>(hist_lds) + ((lane & (kHistRep - 1)) << 2);
-  uint32_t clsterm = cls0 << 4;
+  uint32_t clsterm = cls0 << kClsShift;
   const uint32_t nl_lo = (uint32_t)NL, nl_hi = (uint32_t)(NL >> 32);
 #pragma unroll
   for (int k = 0; k < 64; ++k) {
     const uint32_t w = d[k >> 2];
     const int b = k & 3;
-    const uint32_t off = (b == 0) ? ((w << 6) & 0x3FC0u) : ((w >> (8 * b - 6)) & 0x3FC0u);
+    const uint32_t off = (b == 0) ? ((w << kByteShift) & kByteMask) : ((w >> (8 * b - kByteShift)) & kByteMask);
     __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + off + clsterm), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t m = (k < 32) ? nl_lo : nl_hi;
     const int j = k & 31;
-    const uint32_t step = (j >= 4) ? ((m >> (j - 4)) & 16u) : ((m << (4 - j)) & 16u);
-    clsterm = (clsterm + step) & 48u;
+    const uint32_t step = (j >= kClsShift) ? ((m >> (j - kClsShift)) & kClsOne) : ((m << (kClsShift - j)) & kClsOne);
+    clsterm = (clsterm + step) & kClsMask;
   }
 }
 
