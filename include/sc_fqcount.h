@@ -35,12 +35,17 @@ extern "C" {
 #define SCFQ_EARG    (-5)  /* bad argument (NULL pointer, struct_size mismatch, bad flag) */
 #define SCFQ_EIO     (-6)  /* read error after a successful open */
 #define SCFQ_ENOMEM  (-7)  /* host allocation failed */
+#define SCFQ_ESPEC   (-8)  /* the speculative quality histogram of a shard backed a class that is not the quality line
+                              (malformed input cut into shards): count that shard again with SCFQ_HIST_EXACT.
+                              scfq_count_file / scfq_count_buffer do this by themselves and never return it. */
 
 /* ---- option flags ------------------------------------------------------------------------ */
 #define SCFQ_QUAL_HIST     0x1u  /* also build the 256-bin histogram of quality-line bytes (K3; not in reference) */
 #define SCFQ_STRUCT_CHECK  0x2u  /* also count header lines not starting '@' / separator lines not starting '+' (K4) */
 #define SCFQ_TIMING        0x4u  /* bracket the scan kernel with HIP events; read back with scfq_last_timing() */
 #define SCFQ_PREV_IN_MEMORY 0x8u /* scfq_partial_buffer: the byte before `ptr` is addressable and is the look-behind halo */
+#define SCFQ_HIST_EXACT    0x10u /* with SCFQ_QUAL_HIST: build all four class histograms exactly (slower kernel) instead of the
+                                    verified-speculative form that only completes the quality class (scfq_partial.hist_class) */
 
 /* ---- results: the counters of src/fq_count.nim:22-28 plus derivation inputs ------------- */
 typedef struct scfq_counts {
@@ -85,7 +90,10 @@ typedef struct scfq_partial {
   uint64_t first_plus[4]; /* K4: ... whose first byte is '+' */
   uint64_t bytes;         /* bytes covered */
   uint64_t last_byte;     /* value of the last byte covered (undefined when bytes == 0) */
-  uint64_t reserved[5];
+  uint64_t hist_class;    /* K3 side array: 0 = all four class histograms are complete; k+1 (k = 0..3) = only class k is
+                             (the speculative form histograms just the lines it verified to be quality lines);
+                             5 = none (shards that disagree were combined: finalize returns SCFQ_ESPEC) */
+  uint64_t reserved[4];
 } scfq_partial;
 
 #define SCFQ_HIST_WORDS (4 * 256)  /* optional K3 side array: uint64_t hist[4][256], class-major */
@@ -141,6 +149,9 @@ const char* scfq_strerror(int rc);   /* static storage */
 const char* scfq_last_error_detail(void); /* static, thread-local: e.g. the failing HIP call */
 int  scfq_last_timing(scfq_timing* t);
 int  scfq_device_count(void);        /* number of visible HIP devices, or negative on error */
+/* Diagnostic: ranges of this thread's last histogram session that the speculative K3 form served / that were (re)done
+ * by the exact kernel (no guess, or a guess that did not verify). */
+int  scfq_debug_hist_stats(uint64_t* fast_ranges, uint64_t* redone_ranges);
 int  scfq_shutdown(void);            /* frees streams, pinned and device scratch; safe to call twice */
 
 /* Diagnostic only (used by the parity tests as a second, independent device implementation):

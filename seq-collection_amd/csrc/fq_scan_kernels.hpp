@@ -48,6 +48,16 @@ constexpr int kHistRep = 4;
 constexpr int kHistWords = 256 * 4 * kHistRep;
 constexpr int kHistWaves = 2;   // waves per block in the histogram variant (LDS: 2 x (ring + 16 KiB))
 
+// K3, speculative fast form (HIST == 2): every range comes with a GUESS of which relative class is the quality line
+// (fq_scan_tiles<.., GUESS> reads the '@' / '+' line starts of the first tiles of the range; the guess is VERIFIED
+// against the exact phases of the ordered fold afterwards and wrong / missing guesses are redone by the exact
+// HIST == 1 kernel, so results never depend on it).  With the class known only quality bytes are histogrammed, into ONE
+// workgroup-shared histogram of 256 bins x kQRep lane-keyed copies (16 KiB for 4 waves instead of 16 KiB per wave):
+// u32 bin[byte * kQRep + copy].
+constexpr int kQRep = 16;
+constexpr int kQWords = 256 * kQRep;
+constexpr uint32_t kNoGuess = 255u;
+
 // ------------------------------------------------------------------------------------------------
 // cross-lane helpers (wave64, DPP)
 // ------------------------------------------------------------------------------------------------
@@ -260,6 +270,7 @@ struct WaveState {
   uint32_t phase;      // wave-uniform: newlines seen so far in this range, mod 4
   uint32_t nl_total;   // wave-uniform: newlines seen so far in this range
   int32_t prev_last;   // wave-uniform: byte before the next tile (-1: none / start of input)
+  uint32_t qcls;       // wave-uniform, HIST == 2: relative class guessed to be the quality line (4 = no guess: no histogram)
 };
 
 // widen the pending 8-bit fields into the 16-bit per-lane accumulators (at most every 3rd tile: 3 x 64 < 256)
@@ -281,7 +292,7 @@ __device__ __forceinline__ void flush_pending(WaveState& st) {
 //   STRUCT : K4 line-start checks ('@' / '+')
 //   HIST   : K3 byte histogram per class into this wave's LDS histogram
 // ------------------------------------------------------------------------------------------------
-template <bool EDGE, bool STRUCT, bool HIST>
+template <bool EDGE, bool STRUCT, int HIST>
 __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint64_t V, int64_t first_valid_pos,
                                              int32_t prev_byte_param, WaveState& st, uint32_t* hist_lds,
                                              const PlaneConsts& pc) {
@@ -342,7 +353,19 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
       t_fat += popc64(ls & m.at) << sh;
       t_fpl += popc64(ls & m.pl) << sh;
     }
-    if (HIST) {
+    if (HIST == 2) {
+      // K3 fast form (edge tiles only; interior tiles use hist_tile_q): the bytes of a quality segment, without its newline
+      if ((sh >> 3) == st.qcls) {
+        uint64_t s = seg;
+        while (s) {
+          const int k = __builtin_ctzll(s);
+          s &= s - 1;
+          const uint32_t byte = slot[lane_base + k];
+          atomicAdd(&hist_lds[byte * kQRep + (lane & (kQRep - 1))], 1u);
+        }
+      }
+    }
+    if (HIST == 1) {
       // K3 (edge tiles only; interior tiles use hist_tile_full): every valid byte of this segment INCLUDING its
       // newline goes to bin[class][byte]; newline and "\r\n" bytes are taken back once per range
       uint64_t s = upto & VR;
@@ -401,13 +424,61 @@ __device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist
   }
 }
 
+// K3 fast form, interior tiles: the class that is the quality line is known (guessed, verified later), so only the
+// lane's quality bytes are counted.  Segment i of a lane (between its newlines i-1 and i) has class (cls0 + i) & 3; the
+// first quality segment [a, b) is split into whole dwords [A, Bd) - four unpredicated atomics under one dword-level
+// exec mask, byte -> bin offset in two cheap ops - and at most 3 head + 3 tail bytes re-read from LDS.  Further quality
+// segments of the same lane (5+ newlines in 64 bytes) take a per-byte loop.
+__device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, const uint8_t* lane_bytes, int lane, uint32_t cls0,
+                                            uint64_t NL, uint32_t cnt, uint32_t qcls) {
+  uint8_t* base = reinterpret_cast<uint8_t*>(hq) + ((lane & (kQRep - 1)) << 2);
+  constexpr uint32_t kMask = 0xFFu << 6;   // byte offset of a bin copy: byte << 6 | copy << 2
+  static_assert(kQRep == 16, "bin offset arithmetic assumes 16 copies");
+  auto bump = [&](uint32_t off) {
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  const uint32_t i0 = (qcls - cls0) & 3u;
+  const uint64_t x0 = NL, x1 = x0 & (x0 - 1), x2 = x1 & (x1 - 1), x3 = x2 & (x2 - 1);
+  const uint64_t xa = (i0 == 1) ? x0 : (i0 == 2) ? x1 : x2;                      // begins with newline i0-1 (i0 >= 1)
+  const uint64_t xb = (i0 == 0) ? x0 : (i0 == 1) ? x1 : (i0 == 2) ? x2 : x3;    // begins with newline i0
+  const uint32_t a = (i0 == 0) ? 0u : (xa ? (uint32_t)__builtin_ctzll(xa) + 1u : 65u);   // 65: the lane has no such segment
+  const uint32_t b = xb ? (uint32_t)__builtin_ctzll(xb) : 64u;
+  const uint32_t A = (a + 3u) >> 2, Bd = b >> 2;
+  const uint32_t width = (Bd > A) ? Bd - A : 0u;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if ((uint32_t)j - A < width) {
+      const uint32_t w = d[j];
+      bump((w << 6) & kMask);
+      bump((w >> 2) & kMask);
+      bump((w >> 10) & kMask);
+      bump((w >> 18) & kMask);
+    }
+  }
+  const uint32_t he = (b < 4u * A) ? b : 4u * A;               // head bytes [a, he)
+  const uint32_t ts = (Bd > A) ? 4u * Bd : 4u * A;             // tail bytes [ts, b)
+#pragma unroll
+  for (uint32_t i = 0; i < 3; ++i) {
+    const uint32_t hp = a + i, tp = ts + i;
+    if (hp < he) bump((uint32_t)lane_bytes[hp] << 6);
+    if (tp < b) bump((uint32_t)lane_bytes[tp] << 6);
+  }
+  if (cnt >= i0 + 4u) {   // rare: another quality segment starts in this lane
+    for (uint32_t k = b + 1; k < 64; ++k) {
+      const uint64_t bit = 1ull << k;
+      const uint32_t cls = (cls0 + popc64(NL & (bit - 1))) & 3u;
+      if (cls == qcls && !(NL & bit)) bump((uint32_t)lane_bytes[k] << 6);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Interior tile of the default variant (no EDGE / STRUCT / HIST): the same arithmetic as
 // process_tile with the segment loop restructured so that the common FASTQ shapes (0, 1 or 2
 // newlines in a lane's 64 bytes) cost one straight-line "first segment" block, one "last segment"
 // block and at most one pass of the middle loop.
 // ------------------------------------------------------------------------------------------------
-template <bool STRUCT, bool HIST>
+template <bool STRUCT, int HIST>
 __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane, WaveState& st, uint32_t* hist_lds,
                                                   const PlaneConsts& pc) {
   const uint4* p = reinterpret_cast<const uint4*>(slot + lane * 64);
@@ -434,7 +505,10 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint32_t incl = wave_inclusive_scan(cnt);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const uint32_t sh0 = ((st.phase + incl - cnt) & 3u) * 8u;
-  if (HIST) hist_tile_full(d, hist_lds, lane, sh0 >> 3, NL);
+  if (HIST == 1) hist_tile_full(d, hist_lds, lane, sh0 >> 3, NL);
+  if (HIST == 2) {
+    if (st.qcls < 4u) hist_tile_q(d, hist_lds, slot + lane * 64, lane, sh0 >> 3, NL, cnt, st.qcls);   // wave-uniform branch
+  }
 
   // K4: line-start bytes = the byte after a '\n' (bit 0: previous lane's / previous tile's last byte)
   uint64_t LS = 0;
@@ -551,25 +625,44 @@ struct ScanArgs {
   uint32_t tiles_per_range;
   uint64_t n_ranges;
   uint64_t* partials;      // [n_ranges][kPartialWords]
-  uint32_t* hist_partials; // [n_ranges][4][256] u32, HIST only
+  uint32_t* hist_partials; // [n_ranges][4][256] u32, HIST == 1 only
+  const uint8_t* todo;     // HIST == 1, optional: scan only the ranges with todo[range] != 0 (redo pass of the fast form)
+  const uint8_t* guess;    // HIST == 2: per range, the relative class guessed to be the header line (0..3), kNoGuess = none
+  uint32_t* hist_wg;       // HIST == 2: [n_workgroups][256] u32, quality-class histogram of the workgroup's ranges
+  uint8_t* guess_out;      // GUESS: per range result
+  uint32_t guess_cap_tiles;// GUESS: tiles a range may look at before giving up
 };
 
 // RING = LDS ring slots per wave (1 being consumed + RING-1 in flight); NT = non-temporal DMA loads
-template <bool STRUCT, bool HIST, int RING = kRing, bool NT = true>
-__global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void fq_scan_tiles(ScanArgs a) {
-  constexpr int WAVES = HIST ? kHistWaves : kWavesPerBlock;
+// HIST  = 0 none | 1 exact 4-class per-wave histogram | 2 speculative quality-class workgroup histogram (see kQRep)
+// GUESS = true: no partials; look at the line starts of the first tiles of each range (K4 accounting) and report which
+//         relative class is the header line: the only h with an '@' line start in class h and a '+' line start in
+//         class h+2 (in a well-formed FASTQ only the header/separator pair can satisfy it: a sequence line never
+//         starts with '@' or '+').  Ambiguous or not found within guess_cap_tiles: kNoGuess.
+template <bool STRUCT, int HIST, int RING = kRing, bool NT = true, bool GUESS = false>
+__global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : 64 * kWavesPerBlock) void fq_scan_tiles(ScanArgs a) {
+  constexpr int WAVES = HIST == 1 ? kHistWaves : kWavesPerBlock;
   static_assert(RING >= 2 && RING <= 4, "ring depth");
+  static_assert(!GUESS || (STRUCT && HIST == 0), "the guess pass is the K4 accounting without partials");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* ring = smem + wave * (RING * kTile);
+  const uint64_t range = (uint64_t)blockIdx.x * WAVES + wave;
+  bool active = range < a.n_ranges;
+  if (HIST == 1 && active && a.todo) active = (a.todo[range] != 0);
+  if (HIST != 2 && !active) return;     // HIST == 2: every wave reaches the workgroup barriers below
   uint32_t* hist_lds = nullptr;
-  if (HIST) {
+  if (HIST == 1) {
     hist_lds = reinterpret_cast<uint32_t*>(smem + WAVES * RING * kTile) + wave * kHistWords;
     for (int k = lane; k < kHistWords; k += 64) hist_lds[k] = 0;
   }
-  const uint64_t range = (uint64_t)blockIdx.x * WAVES + wave;
-  if (range >= a.n_ranges) return;
+  if (HIST == 2) {
+    hist_lds = reinterpret_cast<uint32_t*>(smem + WAVES * RING * kTile);
+    for (int k = threadIdx.x; k < kQWords; k += 64 * WAVES) hist_lds[k] = 0;
+    __syncthreads();
+  }
+  if (active) {
 
   // everything that steers the tile loop is wave-uniform: pin it in SGPRs so the per-tile bookkeeping runs on the
   // scalar unit instead of 64-bit VALU compares
@@ -579,7 +672,7 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
   const uint64_t A0 = B & ~(uint64_t)(kTile - 1);
   const uint32_t n_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((E - A0 + kTile - 1) / kTile));
   const uint32_t t_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(range * a.tiles_per_range));
-  uint32_t t_end = t_begin + a.tiles_per_range;
+  uint32_t t_end = t_begin + (GUESS ? a.guess_cap_tiles : a.tiles_per_range);   // a guess may look past its own range
   if (t_end > n_tiles) t_end = n_tiles;
   t_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_end);
   // tiles [full_lo, full_hi) lie entirely inside [B, E); at most the first and the last tile of an input do not
@@ -593,9 +686,18 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
   if (prev_param == -2) prev_param = a.base[-1];
   prev_param = __builtin_amdgcn_readfirstlane(prev_param);
 
+  uint32_t qcls = 4u;
+  if (HIST == 2) {
+    const uint32_t g = a.guess[range];
+    qcls = (g < 4u) ? ((g + 3u) & 3u) : 4u;     // header class h -> quality class h + 3
+  }
+  qcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcls);   // pinned before the first DMA, like the halo bytes
+
   PlaneConsts pc;
   pc.init();
   WaveState st = {};
+  st.qcls = qcls;
+  uint32_t guessed = kNoGuess;
   // byte before this range's first tile: from memory when it belongs to the input, else the caller's halo
   st.prev_last = prev_param;
   if (A0 + (uint64_t)t_begin * kTile > B) st.prev_last = *reinterpret_cast<const uint8_t*>(A0 + (uint64_t)t_begin * kTile - 1);
@@ -656,6 +758,29 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
       process_tile<true, STRUCT, HIST>(sl, lane, V, first_valid, prev_param, st, hist_lds, pc);
     }
     slot = (slot == RING - 1) ? 0 : slot + 1;
+    if (GUESS) {
+      // which relative classes have seen a line start with '@' / with '+' so far (any lane)
+      flush_pending(st);
+      auto any4 = [&](const Acc16& acc) {
+        uint32_t m = 0;
+        if (__builtin_amdgcn_ballot_w64((acc.e & 0xFFFFu) != 0)) m |= 1u;
+        if (__builtin_amdgcn_ballot_w64((acc.o & 0xFFFFu) != 0)) m |= 2u;
+        if (__builtin_amdgcn_ballot_w64((acc.e >> 16) != 0)) m |= 4u;
+        if (__builtin_amdgcn_ballot_w64((acc.o >> 16) != 0)) m |= 8u;
+        return m;
+      };
+      const uint32_t atm = any4(st.fat), plm = any4(st.fplus);
+      const uint32_t cand = atm & ((plm >> 2) | (plm << 2)) & 0xFu;   // bit h: '@' in class h and '+' in class (h + 2) & 3
+      if (cand) {
+        guessed = (cand & (cand - 1)) ? kNoGuess : (uint32_t)__builtin_ctz(cand);
+        wait_vmcnt<0>();     // tiles still in flight write this wave's LDS ring: retire them before the wave ends
+        break;
+      }
+    }
+  }
+  if (GUESS) {
+    if (lane == 0) a.guess_out[range] = (uint8_t)guessed;
+    return;
   }
 
   flush_pending(st);
@@ -686,7 +811,13 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
     out[W_NL] = st.nl_total;
     for (int k = W_BYTES; k < kPartialWords; ++k) out[k] = 0;
   }
-  if (HIST) {
+  if (HIST == 2 && qcls < 4u) {
+    // the '\r' of every "\r\n" that ends a quality line was counted as a line byte: take it back (u32 modular when
+    // that '\r' lies in the previous range, like len)
+    const uint32_t crq = (qcls == 0) ? cr4.x : (qcls == 1) ? cr4.y : (qcls == 2) ? cr4.z : cr4.w;
+    if (lane == 0 && crq) atomicSub(&hist_lds[13 * kQRep], crq);
+  }
+  if (HIST == 1) {
     // per-range histogram partial [class][byte] (u32): sum the lane-keyed copies, then take back the bytes that
     // are not part of any line: newline j of the range ended a line of class j mod 4, and the '\r' of every
     // "\r\n" (per-class counts in cr4; u32 modular like len when that '\r' lies in the previous range)
@@ -701,6 +832,17 @@ __global__ __launch_bounds__(HIST ? 64 * kHistWaves : 64 * kWavesPerBlock) void 
       if (b == 13u) v -= (c == 0 ? cr4.x : c == 1 ? cr4.y : c == 2 ? cr4.z : cr4.w);
       hp[k] = v;
     }
+  }
+  }   // if (active)
+  if (HIST == 2) {
+    // workgroup histogram of the quality class: thread t sums the copies of byte value t
+    __syncthreads();
+    const uint32_t t = threadIdx.x;
+    const uint4* src = reinterpret_cast<const uint4*>(hist_lds + t * kQRep);
+    uint32_t v = 0;
+#pragma unroll
+    for (int r = 0; r < kQRep / 4; ++r) { const uint4 q = src[r]; v += q.x + q.y + q.z + q.w; }
+    a.hist_wg[(uint64_t)blockIdx.x * 256 + t] = v;
   }
 }
 
@@ -820,23 +962,93 @@ __global__ __launch_bounds__(kFold1) void fq_fold_fused(const uint64_t* partials
 
 // K3 fold: state_hist[c][b] += sum_r hist_r[(c - phase_r) & 3][b],  phase_r = block_phase[r / kFold1] + rel_phase[r].
 // One block per kFold1 ranges; thread t owns byte values t (4 classes each), reads are coalesced over t.
+// todo (optional): only the ranges the exact kernel has (re)done carry a partial.
 __global__ __launch_bounds__(256) void fq_fold_hist(const uint32_t* hist_partials, const uint8_t* rel_phase,
-                                                    const uint8_t* block_phase, uint64_t n_ranges,
+                                                    const uint8_t* block_phase, uint64_t n_ranges, const uint8_t* todo,
                                                     unsigned long long* state_hist) {
   const uint32_t b = threadIdx.x;
   const uint64_t r0 = (uint64_t)blockIdx.x * kFold1;
   const uint64_t r1 = (r0 + kFold1 < n_ranges) ? r0 + kFold1 : n_ranges;
   const uint32_t bp = block_phase[blockIdx.x];
   uint64_t acc[4] = {0, 0, 0, 0};
+  bool any = false;
   for (uint64_t r = r0; r < r1; ++r) {
+    if (todo && !todo[r]) continue;
+    any = true;
     const uint32_t ph = (bp + rel_phase[r]) & 3u;
     const uint32_t* src = hist_partials + r * 1024 + b;
 #pragma unroll
     for (uint32_t c = 0; c < 4; ++c)   // u32 partials are modular (take-backs may wrap): sign-extend
       acc[(c + ph) & 3u] += (uint64_t)(int64_t)(int32_t)src[c * 256];
   }
+  if (!any) return;
 #pragma unroll
   for (uint32_t c = 0; c < 4; ++c) atomicAdd(&state_hist[c * 256 + b], (unsigned long long)acc[c]);
+}
+
+// ---- K3 speculative form: verification of the guesses against the exact phases of the ordered fold ------------------
+// ext[0] = 0: the session has no hypothesis yet; H + 1: header lines are class H relative to the session start.
+// ext[1] / ext[2] = ranges whose histogram came from the fast form / had to be (re)done exactly (diagnostics).
+// A guess g of range r says "header lines are class g relative to r"; with the exact starting phase p_r of the range
+// (newlines before it, mod 4) that is class (g + p_r) & 3 relative to the session.  All guesses must agree on one H:
+// force_h >= 0 when the session starts at the start of the input (H = 0 by definition), else H is taken from the
+// first range that has a guess (and is checked again by the host when shards are combined / finalized).  A workgroup
+// (4 consecutive ranges, one shared histogram) with any disagreeing range is discarded as a whole; its ranges and all
+// ranges without a guess are marked todo for the exact kernel.
+constexpr int kExtH = 0, kExtFast = 1, kExtRedo = 2, kExtWords = 8;
+__global__ __launch_bounds__(256) void fq_hist_verify(const uint8_t* guess, const uint8_t* rel_phase, const uint8_t* block_phase,
+                                                      uint64_t n_ranges, int force_h, uint64_t* ext, uint8_t* todo,
+                                                      uint8_t* wg_ok) {
+  __shared__ uint32_t s_first, s_fast, s_redo;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) { s_first = 0xFFFFFFFFu; s_fast = 0; s_redo = 0; }
+  __syncthreads();
+  auto session_class = [&](uint64_t r) { return ((uint32_t)guess[r] + block_phase[r / kFold1] + rel_phase[r]) & 3u; };
+  uint32_t H = (force_h >= 0) ? (uint32_t)force_h : ((uint32_t)ext[kExtH] ? (uint32_t)ext[kExtH] - 1u : kNoGuess);
+  if (H == kNoGuess) {     // block-uniform
+    uint32_t mine = 0xFFFFFFFFu;
+    for (uint64_t r = tid; r < n_ranges; r += 256)
+      if (guess[r] != kNoGuess) { mine = (uint32_t)r; break; }
+    atomicMin(&s_first, mine);
+    __syncthreads();
+    if (s_first != 0xFFFFFFFFu) H = session_class(s_first);
+  }
+  const uint64_t n_wg = (n_ranges + kWavesPerBlock - 1) / kWavesPerBlock;
+  uint32_t fast = 0, redo = 0;
+  for (uint64_t b = tid; b < n_wg; b += 256) {
+    const uint64_t r0 = b * kWavesPerBlock, r1 = (r0 + kWavesPerBlock < n_ranges) ? r0 + kWavesPerBlock : n_ranges;
+    bool poisoned = false;
+    for (uint64_t r = r0; r < r1; ++r)
+      if (guess[r] != kNoGuess && session_class(r) != H) poisoned = true;
+    for (uint64_t r = r0; r < r1; ++r) {
+      const bool again = poisoned || guess[r] == kNoGuess;
+      todo[r] = again ? 1 : 0;
+      if (again) ++redo; else ++fast;
+    }
+    wg_ok[b] = poisoned ? 0 : 1;
+  }
+  atomicAdd(&s_fast, fast);
+  atomicAdd(&s_redo, redo);
+  __syncthreads();
+  if (tid == 0) {
+    if (H != kNoGuess && s_fast) ext[kExtH] = H + 1u;
+    ext[kExtFast] += s_fast;
+    ext[kExtRedo] += s_redo;
+  }
+}
+
+// state_hist[(H + 3) & 3][b] += sum over the verified workgroups of hist_wg[.][b]   (u32 modular partials: sign-extend)
+__global__ __launch_bounds__(256) void fq_fold_hist_wg(const uint32_t* hist_wg, const uint8_t* wg_ok, uint64_t n_wg,
+                                                       const uint64_t* ext, unsigned long long* state_hist) {
+  constexpr uint64_t kPer = 64;
+  const uint32_t t = threadIdx.x;
+  if (!ext[kExtH]) return;                      // no range was taken from the fast form
+  const uint32_t q = ((uint32_t)ext[kExtH] - 1u + 3u) & 3u;
+  const uint64_t b0 = (uint64_t)blockIdx.x * kPer, b1 = (b0 + kPer < n_wg) ? b0 + kPer : n_wg;
+  uint64_t acc = 0;
+  for (uint64_t b = b0; b < b1; ++b)
+    if (wg_ok[b]) acc += (uint64_t)(int64_t)(int32_t)hist_wg[b * 256 + t];
+  if (acc) atomicAdd(&state_hist[q * 256 + t], (unsigned long long)acc);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,7 +44,8 @@ thread_local char g_err[512] = "";
   } while (0)
 
 constexpr uint64_t kDefaultChunk = 64ull << 20;
-constexpr int kStateWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;
+constexpr int kStateWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS + scfq::kExtWords;   // partial | hist[4][256] | ext (K3 speculation)
+constexpr int kExtAt = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;
 
 struct Ctx {
   int dev = -1;
@@ -55,6 +56,12 @@ struct Ctx {
   uint32_t* d_hist_partials = nullptr;
   uint8_t* d_range_phase = nullptr;   // [cap] rel phase per range, then [cap] start phase per level-1 block
   uint64_t cap_hist_ranges = 0;
+  // K3 speculative form: per-range guess / todo flags, per-workgroup verdict and quality histogram
+  uint8_t* d_guess = nullptr;
+  uint8_t* d_todo = nullptr;
+  uint8_t* d_wg_ok = nullptr;
+  uint32_t* d_hist_wg = nullptr;
+  bool from_start = false;             // the session begins at the start of the input: header lines are class 0
   uint64_t* d_block_partials = nullptr;   // level-1 fold output
   uint64_t cap_blocks = 0;
   uint64_t* d_state = nullptr;   // [32 partial words][1024 hist words]
@@ -88,6 +95,7 @@ int env_int(const char* name, int dflt);
 std::mutex g_mu;
 std::map<int, std::vector<std::unique_ptr<Ctx>>> g_ctx;
 thread_local scfq_timing g_last_timing{};
+thread_local uint64_t g_hist_stats[2] = {0, 0};   // ranges of the last session taken from the fast K3 form / redone exactly
 
 int new_ctx(int dev, std::unique_ptr<Ctx>* out);
 
@@ -157,11 +165,19 @@ int ensure_partials(Ctx* c, uint64_t n_ranges, bool hist) {
     HIPCHK(hipStreamSynchronize(c->compute));
     if (c->d_hist_partials) HIPCHK(hipFree(c->d_hist_partials));
     if (c->d_range_phase) HIPCHK(hipFree(c->d_range_phase));
+    if (c->d_guess) HIPCHK(hipFree(c->d_guess));
+    if (c->d_hist_wg) HIPCHK(hipFree(c->d_hist_wg));
     c->d_hist_partials = nullptr;
     c->d_range_phase = nullptr;
+    c->d_guess = nullptr;
+    c->d_hist_wg = nullptr;
     uint64_t cap = std::max<uint64_t>(n_ranges + n_ranges / 4, 4096);
     HIPCHK(hipMalloc(&c->d_hist_partials, cap * 1024 * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&c->d_range_phase, 2 * cap));
+    HIPCHK(hipMalloc(&c->d_guess, 3 * cap));          // guess | todo | wg_ok
+    c->d_todo = c->d_guess + cap;
+    c->d_wg_ok = c->d_todo + cap;
+    HIPCHK(hipMalloc(&c->d_hist_wg, (cap / scfq::kWavesPerBlock + 1) * 256 * sizeof(uint32_t)));
     c->cap_hist_ranges = cap;
   }
   return SCFQ_OK;
@@ -202,14 +218,15 @@ uint32_t pick_tiles_per_range(const Ctx* c, uint64_t n_tiles) {
   return (uint32_t)tpr;
 }
 
-template <bool S, bool H, int RING, bool NT>
+template <bool S, int H, int RING, bool NT, bool GUESS = false>
 void launch_scan(const scfq::ScanArgs& a, unsigned blocks, hipStream_t st) {
-  constexpr int waves = H ? scfq::kHistWaves : scfq::kWavesPerBlock;
+  constexpr int waves = (H == 1) ? scfq::kHistWaves : scfq::kWavesPerBlock;
   unsigned lds = waves * RING * scfq::kTile;
-  if (H) lds += waves * scfq::kHistWords * sizeof(uint32_t);
+  if (H == 1) lds += waves * scfq::kHistWords * sizeof(uint32_t);
+  if (H == 2) lds += scfq::kQWords * sizeof(uint32_t);
   (void)blocks;
   const unsigned grid = (unsigned)((a.n_ranges + waves - 1) / waves);
-  hipLaunchKernelGGL((scfq::fq_scan_tiles<S, H, RING, NT>), dim3(grid), dim3(64 * waves), lds, st, a);
+  hipLaunchKernelGGL((scfq::fq_scan_tiles<S, H, RING, NT, GUESS>), dim3(grid), dim3(64 * waves), lds, st, a);
 }
 
 // tuning knobs (defaults are the measured best): SCFQ_RING = 2|3|4 LDS ring slots per wave, SCFQ_NT = 0|1
@@ -246,18 +263,31 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
     c->ev_bytes.push_back(n);
     HIPCHK(hipEventRecord(ev[0], c->compute));
   }
-  if (hist && strct) launch_scan<true, true, 2, true>(a, blocks, c->compute);
-  else if (hist) launch_scan<false, true, 2, true>(a, blocks, c->compute);
-  else if (strct) launch_scan<true, false, 2, true>(a, blocks, c->compute);
+  // K3: speculative form unless SCFQ_HIST_EXACT asks for the exact 4-class histogram (env SCFQ_HIST_MODE=exact|fast overrides)
+  static const int hist_mode_env = [] { const char* e = std::getenv("SCFQ_HIST_MODE"); return !e ? 0 : (e[0] == 'e' ? 1 : 2); }();
+  const bool spec = hist && (hist_mode_env ? hist_mode_env == 2 : !(flags & SCFQ_HIST_EXACT));
+  a.todo = nullptr;
+  a.guess = c->d_guess;
+  a.hist_wg = c->d_hist_wg;
+  a.guess_out = c->d_guess;
+  a.guess_cap_tiles = (uint32_t)std::max(1, env_int("SCFQ_GUESS_TILES", 64));
+  if (spec) {
+    launch_scan<true, 0, 2, false, true>(a, blocks, c->compute);   // guess pass: first tiles of every range
+    if (strct) launch_scan<true, 2, 2, true>(a, blocks, c->compute);
+    else launch_scan<false, 2, 2, true>(a, blocks, c->compute);
+  }
+  else if (hist && strct) launch_scan<true, 1, 2, true>(a, blocks, c->compute);
+  else if (hist) launch_scan<false, 1, 2, true>(a, blocks, c->compute);
+  else if (strct) launch_scan<true, 0, 2, true>(a, blocks, c->compute);
   else {
     // measured on MI355X (10 GB Illumina): ring 2 + nt 6.36 TB/s, ring 3 + nt 6.23, ring 2 5.91, ring 3 5.87
     static const int ring = env_int("SCFQ_RING", 2), nt = env_int("SCFQ_NT", 1);
-    if (ring == 2 && nt) launch_scan<false, false, 2, true>(a, blocks, c->compute);
-    else if (ring == 2) launch_scan<false, false, 2, false>(a, blocks, c->compute);
-    else if (ring == 4 && nt) launch_scan<false, false, 4, true>(a, blocks, c->compute);
-    else if (ring == 4) launch_scan<false, false, 4, false>(a, blocks, c->compute);
-    else if (nt) launch_scan<false, false, 3, true>(a, blocks, c->compute);
-    else launch_scan<false, false, 3, false>(a, blocks, c->compute);
+    if (ring == 2 && nt) launch_scan<false, 0, 2, true>(a, blocks, c->compute);
+    else if (ring == 2) launch_scan<false, 0, 2, false>(a, blocks, c->compute);
+    else if (ring == 4 && nt) launch_scan<false, 0, 4, true>(a, blocks, c->compute);
+    else if (ring == 4) launch_scan<false, 0, 4, false>(a, blocks, c->compute);
+    else if (nt) launch_scan<false, 0, 3, true>(a, blocks, c->compute);
+    else launch_scan<false, 0, 3, false>(a, blocks, c->compute);
   }
   HIPCHK(hipGetLastError());
   if (timing) HIPCHK(hipEventRecord(ev[1], c->compute));
@@ -266,15 +296,32 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
     uint8_t* rel_phase = hist ? c->d_range_phase : nullptr;
     uint8_t* block_phase = hist ? c->d_range_phase + c->cap_hist_ranges : nullptr;
     if (hist && c->fresh)
-      HIPCHK(hipMemsetAsync(c->d_state + SCFQ_PARTIAL_WORDS, 0, SCFQ_HIST_WORDS * sizeof(uint64_t), c->compute));
+      HIPCHK(hipMemsetAsync(c->d_state + SCFQ_PARTIAL_WORDS, 0, (SCFQ_HIST_WORDS + scfq::kExtWords) * sizeof(uint64_t), c->compute));
     hipLaunchKernelGGL(scfq::fq_fold_fused, dim3((unsigned)n_blocks), dim3(scfq::kFold1), 0, c->compute, c->d_partials,
                        n_ranges, c->d_block_partials, c->d_ticket, c->d_state, c->fresh ? 1 : 0, rel_phase, block_phase,
                        dptr, n);
     HIPCHK(hipGetLastError());
     c->fresh = false;
-    if (hist) {
+    unsigned long long* state_hist = (unsigned long long*)(c->d_state + SCFQ_PARTIAL_WORDS);
+    if (spec) {
+      // verify the guesses against the exact phases, redo what did not verify with the exact kernel, fold both kinds
+      uint64_t* ext = c->d_state + kExtAt;
+      hipLaunchKernelGGL(scfq::fq_hist_verify, dim3(1), dim3(256), 0, c->compute, c->d_guess, rel_phase, block_phase, n_ranges,
+                         c->from_start ? 0 : -1, ext, c->d_todo, c->d_wg_ok);
+      HIPCHK(hipGetLastError());
+      a.todo = c->d_todo;
+      if (strct) launch_scan<true, 1, 2, true>(a, blocks, c->compute);
+      else launch_scan<false, 1, 2, true>(a, blocks, c->compute);
+      HIPCHK(hipGetLastError());
       hipLaunchKernelGGL(scfq::fq_fold_hist, dim3((unsigned)n_blocks), dim3(256), 0, c->compute, c->d_hist_partials,
-                         rel_phase, block_phase, n_ranges, (unsigned long long*)(c->d_state + SCFQ_PARTIAL_WORDS));
+                         rel_phase, block_phase, n_ranges, c->d_todo, state_hist);
+      const uint64_t n_wg = (n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock;
+      hipLaunchKernelGGL(scfq::fq_fold_hist_wg, dim3((unsigned)((n_wg + 63) / 64)), dim3(256), 0, c->compute, c->d_hist_wg,
+                         c->d_wg_ok, n_wg, ext, state_hist);
+      HIPCHK(hipGetLastError());
+    } else if (hist) {
+      hipLaunchKernelGGL(scfq::fq_fold_hist, dim3((unsigned)n_blocks), dim3(256), 0, c->compute, c->d_hist_partials,
+                         rel_phase, block_phase, n_ranges, (const uint8_t*)nullptr, state_hist);
       HIPCHK(hipGetLastError());
     }
   }
@@ -282,7 +329,8 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
   return SCFQ_OK;
 }
 
-int begin_session(Ctx* c) {
+int begin_session(Ctx* c, bool from_start) {
+  c->from_start = from_start;
   c->timing = scfq_timing{};
   c->timing.struct_size = sizeof(scfq_timing);
   c->ev_used = 0;
@@ -315,6 +363,15 @@ int end_session(Ctx* c, bool hist, scfq_partial* out, uint64_t* hist_out) {
     c->timing.h2d_ms += ms;
   }
   std::memcpy(out, c->h_state, sizeof(scfq_partial));
+  out->hist_class = 0;
+  g_hist_stats[0] = g_hist_stats[1] = 0;
+  if (hist) {
+    // speculative K3: only the class the fast form took to be the quality line is complete (0 = all four are)
+    const uint64_t h1 = c->h_state[kExtAt + scfq::kExtH];
+    out->hist_class = h1 ? (((h1 - 1) + 3) & 3u) + 1 : 0;
+    g_hist_stats[0] = c->h_state[kExtAt + scfq::kExtFast];
+    g_hist_stats[1] = c->h_state[kExtAt + scfq::kExtRedo];
+  }
   if (hist && hist_out) std::memcpy(hist_out, c->h_state + SCFQ_PARTIAL_WORDS, SCFQ_HIST_WORDS * sizeof(uint64_t));
   g_last_timing = c->timing;
   return SCFQ_OK;
@@ -328,7 +385,7 @@ uint64_t opt_chunk(const scfq_opts* o) {
 }
 int check_opts(const scfq_opts* o) {
   if (o && o->struct_size != sizeof(scfq_opts)) return SCFQ_EARG;
-  if (o && (o->flags & ~(SCFQ_QUAL_HIST | SCFQ_STRUCT_CHECK | SCFQ_TIMING | SCFQ_PREV_IN_MEMORY))) return SCFQ_EARG;
+  if (o && (o->flags & ~(SCFQ_QUAL_HIST | SCFQ_STRUCT_CHECK | SCFQ_TIMING | SCFQ_PREV_IN_MEMORY | SCFQ_HIST_EXACT))) return SCFQ_EARG;
   if (o && o->n_devices < 0) return SCFQ_EARG;
   if (o && o->n_devices > 0 && !o->device_ids) return SCFQ_EARG;
   return SCFQ_OK;
@@ -571,7 +628,7 @@ int partial_on_current_device(const void* ptr, uint64_t n, int is_device, int pr
   if (rc) return rc;
   const uint32_t flags = opt_flags(opts);
   const bool timing = flags & SCFQ_TIMING;
-  rc = begin_session(c);
+  rc = begin_session(c, prev_byte == -1 && !(flags & SCFQ_PREV_IN_MEMORY));   // -1: the range starts the input
   if (rc) return rc;
   if (is_device) {
     const int prev = (flags & SCFQ_PREV_IN_MEMORY) ? -2 : prev_byte;
@@ -602,6 +659,12 @@ int scfq_device_count(void) {
   return n;
 }
 
+int scfq_debug_hist_stats(uint64_t* fast_ranges, uint64_t* redone_ranges) {
+  if (fast_ranges) *fast_ranges = g_hist_stats[0];
+  if (redone_ranges) *redone_ranges = g_hist_stats[1];
+  return SCFQ_OK;
+}
+
 int scfq_last_timing(scfq_timing* t) {
   if (!t || t->struct_size != sizeof(scfq_timing)) return SCFQ_EARG;
   *t = g_last_timing;
@@ -618,7 +681,32 @@ int scfq_partial_buffer(const void* ptr, uint64_t n, int is_device, int prev_byt
   return partial_on_current_device(ptr, n, is_device, prev_byte, opts, out, hist);
 }
 
+// A shard whose speculative histogram turns out to have backed the wrong class (possible only for a malformed input cut
+// into shards: SCFQ_ESPEC from combine / finalize) is counted again with the exact histogram kernel.
+static int count_buffer_once(const void* ptr, uint64_t n, int is_device, const scfq_opts* opts, scfq_counts* out);
+static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts* out);
+
 int scfq_count_buffer(const void* ptr, uint64_t n, int is_device, const scfq_opts* opts, scfq_counts* out) {
+  int rc = count_buffer_once(ptr, n, is_device, opts, out);
+  if (rc == SCFQ_ESPEC) {
+    scfq_opts o = *opts;     // ESPEC implies opts with SCFQ_QUAL_HIST
+    o.flags |= SCFQ_HIST_EXACT;
+    rc = count_buffer_once(ptr, n, is_device, &o, out);
+  }
+  return rc;
+}
+
+int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
+  int rc = count_file_once(path, opts, out);
+  if (rc == SCFQ_ESPEC) {
+    scfq_opts o = *opts;
+    o.flags |= SCFQ_HIST_EXACT;
+    rc = count_file_once(path, &o, out);
+  }
+  return rc;
+}
+
+static int count_buffer_once(const void* ptr, uint64_t n, int is_device, const scfq_opts* opts, scfq_counts* out) {
   if (!out || out->struct_size != sizeof(scfq_counts) || (!ptr && n)) return SCFQ_EARG;
   int rc = check_opts(opts);
   if (rc) return rc;
@@ -660,7 +748,7 @@ int scfq_count_buffer(const void* ptr, uint64_t n, int is_device, const scfq_opt
   return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
 }
 
-int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
+static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts* out) {
   if (!path || !out || out->struct_size != sizeof(scfq_counts)) return SCFQ_EARG;
   int rc = check_opts(opts);
   if (rc) return rc;
@@ -684,7 +772,7 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
         Ctx* c = nullptr;
         SessionLock sl;
         rc = get_ctx(&c, sl);
-        if (!rc) rc = begin_session(c);
+        if (!rc) rc = begin_session(c, true);
         if (!rc) {
           BgzfSource src(bfd, (uint64_t)bsb.st_size);
           rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
@@ -704,7 +792,7 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
     Ctx* c = nullptr;
     SessionLock sl;
     rc = get_ctx(&c, sl);
-    if (!rc) rc = begin_session(c);
+    if (!rc) rc = begin_session(c, true);
     if (!rc) {
       GzSource src(f);
       rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
@@ -736,7 +824,7 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
         Ctx* c = nullptr;
         SessionLock sl;
         int r = get_ctx(&c, sl);
-        if (!r) r = begin_session(c);
+        if (!r) r = begin_session(c, lo == 0);
         if (!r) { FdSource src(fd, lo, hi); r = ingest(c, src, prev, o.flags, opt_chunk(&o), timing); }
         if (!r) r = end_session(c, want_hist, &parts[d], want_hist ? hists[d].data() : nullptr);
         rcs[d] = r;
@@ -754,7 +842,7 @@ int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
   Ctx* c = nullptr;
   SessionLock sl;
   rc = get_ctx(&c, sl);
-  if (!rc) rc = begin_session(c);
+  if (!rc) rc = begin_session(c, true);
   if (!rc) {
     if (regular) {
       FdSource src(fd, 0, size);
@@ -896,7 +984,7 @@ int scfq_debug_partial_simple(const void* dptr, uint64_t n, int prev_byte, scfq_
   SessionLock sl;
   int rc = get_ctx(&c, sl);
   if (rc) return rc;
-  rc = begin_session(c);
+  rc = begin_session(c, false);
   if (rc) return rc;
   if (n) {
     const uint64_t chunks = (n + 255) / 256;

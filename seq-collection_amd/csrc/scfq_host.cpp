@@ -32,6 +32,12 @@ int scfq_partial_combine(scfq_partial* acc, const scfq_partial* b, uint64_t* his
   rot_add(acc->starts, b->starts, k);
   rot_add(acc->first_at, b->first_at, k);
   rot_add(acc->first_plus, b->first_plus, k);
+  {
+    // which class histograms stay complete: b's class c lands on class (c + k) & 3 of the result
+    const uint64_t cb = (b->hist_class >= 1 && b->hist_class <= 4) ? (((b->hist_class - 1) + k) & 3u) + 1 : b->hist_class;
+    if (acc->hist_class == 0) acc->hist_class = cb;
+    else if (cb != 0 && cb != acc->hist_class) acc->hist_class = 5;
+  }
   if (hist_acc && hist_b) {
     for (unsigned c = 0; c < 4; ++c) {
       const uint64_t* src = hist_b + ((c - k) & 3u) * 256;
@@ -62,7 +68,10 @@ int scfq_partial_finalize(const scfq_partial* p, const uint64_t* hist, scfq_coun
   out->reads = (out->lines + 3) / 4;
   out->bad_at = p->starts[0] - p->first_at[0];
   out->bad_plus = p->starts[2] - p->first_plus[2];
-  if (hist) std::memcpy(out->qual_hist, hist + 3 * 256, 256 * sizeof(uint64_t));   // class 3 == `i mod 4 == 0`
+  if (hist) {
+    if (p->hist_class != 0 && p->hist_class != 4) return SCFQ_ESPEC;   // the speculative form completed another class
+    std::memcpy(out->qual_hist, hist + 3 * 256, 256 * sizeof(uint64_t));   // class 3 == `i mod 4 == 0`
+  }
   return SCFQ_OK;
 }
 
@@ -109,6 +118,7 @@ const char* scfq_strerror(int rc) {
     case SCFQ_EARG: return "invalid argument";
     case SCFQ_EIO: return "read error";
     case SCFQ_ENOMEM: return "out of host memory";
+    case SCFQ_ESPEC: return "speculative quality histogram did not verify across shards (retry with SCFQ_HIST_EXACT)";
     default: return "unknown error";
   }
 }

@@ -20,7 +20,8 @@ SCFQ_QUAL_HIST = 0x1
 SCFQ_STRUCT_CHECK = 0x2
 SCFQ_TIMING = 0x4
 SCFQ_PREV_IN_MEMORY = 0x8
-SCFQ_EOPEN, SCFQ_EGZ, SCFQ_EHIP, SCFQ_ERCCL, SCFQ_EARG, SCFQ_EIO, SCFQ_ENOMEM = -1, -2, -3, -4, -5, -6, -7
+SCFQ_HIST_EXACT = 0x10
+SCFQ_EOPEN, SCFQ_EGZ, SCFQ_EHIP, SCFQ_ERCCL, SCFQ_EARG, SCFQ_EIO, SCFQ_ENOMEM, SCFQ_ESPEC = -1, -2, -3, -4, -5, -6, -7, -8
 PARTIAL_WORDS = 32
 HIST_WORDS = 4 * 256
 
@@ -29,7 +30,7 @@ EXPORTS = [
     "scfq_partial_combine", "scfq_partial_finalize", "scfq_format_tsv", "scfq_strerror",
     "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
-    "scfq_debug_read_file", "scfq_debug_stream_ms",
+    "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
 ]
 
 
@@ -49,7 +50,8 @@ class Partial(ctypes.Structure):
     _fields_ = [("nl", ctypes.c_uint64), ("gc", ctypes.c_uint64 * 4), ("n", ctypes.c_uint64 * 4),
                 ("len", ctypes.c_uint64 * 4), ("starts", ctypes.c_uint64 * 4),
                 ("first_at", ctypes.c_uint64 * 4), ("first_plus", ctypes.c_uint64 * 4),
-                ("bytes", ctypes.c_uint64), ("last_byte", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 5)]
+                ("bytes", ctypes.c_uint64), ("last_byte", ctypes.c_uint64), ("hist_class", ctypes.c_uint64),
+                ("reserved", ctypes.c_uint64 * 4)]
 
     def words(self):
         return list((ctypes.c_uint64 * PARTIAL_WORDS).from_buffer_copy(self))
@@ -199,6 +201,13 @@ def partial_host(data, prev_byte=-1, flags=0, want_hist=False, chunk_bytes=0):
     _check(lib().scfq_partial_buffer(addr, n, 0, prev_byte, ctypes.byref(o), ctypes.byref(p),
                                      ctypes.byref(hist) if want_hist else None), "scfq_partial_buffer")
     return (p, hist) if want_hist else p
+
+
+def hist_stats():
+    """(ranges served by the speculative K3 form, ranges (re)done by the exact kernel) of this thread's last histogram session"""
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    lib().scfq_debug_hist_stats(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def partial_simple_device(dev_ptr, n, prev_byte=-1):

@@ -30,8 +30,12 @@ for case in range(n_cases):
     O.oracle_partial(a.ctypes.data if n else None, n, prev, w, ctypes.byref(h))
     flags = [0, scfq.SCFQ_STRUCT_CHECK, scfq.SCFQ_QUAL_HIST | scfq.SCFQ_STRUCT_CHECK][case % 3]
     if flags & scfq.SCFQ_QUAL_HIST:
-        p, hh = scfq.partial_device(t.data_ptr() + base, n, prev, flags=flags, want_hist=True)
+        p, hh = scfq.partial_device(t.data_ptr() + base, n, prev, flags=flags | scfq.SCFQ_HIST_EXACT, want_hist=True)
         assert list(hh) == list(h), ("hist", case, n, off)
+        p, hh = scfq.partial_device(t.data_ptr() + base, n, prev, flags=flags, want_hist=True)
+        ks = range(4) if p.hist_class == 0 else [p.hist_class - 1]
+        for k in ks:
+            assert list(hh)[k * 256:(k + 1) * 256] == list(h)[k * 256:(k + 1) * 256], ("spec hist", case, n, off, k)
     else:
         p = scfq.partial_device(t.data_ptr() + base, n, prev, flags=flags)
     want = list(w)[:25] if flags & scfq.SCFQ_STRUCT_CHECK else list(w)[:13] + [0] * 12

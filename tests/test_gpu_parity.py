@@ -91,9 +91,18 @@ def test_struct_and_hist_variants(gpu, scfq, oracle, kind):
                 ow, oh = oracle.partial(a, prev, want_hist=True)
                 p = scfq.partial_device(ptr, n, prev, flags=scfq.SCFQ_STRUCT_CHECK)
                 assert_partial_equal(p, ow, ("struct", kind, n, offset, prev))
-                p2, h2 = scfq.partial_device(ptr, n, prev, flags=scfq.SCFQ_QUAL_HIST | scfq.SCFQ_STRUCT_CHECK, want_hist=True)
+                p2, h2 = scfq.partial_device(ptr, n, prev, flags=scfq.SCFQ_QUAL_HIST | scfq.SCFQ_HIST_EXACT | scfq.SCFQ_STRUCT_CHECK, want_hist=True)
                 assert_partial_equal(p2, ow, ("hist+struct", kind, n, offset, prev))
-                assert list(h2) == oh, ("hist", kind, n, offset, prev)
+                assert list(h2) == oh and p2.hist_class == 0, ("hist", kind, n, offset, prev)
+                # speculative form (default): the class it reports complete is exact; 0 = all four are
+                p3, h3 = scfq.partial_device(ptr, n, prev, flags=scfq.SCFQ_QUAL_HIST | scfq.SCFQ_STRUCT_CHECK, want_hist=True)
+                assert_partial_equal(p3, ow, ("spec hist+struct", kind, n, offset, prev))
+                assert p3.hist_class in (0, 1, 2, 3, 4)
+                if p3.hist_class == 0:
+                    assert list(h3) == oh, ("spec hist", kind, n, offset, prev)
+                else:
+                    k = p3.hist_class - 1
+                    assert list(h3)[k * 256:(k + 1) * 256] == oh[k * 256:(k + 1) * 256], ("spec hist class", kind, n, offset, prev, k)
 
 
 def test_shard_boundaries_every_offset(gpu, scfq, oracle):
