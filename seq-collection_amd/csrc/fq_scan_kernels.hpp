@@ -56,6 +56,10 @@ constexpr int kHistWaves = 2;   // waves per block in the histogram variant (LDS
 // u32 bin[byte * kQRep + copy].
 constexpr int kQRep = 16;
 constexpr int kQWords = 256 * kQRep;
+#ifndef SCFQ_QWAVES
+#define SCFQ_QWAVES 8
+#endif
+constexpr int kQWaves = SCFQ_QWAVES;   // waves (= ranges) per workgroup of the speculative form: they share one histogram
 constexpr uint32_t kNoGuess = 255u;
 
 // ------------------------------------------------------------------------------------------------
@@ -271,6 +275,9 @@ struct WaveState {
   uint32_t nl_total;   // wave-uniform: newlines seen so far in this range
   int32_t prev_last;   // wave-uniform: byte before the next tile (-1: none / start of input)
   uint32_t qcls;       // wave-uniform, HIST == 2: relative class guessed to be the quality line (4 = no guess: no histogram)
+  uint32_t piv4;       // wave-uniform, HIST == 2: the range's pivot quality byte, replicated into all four bytes
+  uint32_t piv_set;    // wave-uniform: piv4 is valid
+  uint32_t piv_cnt;    // per lane: quality dwords equal to piv4 (counted here instead of four LDS atomics each)
 };
 
 // widen the pending 8-bit fields into the 16-bit per-lane accumulators (at most every 3rd tile: 3 x 64 < 256)
@@ -429,13 +436,29 @@ __device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist
 // first quality segment [a, b) is split into whole dwords [A, Bd) - four unpredicated atomics under one dword-level
 // exec mask, byte -> bin offset in two cheap ops - and at most 3 head + 3 tail bytes re-read from LDS.  Further quality
 // segments of the same lane (5+ newlines in 64 bytes) take a per-byte loop.
-__device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, const uint8_t* lane_bytes, int lane, uint32_t cls0,
-                                            uint64_t NL, uint32_t cnt, uint32_t qcls) {
+__device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, const uint8_t* slot, int lane, uint32_t cls0,
+                                            uint64_t NL, uint32_t cnt, WaveState& st) {
+  const uint32_t qcls = st.qcls;
+  const uint8_t* lane_bytes = slot + lane * 64;
   uint8_t* base = reinterpret_cast<uint8_t*>(hq) + ((lane & (kQRep - 1)) << 2);
   constexpr uint32_t kMask = 0xFFu << 6;   // byte offset of a bin copy: byte << 6 | copy << 2
   static_assert(kQRep == 16, "bin offset arithmetic assumes 16 copies");
+#ifndef SCFQ_QABLATE
+#define SCFQ_QABLATE 0   // timing-only diagnostic builds: 1 = addresses computed but no LDS atomics, 2 = no histogram work at all
+#endif
+  if (SCFQ_QABLATE == 2) return;
   auto bump = [&](uint32_t off) {
+    if (SCFQ_QABLATE == 1) { uint8_t* p = base + off; asm volatile("" :: "v"(p)); return; }
     __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // bin address of the byte in bits 6..13 of t: the histogram is 16 KiB-aligned in LDS, so "base + offset" is an OR and
+  // the whole address is one v_and_or_b32 on top of the shift
+  const uint32_t base_bits = (uint32_t)(uintptr_t)base;
+  auto bump_byte = [&](uint32_t t) {
+    const uint32_t addr = (t & kMask) | base_bits;
+    if (SCFQ_QABLATE == 1) { asm volatile("" :: "v"(addr)); return; }
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    __hip_atomic_fetch_add((lds_u32*)(uintptr_t)addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   const uint32_t i0 = (qcls - cls0) & 3u;
   const uint64_t x0 = NL, x1 = x0 & (x0 - 1), x2 = x1 & (x1 - 1), x3 = x2 & (x2 - 1);
@@ -445,16 +468,35 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
   const uint32_t b = xb ? (uint32_t)__builtin_ctzll(xb) : 64u;
   const uint32_t A = (a + 3u) >> 2, Bd = b >> 2;
   const uint32_t width = (Bd > A) ? Bd - A : 0u;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if ((uint32_t)j - A < width) {
-      const uint32_t w = d[j];
-      bump((w << 6) & kMask);
-      bump((w >> 2) & kMask);
-      bump((w >> 10) & kMask);
-      bump((w >> 18) & kMask);
+  // Pivot: quality strings are dominated by one value (one byte is ~90 % of an Illumina quality line), which would
+  // serialise the lanes of every atomic on one bin.  A dword made of four pivot bytes is counted in a register instead;
+  // the pivot is whatever byte starts the first whole quality dword this wave meets (any choice is exact).
+  if (!st.piv_set) {
+    const uint64_t have = __builtin_amdgcn_ballot_w64(width != 0);
+    if (have) {
+      const int L = __builtin_ctzll(have);
+      const uint32_t a_l = (uint32_t)__builtin_amdgcn_readlane((int)A, L);
+      const uint32_t byte = slot[L * 64 + 4 * a_l];
+      st.piv4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(byte * 0x01010101u));
+      st.piv_set = 1u;
     }
   }
+  const uint32_t piv4 = st.piv4;
+  uint32_t pc = st.piv_cnt;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t w = d[j];
+    const bool in = (uint32_t)j - A < width;
+    const bool is_piv = (w == piv4);
+    pc += (in && is_piv) ? 1u : 0u;
+    if (in && !is_piv) {
+      bump_byte(w << 6);
+      bump_byte(w >> 2);
+      bump_byte(w >> 10);
+      bump_byte(w >> 18);
+    }
+  }
+  st.piv_cnt = pc;
   const uint32_t he = (b < 4u * A) ? b : 4u * A;               // head bytes [a, he)
   const uint32_t ts = (Bd > A) ? 4u * Bd : 4u * A;             // tail bytes [ts, b)
 #pragma unroll
@@ -507,7 +549,7 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint32_t sh0 = ((st.phase + incl - cnt) & 3u) * 8u;
   if (HIST == 1) hist_tile_full(d, hist_lds, lane, sh0 >> 3, NL);
   if (HIST == 2) {
-    if (st.qcls < 4u) hist_tile_q(d, hist_lds, slot + lane * 64, lane, sh0 >> 3, NL, cnt, st.qcls);   // wave-uniform branch
+    if (st.qcls < 4u) hist_tile_q(d, hist_lds, slot, lane, sh0 >> 3, NL, cnt, st);   // wave-uniform branch
   }
 
   // K4: line-start bytes = the byte after a '\n' (bit 0: previous lane's / previous tile's last byte)
@@ -640,14 +682,15 @@ struct ScanArgs {
 //         class h+2 (in a well-formed FASTQ only the header/separator pair can satisfy it: a sequence line never
 //         starts with '@' or '+').  Ambiguous or not found within guess_cap_tiles: kNoGuess.
 template <bool STRUCT, int HIST, int RING = kRing, bool NT = true, bool GUESS = false>
-__global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : 64 * kWavesPerBlock) void fq_scan_tiles(ScanArgs a) {
-  constexpr int WAVES = HIST == 1 ? kHistWaves : kWavesPerBlock;
+__global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWaves : 64 * kWavesPerBlock) void fq_scan_tiles(ScanArgs a) {
+  constexpr int WAVES = HIST == 1 ? kHistWaves : HIST == 2 ? kQWaves : kWavesPerBlock;
   static_assert(RING >= 2 && RING <= 4, "ring depth");
   static_assert(!GUESS || (STRUCT && HIST == 0), "the guess pass is the K4 accounting without partials");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  uint8_t* ring = smem + wave * (RING * kTile);
+  // HIST == 2: the shared histogram comes first (its bin addressing ORs offsets into a 16 KiB-aligned base), rings after
+  uint8_t* ring = smem + (HIST == 2 ? kQWords * 4 : 0) + wave * (RING * kTile);
   const uint64_t range = (uint64_t)blockIdx.x * WAVES + wave;
   bool active = range < a.n_ranges;
   if (HIST == 1 && active && a.todo) active = (a.todo[range] != 0);
@@ -658,7 +701,8 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : 64 * kWavesPerBlock) 
     for (int k = lane; k < kHistWords; k += 64) hist_lds[k] = 0;
   }
   if (HIST == 2) {
-    hist_lds = reinterpret_cast<uint32_t*>(smem + WAVES * RING * kTile);
+    hist_lds = reinterpret_cast<uint32_t*>(smem);
+    if ((uint32_t)(uintptr_t)hist_lds & (kQWords * 4 - 1)) __builtin_trap();   // a property of the build, not of the input
     for (int k = threadIdx.x; k < kQWords; k += 64 * WAVES) hist_lds[k] = 0;
     __syncthreads();
   }
@@ -816,6 +860,8 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : 64 * kWavesPerBlock) 
     // that '\r' lies in the previous range, like len)
     const uint32_t crq = (qcls == 0) ? cr4.x : (qcls == 1) ? cr4.y : (qcls == 2) ? cr4.z : cr4.w;
     if (lane == 0 && crq) atomicSub(&hist_lds[13 * kQRep], crq);
+    const uint32_t pivots = wave_sum(st.piv_cnt);      // dwords of four pivot bytes that were counted in registers
+    if (lane == 0 && pivots) atomicAdd(&hist_lds[(st.piv4 & 0xFFu) * kQRep], 4u * pivots);
   }
   if (HIST == 1) {
     // per-range histogram partial [class][byte] (u32): sum the lane-keyed copies, then take back the bytes that
@@ -837,12 +883,13 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : 64 * kWavesPerBlock) 
   if (HIST == 2) {
     // workgroup histogram of the quality class: thread t sums the copies of byte value t
     __syncthreads();
-    const uint32_t t = threadIdx.x;
-    const uint4* src = reinterpret_cast<const uint4*>(hist_lds + t * kQRep);
-    uint32_t v = 0;
+    for (uint32_t t = threadIdx.x; t < 256; t += 64 * WAVES) {
+      const uint4* src = reinterpret_cast<const uint4*>(hist_lds + t * kQRep);
+      uint32_t v = 0;
 #pragma unroll
-    for (int r = 0; r < kQRep / 4; ++r) { const uint4 q = src[r]; v += q.x + q.y + q.z + q.w; }
-    a.hist_wg[(uint64_t)blockIdx.x * 256 + t] = v;
+      for (int r = 0; r < kQRep / 4; ++r) { const uint4 q = src[r]; v += q.x + q.y + q.z + q.w; }
+      a.hist_wg[(uint64_t)blockIdx.x * 256 + t] = v;
+    }
   }
 }
 
@@ -993,9 +1040,10 @@ __global__ __launch_bounds__(256) void fq_fold_hist(const uint32_t* hist_partial
 // (newlines before it, mod 4) that is class (g + p_r) & 3 relative to the session.  All guesses must agree on one H:
 // force_h >= 0 when the session starts at the start of the input (H = 0 by definition), else H is taken from the
 // first range that has a guess (and is checked again by the host when shards are combined / finalized).  A workgroup
-// (4 consecutive ranges, one shared histogram) with any disagreeing range is discarded as a whole; its ranges and all
+// (kQWaves consecutive ranges, one shared histogram) with any disagreeing range is discarded as a whole; its ranges and all
 // ranges without a guess are marked todo for the exact kernel.
 constexpr int kExtH = 0, kExtFast = 1, kExtRedo = 2, kExtWords = 8;
+constexpr uint64_t kFoldWgPer = 16;    // workgroup histograms summed per block of fq_fold_hist_wg
 __global__ __launch_bounds__(256) void fq_hist_verify(const uint8_t* guess, const uint8_t* rel_phase, const uint8_t* block_phase,
                                                       uint64_t n_ranges, int force_h, uint64_t* ext, uint8_t* todo,
                                                       uint8_t* wg_ok) {
@@ -1004,19 +1052,22 @@ __global__ __launch_bounds__(256) void fq_hist_verify(const uint8_t* guess, cons
   if (tid == 0) { s_first = 0xFFFFFFFFu; s_fast = 0; s_redo = 0; }
   __syncthreads();
   auto session_class = [&](uint64_t r) { return ((uint32_t)guess[r] + block_phase[r / kFold1] + rel_phase[r]) & 3u; };
+  // every block derives the same H (a pure function of the inputs), so blocks never wait for each other
   uint32_t H = (force_h >= 0) ? (uint32_t)force_h : ((uint32_t)ext[kExtH] ? (uint32_t)ext[kExtH] - 1u : kNoGuess);
   if (H == kNoGuess) {     // block-uniform
-    uint32_t mine = 0xFFFFFFFFu;
-    for (uint64_t r = tid; r < n_ranges; r += 256)
-      if (guess[r] != kNoGuess) { mine = (uint32_t)r; break; }
-    atomicMin(&s_first, mine);
-    __syncthreads();
+    for (uint64_t r0 = 0; r0 < n_ranges; r0 += 256) {
+      const uint64_t r = r0 + tid;
+      if (r < n_ranges && guess[r] != kNoGuess) atomicMin(&s_first, (uint32_t)r);
+      __syncthreads();
+      if (s_first != 0xFFFFFFFFu) break;
+    }
     if (s_first != 0xFFFFFFFFu) H = session_class(s_first);
   }
-  const uint64_t n_wg = (n_ranges + kWavesPerBlock - 1) / kWavesPerBlock;
+  const uint64_t n_wg = (n_ranges + kQWaves - 1) / kQWaves;
   uint32_t fast = 0, redo = 0;
-  for (uint64_t b = tid; b < n_wg; b += 256) {
-    const uint64_t r0 = b * kWavesPerBlock, r1 = (r0 + kWavesPerBlock < n_ranges) ? r0 + kWavesPerBlock : n_ranges;
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + tid;
+  if (b < n_wg) {
+    const uint64_t r0 = b * kQWaves, r1 = (r0 + kQWaves < n_ranges) ? r0 + kQWaves : n_ranges;
     bool poisoned = false;
     for (uint64_t r = r0; r < r1; ++r)
       if (guess[r] != kNoGuess && session_class(r) != H) poisoned = true;
@@ -1027,20 +1078,20 @@ __global__ __launch_bounds__(256) void fq_hist_verify(const uint8_t* guess, cons
     }
     wg_ok[b] = poisoned ? 0 : 1;
   }
-  atomicAdd(&s_fast, fast);
-  atomicAdd(&s_redo, redo);
+  if (fast) atomicAdd(&s_fast, fast);
+  if (redo) atomicAdd(&s_redo, redo);
   __syncthreads();
   if (tid == 0) {
-    if (H != kNoGuess && s_fast) ext[kExtH] = H + 1u;
-    ext[kExtFast] += s_fast;
-    ext[kExtRedo] += s_redo;
+    if (H != kNoGuess && s_fast) ext[kExtH] = H + 1u;      // every writer stores the same value
+    if (s_fast) atomicAdd(reinterpret_cast<unsigned long long*>(&ext[kExtFast]), (unsigned long long)s_fast);
+    if (s_redo) atomicAdd(reinterpret_cast<unsigned long long*>(&ext[kExtRedo]), (unsigned long long)s_redo);
   }
 }
 
 // state_hist[(H + 3) & 3][b] += sum over the verified workgroups of hist_wg[.][b]   (u32 modular partials: sign-extend)
 __global__ __launch_bounds__(256) void fq_fold_hist_wg(const uint32_t* hist_wg, const uint8_t* wg_ok, uint64_t n_wg,
                                                        const uint64_t* ext, unsigned long long* state_hist) {
-  constexpr uint64_t kPer = 64;
+  constexpr uint64_t kPer = kFoldWgPer;
   const uint32_t t = threadIdx.x;
   if (!ext[kExtH]) return;                      // no range was taken from the fast form
   const uint32_t q = ((uint32_t)ext[kExtH] - 1u + 3u) & 3u;

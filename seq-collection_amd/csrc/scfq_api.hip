@@ -177,7 +177,7 @@ int ensure_partials(Ctx* c, uint64_t n_ranges, bool hist) {
     HIPCHK(hipMalloc(&c->d_guess, 3 * cap));          // guess | todo | wg_ok
     c->d_todo = c->d_guess + cap;
     c->d_wg_ok = c->d_todo + cap;
-    HIPCHK(hipMalloc(&c->d_hist_wg, (cap / scfq::kWavesPerBlock + 1) * 256 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&c->d_hist_wg, (cap / scfq::kQWaves + 1) * 256 * sizeof(uint32_t)));
     c->cap_hist_ranges = cap;
   }
   return SCFQ_OK;
@@ -220,7 +220,7 @@ uint32_t pick_tiles_per_range(const Ctx* c, uint64_t n_tiles) {
 
 template <bool S, int H, int RING, bool NT, bool GUESS = false>
 void launch_scan(const scfq::ScanArgs& a, unsigned blocks, hipStream_t st) {
-  constexpr int waves = (H == 1) ? scfq::kHistWaves : scfq::kWavesPerBlock;
+  constexpr int waves = (H == 1) ? scfq::kHistWaves : (H == 2) ? scfq::kQWaves : scfq::kWavesPerBlock;
   unsigned lds = waves * RING * scfq::kTile;
   if (H == 1) lds += waves * scfq::kHistWords * sizeof(uint32_t);
   if (H == 2) lds += scfq::kQWords * sizeof(uint32_t);
@@ -306,7 +306,8 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
     if (spec) {
       // verify the guesses against the exact phases, redo what did not verify with the exact kernel, fold both kinds
       uint64_t* ext = c->d_state + kExtAt;
-      hipLaunchKernelGGL(scfq::fq_hist_verify, dim3(1), dim3(256), 0, c->compute, c->d_guess, rel_phase, block_phase, n_ranges,
+      const uint64_t n_wg = (n_ranges + scfq::kQWaves - 1) / scfq::kQWaves;
+      hipLaunchKernelGGL(scfq::fq_hist_verify, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, c->compute, c->d_guess, rel_phase, block_phase, n_ranges,
                          c->from_start ? 0 : -1, ext, c->d_todo, c->d_wg_ok);
       HIPCHK(hipGetLastError());
       a.todo = c->d_todo;
@@ -315,8 +316,7 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
       HIPCHK(hipGetLastError());
       hipLaunchKernelGGL(scfq::fq_fold_hist, dim3((unsigned)n_blocks), dim3(256), 0, c->compute, c->d_hist_partials,
                          rel_phase, block_phase, n_ranges, c->d_todo, state_hist);
-      const uint64_t n_wg = (n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock;
-      hipLaunchKernelGGL(scfq::fq_fold_hist_wg, dim3((unsigned)((n_wg + 63) / 64)), dim3(256), 0, c->compute, c->d_hist_wg,
+      hipLaunchKernelGGL(scfq::fq_fold_hist_wg, dim3((unsigned)((n_wg + scfq::kFoldWgPer - 1) / scfq::kFoldWgPer)), dim3(256), 0, c->compute, c->d_hist_wg,
                          c->d_wg_ok, n_wg, ext, state_hist);
       HIPCHK(hipGetLastError());
     } else if (hist) {
