@@ -138,6 +138,14 @@ int  scfq_partial_combine(scfq_partial* acc, const scfq_partial* b, uint64_t* hi
  * lines and reads (ceil(lines/4), src/fq_count.nim:39-41). */
 int  scfq_partial_finalize(const scfq_partial* p, const uint64_t* hist, scfq_counts* out);
 
+/* ---- K5: line index (record-boundary detection) ---------------------------------------------
+ * Lines as the reference's `lines(stream)` yields them (src/fq_count.nim:38, src/fq_dedup.nim:42): record i of a FASTQ
+ * is lines 4i .. 4i+3. For a device-resident input writes line_off[j] = offset of the first byte of line j for
+ * j = 0 .. lines-1 and the sentinel line_off[lines] = offset one past the (real or implied) final '\n', so that line j
+ * is bytes [line_off[j], line_off[j+1] - 1) before "\r\n" stripping. line_off_device: device memory of `cap` entries,
+ * or NULL to only count. *lines_out is always set; nothing is written when cap < lines + 1. */
+int scfq_index_lines(const void* device_ptr, uint64_t n, uint64_t* line_off_device, uint64_t cap, uint64_t* lines_out);
+
 /* ---- formatting: src/fq_count.nim:47-51 ---------------------------------------------------
  * "<reads>\t<gc_content>\t<gc_bases>\t<n_bases>\t<bases>" without trailing newline;
  * gc_content = gc/(bases-n) as IEEE double printed the way Nim 1.0.6 `$float` does: C "%.16g",

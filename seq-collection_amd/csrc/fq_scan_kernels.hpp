@@ -1103,6 +1103,134 @@ __global__ __launch_bounds__(256) void fq_fold_hist_wg(const uint32_t* hist_wg, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5: line index (record-boundary detection).  line_off[j] = offset, relative to the first byte of the input, of the
+// first byte of line j.  Lines are what the reference's `lines(stream)` yields (src/fq_count.nim:38, src/fq_dedup.nim:42):
+// every '\n' ends one; record i of a FASTQ is lines 4i .. 4i+3.  Two passes over HBM: K1 + K2 give every range its
+// newline count, fq_nl_prefix turns those into the ordinal of the first line start each range will emit, and
+// fq_index_lines re-scans the newlines (same tiles, same LDS-DMA ring) and scatters `position of '\n' + 1` to
+// line_off[ordinal]: wave prefix-sum of the per-lane newline counts (DPP) + a wave-uniform running total.  Lanes that
+// hold the k-th newline of consecutive lines write consecutive 8-byte slots, so the stores coalesce.
+// ------------------------------------------------------------------------------------------------
+
+// exclusive prefix sum of the per-range newline counts (one block; n_ranges is a few 10^4): first_ord[r] = line_base + 1 +
+// number of '\n' in ranges < r  (the first '\n' of range r starts line first_ord[r]); first_ord[n_ranges] = total + line_base + 1
+__global__ __launch_bounds__(1024) void fq_nl_prefix(const uint64_t* partials, uint64_t n_ranges, uint64_t line_base,
+                                                     uint64_t* first_ord) {
+  __shared__ uint64_t wave_tot[16];
+  __shared__ uint64_t carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry = line_base + 1;
+  __syncthreads();
+  for (uint64_t r0 = 0; r0 < n_ranges; r0 += 1024) {
+    const uint64_t r = r0 + tid;
+    const uint32_t nl = (r < n_ranges) ? (uint32_t)partials[r * kPartialWords + W_NL] : 0u;   // <= 4096 * kMaxTilesPerRange
+    const uint32_t incl = wave_inclusive_scan(nl);
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    uint64_t before = carry;
+    for (uint32_t k = 0; k < w; ++k) before += wave_tot[k];
+    if (r < n_ranges) first_ord[r] = before + incl - nl;
+    __syncthreads();
+    if (tid == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) first_ord[n_ranges] = carry;
+}
+
+struct IndexArgs {
+  const uint8_t* base;        // first byte of the input (any alignment)
+  uint64_t n;                 // bytes
+  uint32_t tiles_per_range;   // the same ranges as the scan that produced the partials
+  uint64_t n_ranges;
+  const uint64_t* first_ord;  // fq_nl_prefix
+  uint64_t* line_off;         // [>= total lines + 1]
+  uint64_t off_base;          // offset of base[0] in the whole input (streaming chunks)
+};
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_lines(IndexArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* ring = smem + wave * (2 * kTile);
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
+  const uint64_t range = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (range >= a.n_ranges) return;
+  const uint64_t B = (uint64_t)(uintptr_t)a.base, E = B + a.n;
+  const uint64_t A0 = B & ~(uint64_t)(kTile - 1);
+  const uint32_t n_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((E - A0 + kTile - 1) / kTile));
+  const uint32_t t_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(range * a.tiles_per_range));
+  uint32_t t_end = t_begin + a.tiles_per_range;
+  if (t_end > n_tiles) t_end = n_tiles;
+  t_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_end);
+  const uint32_t full_lo = (uint32_t)__builtin_amdgcn_readfirstlane((A0 < B) ? 1 : 0);
+  const uint32_t full_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A0 + (uint64_t)n_tiles * kTile > E) ? n_tiles - 1 : n_tiles));
+  // ordinal of the line that the first '\n' of this range starts; pinned before the first DMA (see fq_scan_tiles)
+  uint64_t ord = a.first_ord[range];
+  ord = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ord >> 32)) << 32) |
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ord);
+  PlaneConsts pc;
+  pc.init();
+
+  auto issue = [&](uint32_t t, uint32_t slot) {
+    const uint64_t ts = A0 + (uint64_t)t * kTile;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + slot * kTile));
+    if (t >= full_lo && t < full_hi) {
+      glds_tile<true>(reinterpret_cast<const uint8_t*>(ts + (uint64_t)lane * 16), dst);
+    } else {
+      const uint64_t safe = (B & ~15ull);
+      uint64_t s[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint64_t ps = ts + (uint64_t)k * 1024 + (uint64_t)lane * 16;
+        const bool ok = (ps + 16 > B) && (ps < E);
+        s[k] = (ok ? ps : safe) - (uint64_t)k * 1024;
+      }
+      glds_tile_edge(reinterpret_cast<const uint8_t*>(s[0]), reinterpret_cast<const uint8_t*>(s[1]),
+                     reinterpret_cast<const uint8_t*>(s[2]), reinterpret_cast<const uint8_t*>(s[3]), dst);
+    }
+  };
+
+  if (t_begin < t_end) issue(t_begin, 0);
+  uint32_t slot = 0;
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) { issue(t + 1, slot ^ 1u); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+    const uint4* p = reinterpret_cast<const uint4*>(ring + slot * kTile + lane * 64);
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    uint32_t a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+    masks32_planes<false>(d, pc, a0, a1, a2, a3, a4);
+    masks32_planes<false>(d + 8, pc, b0, b1, b2, b3, b4);
+    uint64_t NL = ~((uint64_t)a0 | ((uint64_t)b0 << 32));
+    const uint64_t ts = A0 + (uint64_t)t * kTile;
+    if (!(t >= full_lo && t < full_hi)) {     // first / last tile of the input: only bytes inside [B, E) exist
+      const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);
+      int64_t lo = (int64_t)B - ls, hi = (int64_t)E - ls;
+      lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
+      hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
+      const uint64_t mhi = (hi >= 64) ? ~0ull : ((1ull << hi) - 1);
+      const uint64_t mlo = (lo >= 64) ? ~0ull : ((1ull << lo) - 1);
+      NL &= mhi & ~mlo;
+    }
+    const uint32_t cnt = popc64(NL);
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total) {      // wave-uniform
+      uint64_t o = ord + (incl - cnt);
+      // offset of the byte AFTER bit k of this lane, relative to the whole input
+      const uint64_t lane_off = a.off_base + (ts + (uint64_t)lane * 64 - B) + 1;
+      uint64_t x = NL;
+      while (x) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(x);
+        x &= x - 1;
+        a.line_off[o++] = lane_off + k;
+      }
+    }
+    ord += total;
+    slot ^= 1u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Diagnostic (NOT the product path): the load structure of fq_scan_tiles alone -- same ranges, same 2-slot
 // non-temporal LDS-DMA ring, one ds_read per lane and tile, no classification or accounting.  Its time is the
 // practical ceiling the scan kernel is compared with on the same device (bench.py "stream_ceiling").

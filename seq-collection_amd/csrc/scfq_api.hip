@@ -62,6 +62,10 @@ struct Ctx {
   uint8_t* d_wg_ok = nullptr;
   uint32_t* d_hist_wg = nullptr;
   bool from_start = false;             // the session begins at the start of the input: header lines are class 0
+  uint32_t last_tpr = 0;               // geometry of the last scan launch (K5 re-walks the same ranges)
+  uint64_t last_ranges = 0;
+  uint64_t* d_first_ord = nullptr;     // K5: per range, ordinal of the first line start it emits
+  uint64_t cap_first_ord = 0;
   uint64_t* d_block_partials = nullptr;   // level-1 fold output
   uint64_t cap_blocks = 0;
   uint64_t* d_state = nullptr;   // [32 partial words][1024 hist words]
@@ -246,6 +250,8 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
   const uint64_t n_ranges = (NT + tpr - 1) / tpr;
   int rc = ensure_partials(c, n_ranges, hist);
   if (rc) return rc;
+  c->last_tpr = tpr;
+  c->last_ranges = n_ranges;
   scfq::ScanArgs a;
   a.base = dptr;
   a.n = n;
@@ -891,6 +897,9 @@ int scfq_shutdown(void) {
     if (c->d_block_partials) (void)hipFree(c->d_block_partials);
     if (c->d_hist_partials) (void)hipFree(c->d_hist_partials);
     if (c->d_range_phase) (void)hipFree(c->d_range_phase);
+    if (c->d_guess) (void)hipFree(c->d_guess);
+    if (c->d_hist_wg) (void)hipFree(c->d_hist_wg);
+    if (c->d_first_ord) (void)hipFree(c->d_first_ord);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -900,6 +909,59 @@ int scfq_shutdown(void) {
     if (c->copy) (void)hipStreamDestroy(c->copy);
   }
   g_ctx.clear();
+  return SCFQ_OK;
+}
+
+// ---- K5: line index of a device-resident input ------------------------------------------------------------------
+int scfq_index_lines(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out) {
+  if ((!dptr && n) || !lines_out) return SCFQ_EARG;
+  Ctx* c = nullptr;
+  SessionLock sl;
+  int rc = get_ctx(&c, sl);
+  if (rc) return rc;
+  rc = begin_session(c, true);
+  if (rc) return rc;
+  const uint8_t* base = static_cast<const uint8_t*>(dptr);
+  rc = scan_async(c, base, n, -1, 0, false);
+  if (rc) return rc;
+  scfq_partial p;
+  rc = end_session(c, false, &p, nullptr);      // synchronises: the newline count sizes the index
+  if (rc) return rc;
+  const uint64_t lines = p.nl + ((n > 0 && p.last_byte != (uint64_t)'\n') ? 1u : 0u);
+  *lines_out = lines;
+  if (!d_line_off || cap < lines + 1) return SCFQ_OK;   // count only / index does not fit: caller sizes and calls again
+  HIPCHK(hipMemsetAsync(d_line_off, 0, sizeof(uint64_t), c->compute));          // line 0 starts at offset 0
+  if (n) {
+    const uint64_t n_ranges = c->last_ranges;
+    if (n_ranges + 1 > c->cap_first_ord) {
+      if (c->d_first_ord) HIPCHK(hipFree(c->d_first_ord));
+      c->d_first_ord = nullptr;
+      c->cap_first_ord = 0;
+      const uint64_t want = std::max<uint64_t>(n_ranges + 1 + n_ranges / 4, 4096);
+      HIPCHK(hipMalloc(&c->d_first_ord, want * sizeof(uint64_t)));
+      c->cap_first_ord = want;
+    }
+    hipLaunchKernelGGL(scfq::fq_nl_prefix, dim3(1), dim3(1024), 0, c->compute, c->d_partials, n_ranges, (uint64_t)0, c->d_first_ord);
+    HIPCHK(hipGetLastError());
+    scfq::IndexArgs ia;
+    ia.base = base;
+    ia.n = n;
+    ia.tiles_per_range = c->last_tpr;
+    ia.n_ranges = n_ranges;
+    ia.first_ord = c->d_first_ord;
+    ia.line_off = d_line_off;
+    ia.off_base = 0;
+    const unsigned grid = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
+    hipLaunchKernelGGL(scfq::fq_index_lines, dim3(grid), dim3(64 * scfq::kWavesPerBlock), scfq::kWavesPerBlock * 2 * scfq::kTile,
+                       c->compute, ia);
+    HIPCHK(hipGetLastError());
+    if (p.last_byte != (uint64_t)'\n') {
+      // the final line has no '\n': the sentinel pretends there is one right after the input
+      c->h_state[0] = n + 1;
+      HIPCHK(hipMemcpyAsync(d_line_off + lines, c->h_state, sizeof(uint64_t), hipMemcpyHostToDevice, c->compute));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(c->compute));
   return SCFQ_OK;
 }
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
     "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
+    "scfq_index_lines",
 ]
 
 
@@ -115,6 +116,8 @@ def lib():
                                          ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SynthInfo)]
         L.scfq_debug_read_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.scfq_debug_read_file.restype = ctypes.c_int64
+        L.scfq_index_lines.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                       ctypes.POINTER(ctypes.c_uint64)]
         L.scfq_debug_stream_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
         L.scfq_debug_stream_ms.restype = ctypes.c_double
         L.scfq_synth_locate.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
@@ -201,6 +204,14 @@ def partial_host(data, prev_byte=-1, flags=0, want_hist=False, chunk_bytes=0):
     _check(lib().scfq_partial_buffer(addr, n, 0, prev_byte, ctypes.byref(o), ctypes.byref(p),
                                      ctypes.byref(hist) if want_hist else None), "scfq_partial_buffer")
     return (p, hist) if want_hist else p
+
+
+def index_lines_device(dev_ptr, n, line_off_ptr=None, cap=0):
+    """K5: number of lines; with a device buffer of `cap` uint64 entries also writes the line-start offsets + sentinel"""
+    lines = ctypes.c_uint64()
+    _check(lib().scfq_index_lines(ctypes.c_void_p(dev_ptr), n, ctypes.c_void_p(line_off_ptr) if line_off_ptr else None, cap,
+                                  ctypes.byref(lines)), "scfq_index_lines")
+    return lines.value
 
 
 def hist_stats():
