@@ -146,6 +146,36 @@ int  scfq_partial_finalize(const scfq_partial* p, const uint64_t* hist, scfq_cou
  * or NULL to only count. *lines_out is always set; nothing is written when cap < lines + 1. */
 int scfq_index_lines(const void* device_ptr, uint64_t n, uint64_t* line_off_device, uint64_t cap, uint64_t* lines_out);
 
+/* ---- `sc fq-dedup` (next row of SURVEY.md §8f): src/fq_dedup.nim:14-84 ------------------------
+ * De-duplicate a FASTQ by read ID: every record (lines 4i .. 4i+3) whose header line equals the header line of an
+ * earlier record is dropped, everything else is echoed, each line as text + '\n' (so "\r\n" comes out as "\n").
+ * Replaces the reference's two streaming passes with Bloom filter + CountTable (:29,42-73) by an exact device
+ * pipeline over the HBM-resident input: line index, header hashes, radix sort, exact compare inside equal-hash runs,
+ * prefix sum of the kept lengths, gather. */
+typedef struct scfq_dedup_stats {
+  uint64_t struct_size;      /* caller sets to sizeof(scfq_dedup_stats) */
+  uint64_t total_reads;      /* n_reads = lines div 4                             src/fq_dedup.nim:49 */
+  uint64_t duplicates;       /* n_dups: records dropped                           :65 */
+  uint64_t false_positive;   /* the reference's Bloom-filter diagnostic (:76-80); always 0 here: no Bloom filter */
+  uint64_t records_out;      /* records echoed */
+  uint64_t bytes_out;        /* bytes echoed */
+  uint64_t hash_collisions;  /* header pairs with equal 64-bit hash and different text (resolved by the exact compare) */
+} scfq_dedup_stats;
+
+/* Input in host (is_device = 0) or device memory; the de-duplicated FASTQ is written to out (host or device memory of
+ * out_cap bytes). *out_bytes is always set to the size of the result: out = NULL only sizes (returns SCFQ_OK), a too
+ * small out returns SCFQ_EARG. */
+int scfq_dedup_buffer(const void* ptr, uint64_t n, int is_device, void* out, uint64_t out_cap, int out_is_device,
+                      uint64_t* out_bytes, scfq_dedup_stats* stats);
+/* Stages the whole input (".gz" by suffix as src/fq_dedup.nim:32: zlib / BGZF inflate on the host) into HBM,
+ * de-duplicates, writes the result to out_fd (what the reference echoes to stdout); out_fd < 0: statistics only. */
+int scfq_dedup_file(const char* path, const scfq_opts* opts, int out_fd, scfq_dedup_stats* stats);
+const char* scfq_dedup_error_detail(void);
+
+/* Whole (inflated) input of `path` into a device buffer the caller frees with scfq_device_free(). */
+int scfq_stage_file(const char* path, const scfq_opts* opts, void** device_ptr_out, uint64_t* n_out);
+int scfq_device_free(void* device_ptr);
+
 /* ---- formatting: src/fq_count.nim:47-51 ---------------------------------------------------
  * "<reads>\t<gc_content>\t<gc_bases>\t<n_bases>\t<bases>" without trailing newline;
  * gc_content = gc/(bases-n) as IEEE double printed the way Nim 1.0.6 `$float` does: C "%.16g",

@@ -49,6 +49,17 @@ void oracle_partial(const uint8_t* buf, size_t n, int prev_byte, uint64_t out27[
 /* src/fq_count.nim:47-51 with Nim 1.0.6 `$float` ("%.16g" + ".0" rule, "nan"). Returns length. */
 int oracle_format_tsv(const oracle_counts* c, char* buf, size_t cap);
 
+/* ---- `sc fq-dedup` (reference: src/fq_dedup.nim:14-84), restated in fqdedup_oracle.c ------------------------------ */
+typedef struct oracle_dedup_stats {
+  uint64_t total_reads;      /* n_reads = lines div 4                 src/fq_dedup.nim:49 */
+  uint64_t duplicates;       /* n_dups: records dropped               :65 */
+  uint64_t false_positive;   /* Bloom diagnostics (:76-80): restated as 0, see fqdedup_oracle.c */
+  uint64_t records_out, bytes_out;
+} oracle_dedup_stats;
+/* Writes the de-duplicated FASTQ (what the reference echoes to stdout) into out; returns its length, -2 when out_cap is
+ * too small, -1 on allocation failure. */
+int64_t oracle_dedup(const uint8_t* buf, size_t n, uint8_t* out, size_t out_cap, oracle_dedup_stats* st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,7 +124,8 @@ static void help_fq_count(FILE* f) {   // docs/fq-count.md:5-19
 static void help_top(FILE* f) {
   std::fprintf(f,
                "sc (%s) — MI355X-native host for the fq-count path of seq-collection\n\n"
-               "Usage:\n  sc COMMAND\n\nCommands:\n\nFASTQ\n  fq-count         Counts lines in a FASTQ\n\n"
+               "Usage:\n  sc COMMAND\n\nCommands:\n\nFASTQ\n  fq-count         Counts lines in a FASTQ\n"
+               "  fq-dedup         Removes exact duplicates from FASTQ Files\n\n"
                "Options:\n  -h, --help                 Show this help\n  -v, --version              Show version\n"
                "      --debug                Debug mode\n",
                kVersion);
@@ -206,6 +207,52 @@ static void fq_count_emit(const FileResult& r) {
   if (!r.extra.empty()) std::fputs(r.extra.c_str(), stderr);
 }
 
+// Nim 1.0.6 `$float` as used by stderr.writeLine (src/fq_dedup.nim:80): "%.16g", ".0" appended when the text has neither
+// '.' nor a letter, NaN -> "nan"
+static std::string nim_float(double v) {
+  if (v != v) return "nan";
+  char f[64];
+  std::snprintf(f, sizeof f, "%.16g", v);
+  std::string t(f);
+  if (t.find_first_of(".abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ") == std::string::npos) t += ".0";
+  return t;
+}
+
+// command "fq-dedup" (sc.nim:118-122): one positional FASTQ, no options; proc fq_dedup (src/fq_dedup.nim:14-84)
+static int cmd_fq_dedup(const std::vector<std::string>& params) {
+  auto help = [](FILE* f) {
+    std::fputs("Removes exact duplicates from FASTQ Files\n\nUsage:\n  fq-dedup [options] fastq\n\nArguments:\n"
+               "  fastq            Input FASTQ\n\nOptions:\n  -h, --help                 Show this help\n", f);
+  };
+  std::vector<std::string> files;
+  for (size_t i = 1; i < params.size(); ++i) {
+    if (params[i] == "-h" || params[i] == "--help") { help(stdout); return 0; }
+    files.push_back(params[i]);
+  }
+  if (files.size() != 1) { help(stdout); quit_error(files.empty() ? "Missing argument: fastq" : "Unknown argument(s): " + files[1], 1); }
+  const std::string& fastq = files[0];
+  if (fastq == "STDIN") quit_error("This command does not support stdin");                    // sc.nim:58-60
+  struct stat sb;
+  if (stat(fastq.c_str(), &sb) != 0 || S_ISDIR(sb.st_mode))                                    // helpers.nim:39-43
+    quit_error(fastq + " does not exist or is not readable");
+  scfq_dedup_stats st;
+  std::memset(&st, 0, sizeof st);
+  st.struct_size = sizeof st;
+  // the reference announces "No Duplicates Found" before pass 2 starts echoing (fq_dedup.nim:51-53); here the FASTQ goes
+  // to fd 1 first and all diagnostics follow: stdout is byte-identical and the lines on stderr keep their order
+  std::fflush(stdout);
+  const int rc = scfq_dedup_file(fastq.c_str(), nullptr, 1, &st);
+  if (rc == SCFQ_EOPEN) quit_error("Unable to open file: " + fastq, 2);                         // fq_dedup.nim:37-38
+  if (rc == SCFQ_EIO) return 0;                                                                 // EPIPE: swallowed like sc.nim:304
+  if (rc != SCFQ_OK) quit_error(std::string(scfq_strerror(rc)) + ": " + scfq_dedup_error_detail() + scfq_last_error_detail(), 1);
+  if (st.duplicates == 0) std::fputs("No Duplicates Found\nCopying fq to stdout\n", stderr);   // :51-53 (check.len == 0)
+  std::fprintf(stderr, "total_reads: %llu\n", (unsigned long long)st.total_reads);            // :74
+  std::fprintf(stderr, "duplicates %llu\n", (unsigned long long)st.duplicates);                // :75
+  std::fprintf(stderr, "false-positive: %llu\n", (unsigned long long)st.false_positive);      // :79
+  std::fprintf(stderr, "false-positive-rate: %s\n", nim_float((double)st.false_positive / (double)st.duplicates).c_str());   // :80
+  return 0;
+}
+
 int main(int argc, char** argv) {
   signal(SIGPIPE, SIG_IGN);   // sc.nim:45-46
   std::vector<std::string> params(argv + 1, argv + argc);
@@ -214,9 +261,10 @@ int main(int argc, char** argv) {
       if (p == "-") { p = "STDIN"; break; }
   if (params.empty() || params[0] == "-h" || params[0] == "--help") { help_top(stdout); return 0; }
   if (params[0] == "-v" || params[0] == "--version") { std::printf("%s\n", kVersion); return 0; }
+  if (params[0] == "fq-dedup") return cmd_fq_dedup(params);
   if (params[0] != "fq-count") {
     help_top(stdout);
-    quit_error("Unknown command: " + params[0] + " (this build provides the fq-count path only)", 1);
+    quit_error("Unknown command: " + params[0] + " (this build provides the fq-count and fq-dedup paths only)", 1);
   }
   if (params.size() == 1) { help_fq_count(stdout); return 0; }   // sc.nim:288-290: len <= 1 -> "-h"
 

@@ -912,6 +912,87 @@ int scfq_shutdown(void) {
   return SCFQ_OK;
 }
 
+// ---- whole (inflated) input into HBM: the staging step of the commands that need random access to records ------------
+// Same source selection as scfq_count_file (plain pread / BGZF block-parallel inflate / serial gzread), same pinned
+// double buffer and copy stream; the device buffer grows geometrically when the inflated size is not known up front.
+int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, uint64_t* n_out) {
+  if (!path || !dptr_out || !n_out) return SCFQ_EARG;
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  *dptr_out = nullptr;
+  *n_out = 0;
+  const size_t plen = std::strlen(path);
+  const bool is_gz = plen >= 3 && std::memcmp(path + plen - 3, ".gz", 3) == 0;     // src/fq_dedup.nim:32, src/fq_count.nim:31
+  std::unique_ptr<Source> src;
+  int fd = -1;
+  gzFile gz = nullptr;
+  uint64_t hint = 64ull << 20;
+  struct Closer { int* fd; gzFile* gz; std::unique_ptr<Source>* s; ~Closer() { s->reset(); if (*gz) gzclose(*gz); if (*fd >= 0) close(*fd); } } closer{&fd, &gz, &src};
+  struct stat sb;
+  if (is_gz) {
+    fd = open(path, O_RDONLY);
+    if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) hint = std::max<uint64_t>(hint, 4 * (uint64_t)sb.st_size);
+    if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && !std::getenv("SCFQ_NO_BGZF") && scfq_bgzf::probe(fd)) {
+      src.reset(new BgzfSource(fd, (uint64_t)sb.st_size));
+    } else {
+      if (fd >= 0) close(fd);
+      fd = -1;
+      gz = gzopen(path, "rb");
+      if (!gz) return SCFQ_EOPEN;
+      gzbuffer(gz, 1u << 20);
+      src.reset(new GzSource(gz));
+    }
+  } else {
+    fd = open(path, O_RDONLY);
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return SCFQ_EOPEN;
+    hint = std::max<uint64_t>((uint64_t)sb.st_size, 4096);
+    src.reset(new FdSource(fd, 0, (uint64_t)sb.st_size));
+  }
+  if (opts && opts->n_devices >= 1) HIPCHK(hipSetDevice(opts->device_ids[0]));
+  Ctx* c = nullptr;
+  SessionLock sl;
+  rc = get_ctx(&c, sl);
+  if (rc) return rc;
+  const uint64_t chunk = opt_chunk(opts);
+  rc = ensure_staging(c, chunk, true);
+  if (rc) return rc;
+  uint8_t* d_buf = nullptr;
+  uint64_t cap = hint, off = 0;
+  HIPCHK(hipMalloc(&d_buf, cap));
+  struct BufGuard { uint8_t** p; ~BufGuard() { if (*p) (void)hipFree(*p); } } bg{&d_buf};
+  for (unsigned it = 0;; ++it) {
+    const int b = it & 1;
+    if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));
+    const int64_t got = src->fill(c->h_pin[b], chunk);
+    if (got < 0) return (int)got;
+    if (got == 0) break;
+    if (off + (uint64_t)got > cap) {
+      HIPCHK(hipStreamSynchronize(c->copy));
+      const uint64_t ncap = std::max<uint64_t>(2 * cap, off + (uint64_t)got);
+      uint8_t* nb = nullptr;
+      HIPCHK(hipMalloc(&nb, ncap));
+      hipError_t e = hipMemcpy(nb, d_buf, off, hipMemcpyDeviceToDevice);
+      if (e != hipSuccess) { (void)hipFree(nb); HIPCHK(e); }
+      (void)hipFree(d_buf);
+      d_buf = nb;
+      cap = ncap;
+    }
+    HIPCHK(hipMemcpyAsync(d_buf + off, c->h_pin[b], (size_t)got, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
+    off += (uint64_t)got;
+  }
+  HIPCHK(hipStreamSynchronize(c->copy));
+  *dptr_out = d_buf;
+  *n_out = off;
+  d_buf = nullptr;      // ownership passes to the caller (scfq_device_free)
+  return SCFQ_OK;
+}
+
+int scfq_device_free(void* dptr) {
+  if (dptr) HIPCHK(hipFree(dptr));
+  return SCFQ_OK;
+}
+
 // ---- K5: line index of a device-resident input ------------------------------------------------------------------
 int scfq_index_lines(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out) {
   if ((!dptr && n) || !lines_out) return SCFQ_EARG;

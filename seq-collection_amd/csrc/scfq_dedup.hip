@@ -1,0 +1,336 @@
+// scfq_dedup.hip — `sc fq-dedup` on the MI355X (gfx950): de-duplicate a FASTQ by read ID, keep the first record of
+// every ID (reference: src/fq_dedup.nim:14-84; CLI sc.nim:118-122).
+//
+// The reference streams the file twice through one thread: pass 1 fills a Bloom filter (1e8 capacity, :29) plus a
+// CountTable of suspects, pass 2 echoes every record whose header was not met before.  The Bloom filter is only a
+// pre-filter (a false positive is still echoed on its first occurrence), so stdout is exactly "drop each record whose
+// header line equals an earlier header line".  Here the whole (inflated) input sits in HBM (288 GB per GPU) and that
+// definition is computed directly, with no probabilistic structure:
+//   K5  line index            (fq_scan_kernels.hpp: K1 + K2 + fq_nl_prefix + fq_index_lines)
+//   D1  dd_hash_headers       64-bit hash of every header line (line 4i, EOL stripped as Nim readLine does)
+//   D2  radix sort            (hash, record) pairs, rocPRIM via hipCUB; stable, so equal hashes stay in file order
+//   D3  dd_mark_duplicates    a record is a duplicate iff an EARLIER record of its equal-hash run has the same bytes:
+//                             exact string compare, so hash collisions cost time, never correctness
+//   D4  dd_record_lengths     bytes each kept record echoes: for each of its lines, text + '\n' ("\r\n" comes out as "\n",
+//                             a final line without '\n' gains one: `echo record`, fq_dedup.nim:59,67,71)
+//   D5  exclusive scan        output offset of every kept record (hipCUB)
+//   D6  dd_gather             one wave per record copies its lines to the output buffer
+// Everything is integer / byte work bound by HBM traffic; there is no CPU fallback.
+#include "../../include/sc_fqcount.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+thread_local char g_derr[512] = "";
+
+#define DCHK(call)                                                                                          \
+  do {                                                                                                      \
+    hipError_t e_ = (call);                                                                                 \
+    if (e_ != hipSuccess) {                                                                                 \
+      std::snprintf(g_derr, sizeof g_derr, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      if (std::getenv("SCFQ_VERBOSE")) std::fprintf(stderr, "scfq: %s\n", g_derr);                          \
+      return SCFQ_EHIP;                                                                                     \
+    }                                                                                                       \
+  } while (0)
+
+struct DevBuf {   // frees on scope exit
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <typename T> T* as() { return static_cast<T*>(p); }
+  int alloc(size_t bytes) { DCHK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return SCFQ_OK; }
+};
+
+// text of line j: [line_off[j], end) where end excludes the '\n' and a '\r' directly before a REAL '\n'
+// (Nim 1.0.6 readLine; a final line without '\n' keeps a trailing '\r')
+__device__ __forceinline__ void line_span(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t j,
+                                          uint64_t& s, uint64_t& e) {
+  s = line_off[j];
+  const uint64_t nlpos = line_off[j + 1] - 1;     // position of the (real or implied) '\n'
+  e = nlpos;
+  if (nlpos < n && e > s && base[e - 1] == '\r') --e;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return x;
+}
+
+// D1: one thread per header line; 8 bytes per step (unaligned 64-bit loads are fine on gfx9 global memory), tail bytewise
+__global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
+                                                      uint64_t seed, uint32_t hash_bits, uint64_t* keys, uint32_t* idx) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_hdr) return;
+  uint64_t s, e;
+  line_span(base, n, line_off, 4 * i, s, e);
+  uint64_t h = seed ^ ((e - s) * 0x9E3779B97F4A7C15ull);
+  uint64_t p = s;
+  for (; p + 8 <= e; p += 8) {
+    uint64_t w;
+    __builtin_memcpy(&w, base + p, 8);
+    h = mix64(h ^ w) + 0x9E3779B97F4A7C15ull;
+  }
+  uint64_t tail = 0;
+  for (int k = 0; p < e; ++p, ++k) tail |= (uint64_t)base[p] << (8 * k);
+  h = mix64(h ^ tail);
+  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // test hook: forces collisions
+  keys[i] = h;
+  idx[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t ra, uint64_t rb) {
+  uint64_t sa, ea, sb, eb;
+  line_span(base, n, line_off, 4 * ra, sa, ea);
+  line_span(base, n, line_off, 4 * rb, sb, eb);
+  if (ea - sa != eb - sb) return false;
+  const uint64_t len = ea - sa;
+  uint64_t k = 0;
+  for (; k + 8 <= len; k += 8) {
+    uint64_t x, y;
+    __builtin_memcpy(&x, base + sa + k, 8);
+    __builtin_memcpy(&y, base + sb + k, 8);
+    if (x != y) return false;
+  }
+  for (; k < len; ++k)
+    if (base[sa + k] != base[sb + k]) return false;
+  return true;
+}
+
+// D3: sorted position p; walk back through the run of equal hashes until an equal header is found (normally the
+// neighbour p-1: either it is the same string, or the run is a genuine collision and is a handful of entries long)
+__global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
+                                                         const uint64_t* keys_sorted, const uint32_t* idx_sorted, uint8_t* dup,
+                                                         unsigned long long* counters /* [0] dups, [1] hash collisions */) {
+  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_hdr) return;
+  const uint64_t key = keys_sorted[p];
+  const uint32_t me = idx_sorted[p];
+  bool is_dup = false;
+  uint32_t collided = 0;
+  for (uint64_t q = p; q > 0 && keys_sorted[q - 1] == key; --q) {
+    if (same_header(base, n, line_off, idx_sorted[q - 1], me)) { is_dup = true; break; }
+    ++collided;
+  }
+  dup[me] = is_dup ? 1 : 0;
+  if (is_dup) atomicAdd(&counters[0], 1ull);
+  if (collided) atomicAdd(&counters[1], (unsigned long long)collided);
+}
+
+// D4: bytes record i echoes (0 when dropped): its lines 4i .. min(4i+3, lines-1), each text + '\n'
+__global__ __launch_bounds__(256) void dd_record_lengths(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
+                                                        uint64_t n_hdr, const uint8_t* dup, uint64_t* out_len) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_hdr) return;
+  uint64_t total = 0;
+  if (!dup[i]) {
+    for (uint64_t j = 4 * i; j < 4 * i + 4 && j < lines; ++j) {
+      uint64_t s, e;
+      line_span(base, n, line_off, j, s, e);
+      total += e - s + 1;
+    }
+  }
+  out_len[i] = total;
+}
+
+// D6: one wave per record.  Fast path (every line of the record ends in a plain '\n' inside the input): the record's
+// output is its input bytes verbatim, copied 16 bytes per lane once the destination is aligned.  Otherwise line by line.
+__global__ __launch_bounds__(256) void dd_gather(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
+                                                uint64_t n_hdr, const uint64_t* out_off, const uint64_t* out_len, uint8_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (i >= n_hdr) return;
+  const uint64_t len = out_len[i];
+  if (!len) return;
+  uint8_t* dst = out + out_off[i];
+  const uint64_t j0 = 4 * i, j1 = (j0 + 4 < lines) ? j0 + 4 : lines;
+  const uint64_t s0 = line_off[j0], s1 = line_off[j1];
+  if (s1 - s0 == len && s1 <= n) {
+    // verbatim: same number of bytes in and out means no '\r' was stripped and no '\n' was added
+    const uint8_t* src = base + s0;
+    uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+    if (head > len) head = len;
+    if (lane < head) dst[lane] = src[lane];
+    const uint64_t body = (len - head) / 16;
+    for (uint64_t k = lane; k < body; k += 64) {
+      uint4 v;
+      __builtin_memcpy(&v, src + head + k * 16, 16);       // source is arbitrarily aligned
+      *reinterpret_cast<uint4*>(dst + head + k * 16) = v;
+    }
+    for (uint64_t k = head + body * 16 + lane; k < len; k += 64) dst[k] = src[k];
+    return;
+  }
+  uint64_t w = 0;
+  for (uint64_t j = j0; j < j1; ++j) {
+    uint64_t s, e;
+    line_span(base, n, line_off, j, s, e);
+    for (uint64_t k = lane; k < e - s; k += 64) dst[w + k] = base[s + k];
+    if (lane == 0) dst[w + (e - s)] = '\n';
+    w += e - s + 1;
+  }
+}
+
+int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t** d_out, uint64_t* out_bytes, scfq_dedup_stats* st, hipStream_t stream) {
+  *d_out = nullptr;
+  *out_bytes = 0;
+  uint64_t lines = 0;
+  int rc = scfq_index_lines(d_in, n, nullptr, 0, &lines);
+  if (rc) return rc;
+  st->total_reads = lines / 4;                       // n_reads = i div 4      src/fq_dedup.nim:49
+  const uint64_t n_hdr = (lines + 3) / 4;            // header lines: 0-based index i mod 4 == 0 (:43,57)
+  if (n_hdr >= (1ull << 32)) { std::snprintf(g_derr, sizeof g_derr, "more than 2^32 records in one input"); return SCFQ_EARG; }
+  if (n_hdr == 0) return SCFQ_OK;
+  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp;
+  if ((rc = line_off.alloc((lines + 1) * 8))) return rc;
+  rc = scfq_index_lines(d_in, n, line_off.as<uint64_t>(), lines + 1, &lines);
+  if (rc) return rc;
+  if ((rc = keys.alloc(n_hdr * 8)) || (rc = keys2.alloc(n_hdr * 8)) || (rc = idx.alloc(n_hdr * 4)) || (rc = idx2.alloc(n_hdr * 4)) ||
+      (rc = dup.alloc(n_hdr)) || (rc = out_len.alloc((n_hdr + 1) * 8)) || (rc = out_off.alloc((n_hdr + 1) * 8)) || (rc = counters.alloc(16)))
+    return rc;
+  DCHK(hipMemsetAsync(counters.p, 0, 16, stream));
+  const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
+  static const uint32_t hash_bits = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); int v = e ? std::atoi(e) : 64; return (uint32_t)std::min(64, std::max(1, v)); }();
+  hipLaunchKernelGGL(dd_hash_headers, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
+                     0x5CF0DED0B1A5ull, hash_bits, keys.as<uint64_t>(), idx.as<uint32_t>());
+  DCHK(hipGetLastError());
+  size_t tmp_bytes = 0;
+  DCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(),
+                                          idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
+  size_t scan_bytes = 0;
+  DCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (int)(n_hdr + 1), stream));
+  if ((rc = tmp.alloc(std::max(tmp_bytes, scan_bytes)))) return rc;
+  DCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(),
+                                          idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
+  hipLaunchKernelGGL(dd_mark_duplicates, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
+                     keys2.as<uint64_t>(), idx2.as<uint32_t>(), dup.as<uint8_t>(), counters.as<unsigned long long>());
+  DCHK(hipGetLastError());
+  hipLaunchKernelGGL(dd_record_lengths, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                     dup.as<uint8_t>(), out_len.as<uint64_t>());
+  DCHK(hipGetLastError());
+  DCHK(hipMemsetAsync(out_len.as<uint64_t>() + n_hdr, 0, 8, stream));       // the scan's last output is the total
+  DCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (int)(n_hdr + 1), stream));
+  uint64_t h[3] = {0, 0, 0};
+  DCHK(hipMemcpyAsync(&h[0], out_off.as<uint64_t>() + n_hdr, 8, hipMemcpyDeviceToHost, stream));
+  DCHK(hipMemcpyAsync(&h[1], counters.p, 16, hipMemcpyDeviceToHost, stream));
+  DCHK(hipStreamSynchronize(stream));
+  st->duplicates = h[1];
+  st->hash_collisions = h[2];
+  st->records_out = n_hdr - h[1];
+  st->bytes_out = h[0];
+  st->false_positive = 0;
+  void* o = nullptr;
+  DCHK(hipMalloc(&o, std::max<uint64_t>(h[0], 16)));
+  hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_hdr + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                     out_off.as<uint64_t>(), out_len.as<uint64_t>(), static_cast<uint8_t*>(o));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) {
+    (void)hipFree(o);
+    std::snprintf(g_derr, sizeof g_derr, "dd_gather -> %s", hipGetErrorString(e));
+    return SCFQ_EHIP;
+  }
+  *d_out = static_cast<uint8_t*>(o);
+  *out_bytes = h[0];
+  return SCFQ_OK;
+}
+
+int write_all(int fd, const uint8_t* p, uint64_t n) {
+  while (n) {
+    ssize_t w = write(fd, p, (size_t)std::min<uint64_t>(n, 1u << 30));
+    if (w < 0) return SCFQ_EIO;
+    p += w;
+    n -= (uint64_t)w;
+  }
+  return SCFQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* scfq_dedup_error_detail(void) { return g_derr; }
+
+int scfq_dedup_buffer(const void* ptr, uint64_t n, int is_device, void* out, uint64_t out_cap, int out_is_device,
+                      uint64_t* out_bytes, scfq_dedup_stats* st) {
+  if ((!ptr && n) || !st || st->struct_size != sizeof(scfq_dedup_stats) || !out_bytes) return SCFQ_EARG;
+  const uint64_t keep_size = st->struct_size;
+  std::memset(st, 0, sizeof(*st));
+  st->struct_size = keep_size;
+  *out_bytes = 0;
+  hipStream_t stream = nullptr;
+  DCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+  DevBuf staged;
+  const uint8_t* d_in = static_cast<const uint8_t*>(ptr);
+  if (!is_device && n) {
+    int rc = staged.alloc(n);
+    if (rc) return rc;
+    DCHK(hipMemcpy(staged.p, ptr, n, hipMemcpyHostToDevice));
+    d_in = staged.as<uint8_t>();
+  }
+  uint8_t* d_out = nullptr;
+  uint64_t nb = 0;
+  int rc = dedup_device(d_in, n, &d_out, &nb, st, stream);
+  if (rc) return rc;
+  *out_bytes = nb;
+  if (nb > out_cap || (!out && nb)) { if (d_out) (void)hipFree(d_out); return out ? SCFQ_EARG : SCFQ_OK; }   // caller sizes and calls again
+  if (nb) {
+    hipError_t e = hipMemcpy(out, d_out, nb, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { std::snprintf(g_derr, sizeof g_derr, "copy of the result -> %s", hipGetErrorString(e)); return SCFQ_EHIP; }
+  }
+  return SCFQ_OK;
+}
+
+int scfq_dedup_file(const char* path, const scfq_opts* opts, int out_fd, scfq_dedup_stats* st) {
+  if (!path || !st || st->struct_size != sizeof(scfq_dedup_stats)) return SCFQ_EARG;
+  const uint64_t keep_size = st->struct_size;
+  std::memset(st, 0, sizeof(*st));
+  st->struct_size = keep_size;
+  void* d_in = nullptr;
+  uint64_t n = 0;
+  int rc = scfq_stage_file(path, opts, &d_in, &n);      // whole (inflated) input into HBM
+  if (rc) return rc;
+  struct InGuard { void* p; ~InGuard() { if (p) (void)hipFree(p); } } ig{d_in};
+  hipStream_t stream = nullptr;
+  DCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+  uint8_t* d_out = nullptr;
+  uint64_t nb = 0;
+  rc = dedup_device(static_cast<const uint8_t*>(d_in), n, &d_out, &nb, st, stream);
+  if (rc) return rc;
+  struct OutGuard { void* p; ~OutGuard() { if (p) (void)hipFree(p); } } og{d_out};
+  if (out_fd < 0 || nb == 0) return SCFQ_OK;
+  // HBM -> two pinned buffers -> write(): the copy of chunk k+1 overlaps the write of chunk k
+  const uint64_t chunk = 32ull << 20;
+  uint8_t* pin[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (int b = 0; b < 2; ++b) { DCHK(hipHostMalloc(&pin[b], chunk, hipHostMallocDefault)); DCHK(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming)); }
+  struct PinGuard { uint8_t** p; hipEvent_t* e; ~PinGuard() { for (int b = 0; b < 2; ++b) { if (p[b]) (void)hipHostFree(p[b]); if (e[b]) (void)hipEventDestroy(e[b]); } } } pg{pin, ev};
+  const uint64_t n_chunks = (nb + chunk - 1) / chunk;
+  auto issue = [&](uint64_t k) -> hipError_t {
+    const uint64_t lo = k * chunk, len = std::min(chunk, nb - lo);
+    hipError_t e = hipMemcpyAsync(pin[k & 1], d_out + lo, len, hipMemcpyDeviceToHost, stream);
+    return e != hipSuccess ? e : hipEventRecord(ev[k & 1], stream);
+  };
+  DCHK(issue(0));
+  for (uint64_t k = 0; k < n_chunks; ++k) {
+    DCHK(hipEventSynchronize(ev[k & 1]));
+    if (k + 1 < n_chunks) DCHK(issue(k + 1));
+    const uint64_t lo = k * chunk, len = std::min(chunk, nb - lo);
+    if (write_all(out_fd, pin[k & 1], len)) return SCFQ_EIO;
+  }
+  return SCFQ_OK;
+}
+
+}  // extern "C"

@@ -31,7 +31,8 @@ EXPORTS = [
     "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
     "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
-    "scfq_index_lines",
+    "scfq_index_lines", "scfq_dedup_buffer", "scfq_dedup_file", "scfq_dedup_error_detail", "scfq_stage_file",
+    "scfq_device_free",
 ]
 
 
@@ -68,6 +69,11 @@ class Timing(ctypes.Structure):
                 ("fold_kernel_ms", ctypes.c_double), ("scan_bytes", ctypes.c_uint64),
                 ("scan_launches", ctypes.c_uint64), ("host_fill_ms", ctypes.c_double),
                 ("ingest_wall_ms", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64), ("h2d_ms", ctypes.c_double)]
+
+
+class DedupStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("struct_size", "total_reads", "duplicates", "false_positive", "records_out",
+                                               "bytes_out", "hash_collisions")]
 
 
 class SynthInfo(ctypes.Structure):
@@ -116,6 +122,13 @@ def lib():
                                          ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SynthInfo)]
         L.scfq_debug_read_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.scfq_debug_read_file.restype = ctypes.c_int64
+        L.scfq_dedup_buffer.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
+                                        ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(DedupStats)]
+        L.scfq_dedup_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(DedupStats)]
+        L.scfq_dedup_error_detail.restype = ctypes.c_char_p
+        L.scfq_stage_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_uint64)]
+        L.scfq_device_free.argtypes = [ctypes.c_void_p]
         L.scfq_index_lines.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64)]
         L.scfq_debug_stream_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
@@ -212,6 +225,40 @@ def index_lines_device(dev_ptr, n, line_off_ptr=None, cap=0):
     _check(lib().scfq_index_lines(ctypes.c_void_p(dev_ptr), n, ctypes.c_void_p(line_off_ptr) if line_off_ptr else None, cap,
                                   ctypes.byref(lines)), "scfq_index_lines")
     return lines.value
+
+
+def _new_dedup_stats():
+    st = DedupStats()
+    st.struct_size = ctypes.sizeof(DedupStats)
+    return st
+
+
+def dedup_device(dev_ptr, n, out_dev_ptr=None, out_cap=0):
+    """fq-dedup of a device-resident FASTQ; result into device memory (out_dev_ptr None: size + statistics only).
+    Returns (bytes_out, DedupStats)."""
+    st = _new_dedup_stats()
+    nb = ctypes.c_uint64()
+    _check(lib().scfq_dedup_buffer(ctypes.c_void_p(dev_ptr), n, 1, ctypes.c_void_p(out_dev_ptr) if out_dev_ptr else None,
+                                   out_cap, 1, ctypes.byref(nb), ctypes.byref(st)), "scfq_dedup_buffer")
+    return nb.value, st
+
+
+def dedup_host(data):
+    """fq-dedup of a host buffer (bytes / numpy uint8); returns (bytes, DedupStats)"""
+    addr, n, keep = _host_ptr(data)
+    st = _new_dedup_stats()
+    nb = ctypes.c_uint64()
+    _check(lib().scfq_dedup_buffer(addr, n, 0, None, 0, 0, ctypes.byref(nb), ctypes.byref(st)), "scfq_dedup_buffer")
+    out = (ctypes.c_uint8 * max(nb.value, 1))()
+    st = _new_dedup_stats()
+    _check(lib().scfq_dedup_buffer(addr, n, 0, out, nb.value, 0, ctypes.byref(nb), ctypes.byref(st)), "scfq_dedup_buffer")
+    return bytes(out[:nb.value]), st
+
+
+def dedup_file(path, out_fd=-1):
+    st = _new_dedup_stats()
+    _check(lib().scfq_dedup_file(os.fsencode(path), None, out_fd, ctypes.byref(st)), "scfq_dedup_file")
+    return st
 
 
 def hist_stats():

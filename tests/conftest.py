@@ -35,10 +35,14 @@ class OracleCounts(ctypes.Structure):
                [("qual_hist", ctypes.c_uint64 * 256)]
 
 
+class OracleDedupStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in "total_reads duplicates false_positive records_out bytes_out".split()]
+
+
 def _build_oracle():
     so = os.path.join(ROOT, "oracle", "libfqcount_oracle.so")
-    src = os.path.join(ROOT, "oracle", "fqcount_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("fqcount_oracle.c", "fqdedup_oracle.c", "fqcount_oracle.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return so
 
@@ -53,6 +57,8 @@ def oracle():
     L.oracle_partial.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
                                  ctypes.c_void_p]
     L.oracle_format_tsv.argtypes = [ctypes.POINTER(OracleCounts), ctypes.c_char_p, ctypes.c_size_t]
+    L.oracle_dedup.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(OracleDedupStats)]
+    L.oracle_dedup.restype = ctypes.c_int64
 
     class O:
         lib = L
@@ -85,6 +91,16 @@ def oracle():
             L.oracle_partial(a.ctypes.data if a.size else None, a.size, prev_byte, w,
                              ctypes.byref(h) if want_hist else None)
             return (list(w), list(h)) if want_hist else list(w)
+
+        @classmethod
+        def dedup(cls, data):
+            """(output bytes, stats) of the fq-dedup restatement"""
+            a = cls._buf(data)
+            out = (ctypes.c_uint8 * (2 * a.size + 16))()
+            st = OracleDedupStats()
+            n = L.oracle_dedup(a.ctypes.data if a.size else None, a.size, out, 2 * a.size + 16, ctypes.byref(st))
+            assert n >= 0, n
+            return bytes(out[:n]), st
 
         @staticmethod
         def tsv(c):
