@@ -43,11 +43,29 @@ thread_local char g_derr[512] = "";
     }                                                                                                       \
   } while (0)
 
-struct DevBuf {   // frees on scope exit
+// Scratch comes from the device's stream-ordered memory pool, which is told to keep what it has (release threshold =
+// everything): after the first call a de-duplication allocates nothing from the driver (hipMalloc / hipFree of multi-GB
+// buffers cost more than all kernels of the pipeline together).
+int pool_keep_memory() {
+  static thread_local int done_dev = -1;
+  int dev = 0;
+  DCHK(hipGetDevice(&dev));
+  if (done_dev == dev) return SCFQ_OK;
+  hipMemPool_t pool;
+  DCHK(hipDeviceGetDefaultMemPool(&pool, dev));
+  uint64_t keep = UINT64_MAX;
+  DCHK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+  done_dev = dev;
+  return SCFQ_OK;
+}
+
+struct DevBuf {   // returns its memory to the pool on scope exit (stream-ordered)
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipStream_t s = nullptr;
+  ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
   template <typename T> T* as() { return static_cast<T*>(p); }
-  int alloc(size_t bytes) { DCHK(hipMalloc(&p, std::max<size_t>(bytes, 16))); return SCFQ_OK; }
+  int alloc(size_t bytes, hipStream_t stream) { s = stream; DCHK(hipMallocAsync(&p, std::max<size_t>(bytes, 16), stream)); return SCFQ_OK; }
+  void* release() { void* q = p; p = nullptr; return q; }
 };
 
 // text of line j: [line_off[j], end) where end excludes the '\n' and a '\r' directly before a REAL '\n'
@@ -180,22 +198,29 @@ __global__ __launch_bounds__(256) void dd_gather(const uint8_t* base, uint64_t n
   }
 }
 
-int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t** d_out, uint64_t* out_bytes, scfq_dedup_stats* st, hipStream_t stream) {
+// user_out / user_cap: device memory of the caller to gather into directly (nullptr: the result gets its own buffer, *d_out,
+// which the caller returns with hipFreeAsync on `stream`); sized_only: stop after the statistics (out_bytes is set)
+int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t user_cap, bool sized_only, uint8_t** d_out,
+                 uint64_t* out_bytes, scfq_dedup_stats* st, hipStream_t stream) {
   *d_out = nullptr;
   *out_bytes = 0;
   uint64_t lines = 0;
-  int rc = scfq_index_lines(d_in, n, nullptr, 0, &lines);
+  int rc = pool_keep_memory();
+  if (rc) return rc;
+  rc = scfq_index_lines(d_in, n, nullptr, 0, &lines);
   if (rc) return rc;
   st->total_reads = lines / 4;                       // n_reads = i div 4      src/fq_dedup.nim:49
   const uint64_t n_hdr = (lines + 3) / 4;            // header lines: 0-based index i mod 4 == 0 (:43,57)
-  if (n_hdr >= (1ull << 32)) { std::snprintf(g_derr, sizeof g_derr, "more than 2^32 records in one input"); return SCFQ_EARG; }
+  if (n_hdr >= (1ull << 31)) { std::snprintf(g_derr, sizeof g_derr, "more than 2^31 records in one input"); return SCFQ_EARG; }
   if (n_hdr == 0) return SCFQ_OK;
   DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp;
-  if ((rc = line_off.alloc((lines + 1) * 8))) return rc;
+  if ((rc = line_off.alloc((lines + 1) * 8, stream))) return rc;
+  DCHK(hipStreamSynchronize(stream));       // scfq_index_lines works on the library's own stream
   rc = scfq_index_lines(d_in, n, line_off.as<uint64_t>(), lines + 1, &lines);
   if (rc) return rc;
-  if ((rc = keys.alloc(n_hdr * 8)) || (rc = keys2.alloc(n_hdr * 8)) || (rc = idx.alloc(n_hdr * 4)) || (rc = idx2.alloc(n_hdr * 4)) ||
-      (rc = dup.alloc(n_hdr)) || (rc = out_len.alloc((n_hdr + 1) * 8)) || (rc = out_off.alloc((n_hdr + 1) * 8)) || (rc = counters.alloc(16)))
+  if ((rc = keys.alloc(n_hdr * 8, stream)) || (rc = keys2.alloc(n_hdr * 8, stream)) || (rc = idx.alloc(n_hdr * 4, stream)) ||
+      (rc = idx2.alloc(n_hdr * 4, stream)) || (rc = dup.alloc(n_hdr, stream)) || (rc = out_len.alloc((n_hdr + 1) * 8, stream)) ||
+      (rc = out_off.alloc((n_hdr + 1) * 8, stream)) || (rc = counters.alloc(16, stream)))
     return rc;
   DCHK(hipMemsetAsync(counters.p, 0, 16, stream));
   const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
@@ -208,7 +233,7 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t** d_out, uint64_t* out
                                           idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
   size_t scan_bytes = 0;
   DCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (int)(n_hdr + 1), stream));
-  if ((rc = tmp.alloc(std::max(tmp_bytes, scan_bytes)))) return rc;
+  if ((rc = tmp.alloc(std::max(tmp_bytes, scan_bytes), stream))) return rc;
   DCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(),
                                           idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
   hipLaunchKernelGGL(dd_mark_duplicates, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
@@ -228,19 +253,21 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t** d_out, uint64_t* out
   st->records_out = n_hdr - h[1];
   st->bytes_out = h[0];
   st->false_positive = 0;
-  void* o = nullptr;
-  DCHK(hipMalloc(&o, std::max<uint64_t>(h[0], 16)));
-  hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_hdr + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
-                     out_off.as<uint64_t>(), out_len.as<uint64_t>(), static_cast<uint8_t*>(o));
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  if (e != hipSuccess) {
-    (void)hipFree(o);
-    std::snprintf(g_derr, sizeof g_derr, "dd_gather -> %s", hipGetErrorString(e));
-    return SCFQ_EHIP;
-  }
-  *d_out = static_cast<uint8_t*>(o);
   *out_bytes = h[0];
+  if (sized_only || h[0] == 0) return SCFQ_OK;
+  DevBuf own;
+  uint8_t* o = user_out;
+  if (!o) {
+    if ((rc = own.alloc(h[0], stream))) return rc;
+    o = own.as<uint8_t>();
+  } else if (user_cap < h[0]) {
+    return SCFQ_EARG;
+  }
+  hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_hdr + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                     out_off.as<uint64_t>(), out_len.as<uint64_t>(), o);
+  DCHK(hipGetLastError());
+  DCHK(hipStreamSynchronize(stream));
+  if (!user_out) *d_out = static_cast<uint8_t*>(own.release());
   return SCFQ_OK;
 }
 
@@ -273,22 +300,25 @@ int scfq_dedup_buffer(const void* ptr, uint64_t n, int is_device, void* out, uin
   DevBuf staged;
   const uint8_t* d_in = static_cast<const uint8_t*>(ptr);
   if (!is_device && n) {
-    int rc = staged.alloc(n);
+    int rc = pool_keep_memory();
+    if (!rc) rc = staged.alloc(n, stream);
     if (rc) return rc;
-    DCHK(hipMemcpy(staged.p, ptr, n, hipMemcpyHostToDevice));
+    DCHK(hipMemcpyAsync(staged.p, ptr, n, hipMemcpyHostToDevice, stream));
+    DCHK(hipStreamSynchronize(stream));
     d_in = staged.as<uint8_t>();
   }
   uint8_t* d_out = nullptr;
   uint64_t nb = 0;
-  int rc = dedup_device(d_in, n, &d_out, &nb, st, stream);
-  if (rc) return rc;
+  // device destination: gather straight into the caller's buffer; host destination: gather into pool memory, copy down
+  const bool direct = out && out_is_device;
+  int rc = dedup_device(d_in, n, direct ? static_cast<uint8_t*>(out) : nullptr, direct ? out_cap : 0, /*sized_only=*/!out, &d_out, &nb, st, stream);
   *out_bytes = nb;
-  if (nb > out_cap || (!out && nb)) { if (d_out) (void)hipFree(d_out); return out ? SCFQ_EARG : SCFQ_OK; }   // caller sizes and calls again
-  if (nb) {
-    hipError_t e = hipMemcpy(out, d_out, nb, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
-    (void)hipFree(d_out);
-    if (e != hipSuccess) { std::snprintf(g_derr, sizeof g_derr, "copy of the result -> %s", hipGetErrorString(e)); return SCFQ_EHIP; }
-  }
+  if (rc) return rc;
+  if (!out || direct || nb == 0) { if (d_out) (void)hipFreeAsync(d_out, stream); return SCFQ_OK; }
+  struct OutGuard { void* p; hipStream_t s; ~OutGuard() { if (p) (void)hipFreeAsync(p, s); } } og{d_out, stream};
+  if (nb > out_cap) return SCFQ_EARG;      // caller sizes (out = NULL) and calls again
+  DCHK(hipMemcpyAsync(out, d_out, nb, hipMemcpyDeviceToHost, stream));
+  DCHK(hipStreamSynchronize(stream));
   return SCFQ_OK;
 }
 
@@ -307,9 +337,9 @@ int scfq_dedup_file(const char* path, const scfq_opts* opts, int out_fd, scfq_de
   struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
   uint8_t* d_out = nullptr;
   uint64_t nb = 0;
-  rc = dedup_device(static_cast<const uint8_t*>(d_in), n, &d_out, &nb, st, stream);
+  rc = dedup_device(static_cast<const uint8_t*>(d_in), n, nullptr, 0, /*sized_only=*/out_fd < 0, &d_out, &nb, st, stream);
   if (rc) return rc;
-  struct OutGuard { void* p; ~OutGuard() { if (p) (void)hipFree(p); } } og{d_out};
+  struct OutGuard { void* p; hipStream_t s; ~OutGuard() { if (p) (void)hipFreeAsync(p, s); } } og{d_out, stream};
   if (out_fd < 0 || nb == 0) return SCFQ_OK;
   // HBM -> two pinned buffers -> write(): the copy of chunk k+1 overlaps the write of chunk k
   const uint64_t chunk = 32ull << 20;
