@@ -176,6 +176,17 @@ const char* scfq_dedup_error_detail(void);
 int scfq_stage_file(const char* path, const scfq_opts* opts, void** device_ptr_out, uint64_t* n_out);
 int scfq_device_free(void* device_ptr);
 
+/* ---- `sc fq-meta` (next row of SURVEY.md §8f): src/fq_meta.nim:197-278 -------------------------
+ * One 16-column TSV row (scfq_meta_header() names them, fq_meta.nim:11-26) from the first sample_n records of a FASTQ:
+ * machine / flowcell / run / lane parsed from the first header, sequencer guess from the instrument and flow-cell tables,
+ * most frequent index, quality range and format guess. Host-side string work over a few hundred lines, as in the
+ * reference. SCFQ_META_WHOLE_FILE (addition): min_qual / max_qual and the format columns use the quality-line histogram
+ * of the whole file (K3 on the device) instead of the sampled records. Returns the row length (bytes needed excluding NUL)
+ * or a negative code; SCFQ_EARG also when the first header has too few ':' fields (IndexError in the reference). */
+#define SCFQ_META_WHOLE_FILE 0x1u
+const char* scfq_meta_header(void);
+int scfq_meta_file_tsv(const char* path, uint32_t sample_n, uint32_t flags, char* out, uint64_t cap);
+
 /* ---- formatting: src/fq_count.nim:47-51 ---------------------------------------------------
  * "<reads>\t<gc_content>\t<gc_bases>\t<n_bases>\t<bases>" without trailing newline;
  * gc_content = gc/(bases-n) as IEEE double printed the way Nim 1.0.6 `$float` does: C "%.16g",

@@ -125,7 +125,7 @@ static void help_top(FILE* f) {
   std::fprintf(f,
                "sc (%s) — MI355X-native host for the fq-count path of seq-collection\n\n"
                "Usage:\n  sc COMMAND\n\nCommands:\n\nFASTQ\n  fq-count         Counts lines in a FASTQ\n"
-               "  fq-dedup         Removes exact duplicates from FASTQ Files\n\n"
+               "  fq-dedup         Removes exact duplicates from FASTQ Files\n  fq-meta          Output metadata for FASTQ\n\n"
                "Options:\n  -h, --help                 Show this help\n  -v, --version              Show version\n"
                "      --debug                Debug mode\n",
                kVersion);
@@ -253,6 +253,48 @@ static int cmd_fq_dedup(const std::vector<std::string>& params) {
   return 0;
 }
 
+// command "fq-meta" (sc.nim:67-79): -n/--lines (default 100), -t/--header, -b/--basename, -a/--absolute, [fastq ...]
+static int cmd_fq_meta(const std::vector<std::string>& params) {
+  auto help = [](FILE* f) {
+    std::fputs("Output metadata for FASTQ\n\nUsage:\n  fq-meta [options] [fastq ...]\n\nArguments:\n  [fastq ...]      List of FASTQ files\n\n"
+               "Options:\n  -n, --lines=LINES          Number of sequences to sample (n_lines) for qual and index/barcode determination (default: 100)\n"
+               "  -t, --header               Output the header\n  -b, --basename             Add basename column\n"
+               "  -a, --absolute             Add column for absolute path\n  -h, --help                 Show this help\n"
+               "\nMI355X option (addition):\n      --whole-file           Quality range from the histogram of every quality line (device scan)\n", f);
+  };
+  bool header = false, basename = false, absolute = false;
+  uint32_t flags = 0;
+  std::string lines = "100";
+  std::vector<std::string> files;
+  for (size_t i = 1; i < params.size(); ++i) {
+    const std::string& a = params[i];
+    if (a == "-h" || a == "--help") { help(stdout); return 0; }
+    else if (a == "-t" || a == "--header") header = true;
+    else if (a == "-b" || a == "--basename") basename = true;
+    else if (a == "-a" || a == "--absolute") absolute = true;
+    else if (a == "--whole-file") flags |= SCFQ_META_WHOLE_FILE;
+    else if ((a == "-n" || a == "--lines") && i + 1 < params.size()) lines = params[++i];
+    else if (a.rfind("--lines=", 0) == 0) lines = a.substr(8);
+    else if (a.rfind("-n", 0) == 0 && a.size() > 2 && a[1] == 'n') lines = a.substr(a[2] == '=' ? 3 : 2);
+    else if (a.size() > 1 && a[0] == '-' && a != "-") { help(stdout); quit_error("Error: Unknown option: " + a, 1); }
+    else files.push_back(a);
+  }
+  char* endp = nullptr;
+  const long n = std::strtol(lines.c_str(), &endp, 10);
+  if (lines.empty() || *endp || n < 0) quit_error("invalid integer: " + lines, 1);      // parseInt raises ValueError (sc.nim:79)
+  if (header) std::printf("%s\n", output_header(scfq_meta_header(), basename, absolute).c_str());   // sc.nim:75-76
+  for (const auto& fastq : files) {                                                          // sc.nim:77-79
+    char row[4096];
+    const int rc = scfq_meta_file_tsv(fastq.c_str(), (uint32_t)n, flags, row, sizeof row);
+    if (rc == SCFQ_EOPEN) quit_error("Unable to open file: " + fastq, 2);                   // fq_meta.nim:223-224
+    if (rc == SCFQ_EARG) quit_error("index out of bounds", 1);                              // extract_read_info IndexError -> sc.nim:299-305
+    if (rc < 0) quit_error(std::string(scfq_strerror(rc)) + ": " + scfq_last_error_detail(), 1);
+    std::printf("%s\n", output_w_fnames(row, fastq, basename, absolute).c_str());
+  }
+  std::fflush(stdout);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   signal(SIGPIPE, SIG_IGN);   // sc.nim:45-46
   std::vector<std::string> params(argv + 1, argv + argc);
@@ -262,9 +304,10 @@ int main(int argc, char** argv) {
   if (params.empty() || params[0] == "-h" || params[0] == "--help") { help_top(stdout); return 0; }
   if (params[0] == "-v" || params[0] == "--version") { std::printf("%s\n", kVersion); return 0; }
   if (params[0] == "fq-dedup") return cmd_fq_dedup(params);
+  if (params[0] == "fq-meta") return cmd_fq_meta(params);
   if (params[0] != "fq-count") {
     help_top(stdout);
-    quit_error("Unknown command: " + params[0] + " (this build provides the fq-count and fq-dedup paths only)", 1);
+    quit_error("Unknown command: " + params[0] + " (this build provides the FASTQ commands only)", 1);
   }
   if (params.size() == 1) { help_fq_count(stdout); return 0; }   // sc.nim:288-290: len <= 1 -> "-h"
 

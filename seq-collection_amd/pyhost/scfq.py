@@ -32,7 +32,7 @@ EXPORTS = [
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
     "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
     "scfq_index_lines", "scfq_dedup_buffer", "scfq_dedup_file", "scfq_dedup_error_detail", "scfq_stage_file",
-    "scfq_device_free",
+    "scfq_device_free", "scfq_meta_header", "scfq_meta_file_tsv",
 ]
 
 
@@ -129,6 +129,8 @@ def lib():
         L.scfq_stage_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.POINTER(ctypes.c_uint64)]
         L.scfq_device_free.argtypes = [ctypes.c_void_p]
+        L.scfq_meta_header.restype = ctypes.c_char_p
+        L.scfq_meta_file_tsv.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64]
         L.scfq_index_lines.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64)]
         L.scfq_debug_stream_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
@@ -259,6 +261,20 @@ def dedup_file(path, out_fd=-1):
     st = _new_dedup_stats()
     _check(lib().scfq_dedup_file(os.fsencode(path), None, out_fd, ctypes.byref(st)), "scfq_dedup_file")
     return st
+
+
+SCFQ_META_WHOLE_FILE = 0x1
+
+
+def meta_header():
+    return lib().scfq_meta_header().decode()
+
+
+def meta_file_tsv(path, sample_n=100, flags=0):
+    """the 16-column fq-meta row of `path` (reference: src/fq_meta.nim:197-278)"""
+    buf = ctypes.create_string_buffer(4096)
+    _check(min(0, lib().scfq_meta_file_tsv(os.fsencode(path), sample_n, flags, buf, 4096)), "scfq_meta_file_tsv")
+    return buf.value.decode()
 
 
 def hist_stats():

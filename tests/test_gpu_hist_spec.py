@@ -169,3 +169,16 @@ def test_streaming_chunks_and_files(gpu, scfq, oracle, tmp_path):
     if gpu.cuda.device_count() >= 1:
         c = scfq.count_host(a, devices=[0, 0], flags=scfq.SCFQ_QUAL_HIST, chunk_bytes=1 << 18)    # two shards on one device
         assert list(c.qual_hist) == list(oc.qual_hist)
+
+
+def test_fq_meta_whole_file_quality_range(gpu, scfq):
+    """SCFQ_META_WHOLE_FILE: min_qual / max_qual from K3's histogram of every quality line == the sampled loop over all records"""
+    import os
+    from conftest import GOLDEN
+    for name in ("novaseq.fq", "illumina_3.fq", "sra.fq", "dup.fq.gz", "illumina_8.fq"):
+        path = os.path.join(GOLDEN, name)
+        full = scfq.meta_file_tsv(path, sample_n=1000).split("\t")
+        first = scfq.meta_file_tsv(path, sample_n=1).split("\t")
+        whole = scfq.meta_file_tsv(path, sample_n=1, flags=scfq.SCFQ_META_WHOLE_FILE).split("\t")
+        assert whole[10:15] == full[10:15], name              # quality columns of the whole file
+        assert whole[:10] == first[:10] and whole[15] == "1", name   # everything else still from the first record
