@@ -36,6 +36,7 @@ def main():
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
+    print("rep times ms:", [round(t * 1e3, 1) for t in times], file=sys.stderr)
     # generator IDs (lane:tile:x:y) can repeat by chance: the exact duplicate count comes from the pipeline itself and is
     # checked against the oracle on the sample below; the copies appended above are a lower bound
     assert st.duplicates >= dup_plan.records and st.total_reads == plan.records + dup_plan.records
