@@ -11,8 +11,10 @@
 #include "../../include/sc_fqcount.h"
 #include "fq_scan_kernels.hpp"
 #include "scfq_bgzf.hpp"
+#include "scfq_gzfast.hpp"
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -483,6 +485,37 @@ struct GzSource : Source {
   }
 };
 
+// Regular gzip files: the library's own inflate (scfq_inflate.hpp) on a decoder thread, CRC + copy on this one; same
+// bytes and the same accept / reject decisions as gzread.  SCFQ_INFLATE=zlib keeps everything on zlib.
+struct FastGzSource : Source {
+  scfq_gzfast::Stream st;
+  int64_t fill(uint8_t* dst, uint64_t cap) override {
+    const int64_t r = st.next_chunk(dst, cap);
+    return r < 0 ? (int64_t)SCFQ_EGZ : r;
+  }
+};
+
+bool use_own_inflate() {
+  static const bool v = [] { const char* e = std::getenv("SCFQ_INFLATE"); return !(e && e[0] == 'z'); }();
+  return v;
+}
+
+// the source for a ".gz" path that is not BGZF: own decoder when the file is a mappable regular file that starts with a
+// gzip member and the staging chunk is big enough for the decoder's write slack, zlib otherwise (transparent
+// pass-through of non-gzip bytes, FIFOs, tiny chunks)
+std::unique_ptr<Source> open_gz_source(const char* path, uint64_t chunk, gzFile* gz_out) {
+  *gz_out = nullptr;
+  if (use_own_inflate() && chunk >= (1u << 16)) {
+    auto f = std::make_unique<FastGzSource>();
+    if (f->st.open(path)) return f;
+  }
+  gzFile gz = gzopen(path, "rb");
+  if (!gz) return nullptr;
+  gzbuffer(gz, 1u << 20);
+  *gz_out = gz;
+  return std::make_unique<GzSource>(gz);
+}
+
 // BGZF input: block-parallel inflate straight into the pinned chunk (same bytes as gzread would produce).
 struct BgzfSource : Source {
   int fd;
@@ -491,8 +524,12 @@ struct BgzfSource : Source {
   uint64_t carry_off = 0;
   gzFile fallback = nullptr;   // serial zlib from the first non-BGZF member on
   bool done = false;
-  BgzfSource(int fd_, uint64_t size) : fd(fd_), fsize(size) {}
-  ~BgzfSource() override { if (fallback) gzclose(fallback); }
+  const uint8_t* map = nullptr;   // the compressed file, mapped: block headers are parsed and blocks inflated in place
+  BgzfSource(int fd_, uint64_t size) : fd(fd_), fsize(size) {
+    void* m = size ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd_, 0) : MAP_FAILED;
+    if (m != MAP_FAILED) { map = static_cast<const uint8_t*>(m); (void)madvise(m, size, MADV_SEQUENTIAL); }
+  }
+  ~BgzfSource() override { if (fallback) gzclose(fallback); if (map) munmap(const_cast<uint8_t*>(map), fsize); }
 
   int64_t serial_fill(uint8_t* dst, uint64_t cap) {
     uint64_t got = 0;
@@ -517,24 +554,31 @@ struct BgzfSource : Source {
     // compressed window: BGZF blocks are <= 64 KiB in and out, so `cap` compressed bytes cover >= `cap` output in
     // all but pathological (stored) cases; a short window only means a shorter chunk
     const uint64_t want = std::min<uint64_t>(fsize - pos, std::max<uint64_t>(cap, 1u << 20));
-    cbuf.resize(want);
     uint64_t avail = 0;
-    while (avail < want) {
-      ssize_t r = pread(fd, cbuf.data() + avail, want - avail, (off_t)(pos + avail));
-      if (r < 0) return SCFQ_EIO;
-      if (r == 0) break;
-      avail += (uint64_t)r;
+    const uint8_t* cb;
+    if (map) {
+      cb = map + pos;
+      avail = want;
+    } else {      // not mappable: copy the window out of the file
+      cbuf.resize(want);
+      while (avail < want) {
+        ssize_t r = pread(fd, cbuf.data() + avail, want - avail, (off_t)(pos + avail));
+        if (r < 0) return SCFQ_EIO;
+        if (r == 0) break;
+        avail += (uint64_t)r;
+      }
+      cb = cbuf.data();
     }
     std::vector<scfq_bgzf::Block> blocks;
     uint64_t p = 0, out = 0;
     bool to_serial = false;
     while (p < avail) {
       uint32_t hl = 0;
-      const uint32_t bs = scfq_bgzf::block_size(cbuf.data() + p, avail - p, &hl);
+      const uint32_t bs = scfq_bgzf::block_size(cb + p, avail - p, &hl);
       if (!bs) {
         const bool tail_short = (avail - p < 18) && (pos + avail < fsize);
         if (tail_short) break;                                   // header split by the window: next fill
-        if (avail - p >= 2 && cbuf[p] == 0x1f && cbuf[p + 1] == 0x8b) to_serial = true;   // ordinary gzip member
+        if (avail - p >= 2 && cb[p] == 0x1f && cb[p + 1] == 0x8b) to_serial = true;   // ordinary gzip member
         else done = true;                                        // trailing garbage after a gzip stream: ignored, as zlib does
         break;
       }
@@ -542,19 +586,19 @@ struct BgzfSource : Source {
         if (pos + avail >= fsize) return SCFQ_EGZ;               // truncated final block
         break;                                                   // block split by the window: next fill
       }
-      const uint32_t isize = scfq_bgzf::rd32(cbuf.data() + p + bs - 4);
+      const uint32_t isize = scfq_bgzf::rd32(cb + p + bs - 4);
       if (out + isize > cap) {
         if (!blocks.empty()) break;
         // a single block larger than the chunk: inflate it aside and serve it in pieces
-        std::vector<scfq_bgzf::Block> one{{p, bs, hl, isize, scfq_bgzf::rd32(cbuf.data() + p + bs - 8), 0}};
+        std::vector<scfq_bgzf::Block> one{{p, bs, hl, isize, scfq_bgzf::rd32(cb + p + bs - 8), 0}};
         carry.assign(isize, 0);
-        if (scfq_bgzf::inflate_blocks(cbuf.data(), one, 0, 1, carry.data())) return SCFQ_EGZ;
+        if (scfq_bgzf::inflate_blocks(cb, one, 0, 1, carry.data())) return SCFQ_EGZ;
         pos += p + bs;
         carry_off = std::min<uint64_t>(cap, carry.size());
         std::memcpy(dst, carry.data(), carry_off);
         return (int64_t)carry_off;
       }
-      blocks.push_back({p, bs, hl, isize, scfq_bgzf::rd32(cbuf.data() + p + bs - 8), out});
+      blocks.push_back({p, bs, hl, isize, scfq_bgzf::rd32(cb + p + bs - 8), out});
       out += isize;
       p += bs;
     }
@@ -565,8 +609,8 @@ struct BgzfSource : Source {
       std::vector<int> rcs(nt, 0);
       std::vector<std::thread> th;
       for (int t = 1; t < nt; ++t)
-        th.emplace_back([&, t] { rcs[t] = scfq_bgzf::inflate_blocks(cbuf.data(), blocks, blocks.size() * t / nt, blocks.size() * (t + 1) / nt, dst); });
-      rcs[0] = scfq_bgzf::inflate_blocks(cbuf.data(), blocks, 0, blocks.size() / nt, dst);
+        th.emplace_back([&, t] { rcs[t] = scfq_bgzf::inflate_blocks(cb, blocks, blocks.size() * t / nt, blocks.size() * (t + 1) / nt, dst); });
+      rcs[0] = scfq_bgzf::inflate_blocks(cb, blocks, 0, blocks.size() / nt, dst);
       for (auto& x : th) x.join();
       for (int r : rcs) if (r) return SCFQ_EGZ;
     }
@@ -791,19 +835,16 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
       }
       if (bfd >= 0) close(bfd);
     }
-    gzFile f = gzopen(path, "rb");
-    if (!f) return SCFQ_EOPEN;
-    gzbuffer(f, 1u << 20);
-    if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { gzclose(f); return SCFQ_EHIP; }
+    gzFile f = nullptr;
+    std::unique_ptr<Source> gsrc = open_gz_source(path, opt_chunk(&o), &f);
+    if (!gsrc) return SCFQ_EOPEN;
+    struct GzCloser { gzFile* f; std::unique_ptr<Source>* s; ~GzCloser() { s->reset(); if (*f) gzclose(*f); } } gzc{&f, &gsrc};
+    if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) return SCFQ_EHIP;
     Ctx* c = nullptr;
     SessionLock sl;
     rc = get_ctx(&c, sl);
     if (!rc) rc = begin_session(c, true);
-    if (!rc) {
-      GzSource src(f);
-      rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
-    }
-    gzclose(f);
+    if (!rc) rc = ingest(c, *gsrc, -1, o.flags, opt_chunk(&o), timing);
     if (rc) return rc;
     rc = end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
     if (rc) return rc;
@@ -937,10 +978,8 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
     } else {
       if (fd >= 0) close(fd);
       fd = -1;
-      gz = gzopen(path, "rb");
-      if (!gz) return SCFQ_EOPEN;
-      gzbuffer(gz, 1u << 20);
-      src.reset(new GzSource(gz));
+      src = open_gz_source(path, opt_chunk(opts), &gz);
+      if (!src) return SCFQ_EOPEN;
     }
   } else {
     fd = open(path, O_RDONLY);
@@ -1065,9 +1104,8 @@ int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t
     } else {
       if (fd >= 0) close(fd);
       fd = -1;
-      gz = gzopen(path, "rb");
-      if (!gz) return SCFQ_EOPEN;
-      src.reset(new GzSource(gz));
+      src = open_gz_source(path, chunk, &gz);
+      if (!src) return SCFQ_EOPEN;
     }
   } else {
     fd = open(path, O_RDONLY);

@@ -11,9 +11,13 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "scfq_inflate.hpp"
+
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -49,7 +53,32 @@ inline bool probe(int fd) {
 struct Block { uint64_t in_off; uint32_t in_len, hdr_len, isize, crc; uint64_t out_off; };
 
 // Inflate blocks[lo,hi) from cbuf into dst. Returns 0 or -1 (corrupt block / CRC / length mismatch).
+// Default: the library's own decoder (scfq_inflate.hpp) into a thread-local scratch (its fast loop writes a little past
+// the end of what it produces, and the neighbouring block's bytes belong to another thread), then one memcpy.
+// SCFQ_INFLATE=zlib, or a block that claims more than 64 KiB, takes the zlib path below.
+inline int inflate_blocks_zlib(const uint8_t* cbuf, const std::vector<Block>& blocks, size_t lo, size_t hi, uint8_t* dst);
+
 inline int inflate_blocks(const uint8_t* cbuf, const std::vector<Block>& blocks, size_t lo, size_t hi, uint8_t* dst) {
+  static const bool own = [] { const char* e = std::getenv("SCFQ_INFLATE"); return !(e && e[0] == 'z'); }();
+  if (!own) return inflate_blocks_zlib(cbuf, blocks, lo, hi, dst);
+  constexpr uint32_t kMaxBlock = 1u << 16;
+  std::vector<uint8_t> scratch(kMaxBlock + 2 * scfq_inflate::kOutSlack);
+  auto dec = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
+  for (size_t i = lo; i < hi; ++i) {
+    const Block& b = blocks[i];
+    if (b.isize > kMaxBlock) { if (inflate_blocks_zlib(cbuf, blocks, i, i + 1, dst)) return -1; continue; }
+    const uint8_t* in = cbuf + b.in_off + b.hdr_len;
+    dec->begin(in, in + (b.in_len - b.hdr_len - 8));
+    uint8_t* out = scratch.data();
+    const int r = dec->run(out, scratch.data() + scratch.size());
+    if (r != scfq_inflate::kStreamEnd || (uint32_t)(out - scratch.data()) != b.isize) return -1;
+    if ((uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), scratch.data(), b.isize) != b.crc) return -1;
+    std::memcpy(dst + b.out_off, scratch.data(), b.isize);
+  }
+  return 0;
+}
+
+inline int inflate_blocks_zlib(const uint8_t* cbuf, const std::vector<Block>& blocks, size_t lo, size_t hi, uint8_t* dst) {
   z_stream zs;
   std::memset(&zs, 0, sizeof zs);
   if (inflateInit2(&zs, -15) != Z_OK) return -1;
