@@ -14,7 +14,7 @@
 //   D4  dd_record_lengths     bytes each kept record echoes: for each of its lines, text + '\n' ("\r\n" comes out as "\n",
 //                             a final line without '\n' gains one: `echo record`, fq_dedup.nim:59,67,71)
 //   D5  exclusive scan        output offset of every kept record (hipCUB)
-//   D6  dd_gather             one wave per record copies its lines to the output buffer
+//   D6  dd_gather             one wave per 32 records: one contiguous 16 B/lane copy when the group is kept verbatim
 // Everything is integer / byte work bound by HBM traffic; there is no CPU fallback.
 #include "../../include/sc_fqcount.h"
 
@@ -24,6 +24,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,23 +86,42 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x;
 }
 
-// D1: one thread per header line; 8 bytes per step (unaligned 64-bit loads are fine on gfx9 global memory), tail bytewise
+// The first 64 bytes of a header as eight 64-bit words, bytes past the header zeroed.  All eight loads are issued before
+// any is used (one memory round trip instead of eight dependent ones: these kernels are latency-bound, every thread
+// chases its own header); addresses are clamped to stay inside the input.
+__device__ __forceinline__ void load_head64(const uint8_t* base, uint64_t n, uint64_t s, uint64_t len, uint64_t w[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint64_t a = s + 8u * k;
+    uint32_t shift = 0;
+    if (a + 8 > n) { const uint64_t a2 = (n >= 8) ? n - 8 : 0; shift = (uint32_t)(a - a2) * 8; a = a2; }   // last bytes of the input
+    uint64_t v = 0;
+    if (8u * k < len && n >= 8) { __builtin_memcpy(&v, base + a, 8); v = (shift < 64) ? (v >> shift) : 0; }
+    else if (8u * k < len) { for (uint64_t b = 0; b < 8 && a + b < n; ++b) v |= (uint64_t)base[a + b] << (8 * b); }
+    const uint64_t valid = (len > 8u * k) ? len - 8u * k : 0;          // bytes of this word that belong to the header
+    w[k] = (valid >= 8) ? v : (valid ? (v & ((1ull << (8 * valid)) - 1)) : 0);
+  }
+}
+
+// D1: one thread per header line
 __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
                                                       uint64_t seed, uint32_t hash_bits, uint64_t* keys, uint32_t* idx) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_hdr) return;
   uint64_t s, e;
   line_span(base, n, line_off, 4 * i, s, e);
-  uint64_t h = seed ^ ((e - s) * 0x9E3779B97F4A7C15ull);
-  uint64_t p = s;
-  for (; p + 8 <= e; p += 8) {
-    uint64_t w;
-    __builtin_memcpy(&w, base + p, 8);
-    h = mix64(h ^ w) + 0x9E3779B97F4A7C15ull;
+  const uint64_t len = e - s;
+  uint64_t h = seed ^ (len * 0x9E3779B97F4A7C15ull);
+  uint64_t w[8];
+  load_head64(base, n, s, len, w);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) h = mix64(h ^ w[k]) + 0x9E3779B97F4A7C15ull;
+  for (uint64_t p = s + 64; p < e; p += 8) {         // headers longer than 64 bytes: the rest, 8 bytes per step
+    uint64_t v = 0;
+    if (p + 8 <= e) __builtin_memcpy(&v, base + p, 8);
+    else for (uint64_t b = 0; p + b < e; ++b) v |= (uint64_t)base[p + b] << (8 * b);
+    h = mix64(h ^ v) + 0x9E3779B97F4A7C15ull;
   }
-  uint64_t tail = 0;
-  for (int k = 0; p < e; ++p, ++k) tail |= (uint64_t)base[p] << (8 * k);
-  h = mix64(h ^ tail);
   if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // test hook: forces collisions
   keys[i] = h;
   idx[i] = (uint32_t)i;
@@ -113,14 +133,14 @@ __device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, con
   line_span(base, n, line_off, 4 * rb, sb, eb);
   if (ea - sa != eb - sb) return false;
   const uint64_t len = ea - sa;
-  uint64_t k = 0;
-  for (; k + 8 <= len; k += 8) {
-    uint64_t x, y;
-    __builtin_memcpy(&x, base + sa + k, 8);
-    __builtin_memcpy(&y, base + sb + k, 8);
-    if (x != y) return false;
-  }
-  for (; k < len; ++k)
+  uint64_t wa[8], wb[8];
+  load_head64(base, n, sa, len, wa);
+  load_head64(base, n, sb, len, wb);
+  uint64_t diff = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) diff |= wa[k] ^ wb[k];
+  if (diff) return false;
+  for (uint64_t k = 64; k < len; ++k)
     if (base[sa + k] != base[sb + k]) return false;
   return true;
 }
@@ -140,8 +160,10 @@ __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, u
     if (same_header(base, n, line_off, idx_sorted[q - 1], me)) { is_dup = true; break; }
     ++collided;
   }
-  dup[me] = is_dup ? 1 : 0;
-  if (is_dup) atomicAdd(&counters[0], 1ull);
+  if (is_dup) {                       // dup[] was zeroed: only the duplicates pay a scattered byte store
+    dup[me] = 1;
+    atomicAdd(&counters[0], 1ull);
+  }
   if (collided) atomicAdd(&counters[1], (unsigned long long)collided);
 }
 
@@ -161,40 +183,52 @@ __global__ __launch_bounds__(256) void dd_record_lengths(const uint8_t* base, ui
   out_len[i] = total;
 }
 
-// D6: one wave per record.  Fast path (every line of the record ends in a plain '\n' inside the input): the record's
-// output is its input bytes verbatim, copied 16 bytes per lane once the destination is aligned.  Otherwise line by line.
+// D6: one wave per group of kGatherGroup consecutive records.  When the whole group is kept and echoed verbatim (same
+// number of bytes in and out: no '\r' stripped, no '\n' added, nothing dropped) it is ONE contiguous copy of ~11 KB,
+// 16 bytes per lane per step; a group that is dropped entirely costs two loads.  Mixed groups go record by record, a
+// record that is not verbatim line by line.
+constexpr uint64_t kGatherGroup = 32;
+
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint64_t len, uint32_t lane) {
+  uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+  if (head > len) head = len;
+  if (lane < head) dst[lane] = src[lane];
+  const uint64_t body = (len - head) / 16;
+  for (uint64_t k = lane; k < body; k += 64) {
+    uint4 v;
+    __builtin_memcpy(&v, src + head + k * 16, 16);       // the source is arbitrarily aligned
+    *reinterpret_cast<uint4*>(dst + head + k * 16) = v;
+  }
+  for (uint64_t k = head + body * 16 + lane; k < len; k += 64) dst[k] = src[k];
+}
+
 __global__ __launch_bounds__(256) void dd_gather(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
                                                 uint64_t n_hdr, const uint64_t* out_off, const uint64_t* out_len, uint8_t* out) {
-  const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
-  if (i >= n_hdr) return;
-  const uint64_t len = out_len[i];
-  if (!len) return;
-  uint8_t* dst = out + out_off[i];
-  const uint64_t j0 = 4 * i, j1 = (j0 + 4 < lines) ? j0 + 4 : lines;
-  const uint64_t s0 = line_off[j0], s1 = line_off[j1];
-  if (s1 - s0 == len && s1 <= n) {
-    // verbatim: same number of bytes in and out means no '\r' was stripped and no '\n' was added
-    const uint8_t* src = base + s0;
-    uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
-    if (head > len) head = len;
-    if (lane < head) dst[lane] = src[lane];
-    const uint64_t body = (len - head) / 16;
-    for (uint64_t k = lane; k < body; k += 64) {
-      uint4 v;
-      __builtin_memcpy(&v, src + head + k * 16, 16);       // source is arbitrarily aligned
-      *reinterpret_cast<uint4*>(dst + head + k * 16) = v;
+  const uint64_t i0 = g * kGatherGroup;
+  if (i0 >= n_hdr) return;
+  const uint64_t i1 = (i0 + kGatherGroup < n_hdr) ? i0 + kGatherGroup : n_hdr;
+  const uint64_t o0 = out_off[i0], o1 = out_off[i1];          // out_off has n_hdr + 1 entries
+  if (o1 == o0) return;                                       // every record of the group was dropped
+  const uint64_t jl = (4 * i1 < lines) ? 4 * i1 : lines;
+  const uint64_t s0 = line_off[4 * i0], s1 = line_off[jl];
+  if (s1 - s0 == o1 - o0 && s1 <= n) { wave_copy(out + o0, base + s0, o1 - o0, lane); return; }
+  for (uint64_t i = i0; i < i1; ++i) {
+    const uint64_t len = out_len[i];
+    if (!len) continue;
+    uint8_t* dst = out + out_off[i];
+    const uint64_t j0 = 4 * i, j1 = (j0 + 4 < lines) ? j0 + 4 : lines;
+    const uint64_t r0 = line_off[j0], r1 = line_off[j1];
+    if (r1 - r0 == len && r1 <= n) { wave_copy(dst, base + r0, len, lane); continue; }
+    uint64_t w = 0;
+    for (uint64_t j = j0; j < j1; ++j) {
+      uint64_t s, e;
+      line_span(base, n, line_off, j, s, e);
+      for (uint64_t k = lane; k < e - s; k += 64) dst[w + k] = base[s + k];
+      if (lane == 0) dst[w + (e - s)] = '\n';
+      w += e - s + 1;
     }
-    for (uint64_t k = head + body * 16 + lane; k < len; k += 64) dst[k] = src[k];
-    return;
-  }
-  uint64_t w = 0;
-  for (uint64_t j = j0; j < j1; ++j) {
-    uint64_t s, e;
-    line_span(base, n, line_off, j, s, e);
-    for (uint64_t k = lane; k < e - s; k += 64) dst[w + k] = base[s + k];
-    if (lane == 0) dst[w + (e - s)] = '\n';
-    w += e - s + 1;
   }
 }
 
@@ -205,10 +239,21 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   *d_out = nullptr;
   *out_bytes = 0;
   uint64_t lines = 0;
+  // SCFQ_DEDUP_TRACE=1: host-clock stage times on stderr (each mark synchronises the stream: diagnostic only)
+  static const bool trace = std::getenv("SCFQ_DEDUP_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(stream);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "scfq dedup: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   int rc = pool_keep_memory();
   if (rc) return rc;
   rc = scfq_index_lines(d_in, n, nullptr, 0, &lines);
   if (rc) return rc;
+  mark("count lines (K1 + K2)");
   st->total_reads = lines / 4;                       // n_reads = i div 4      src/fq_dedup.nim:49
   const uint64_t n_hdr = (lines + 3) / 4;            // header lines: 0-based index i mod 4 == 0 (:43,57)
   if (n_hdr >= (1ull << 31)) { std::snprintf(g_derr, sizeof g_derr, "more than 2^31 records in one input"); return SCFQ_EARG; }
@@ -216,18 +261,22 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp;
   if ((rc = line_off.alloc((lines + 1) * 8, stream))) return rc;
   DCHK(hipStreamSynchronize(stream));       // scfq_index_lines works on the library's own stream
+  mark("alloc line index");
   rc = scfq_index_lines(d_in, n, line_off.as<uint64_t>(), lines + 1, &lines);
   if (rc) return rc;
+  mark("line index (K1 + K2 + K5)");
   if ((rc = keys.alloc(n_hdr * 8, stream)) || (rc = keys2.alloc(n_hdr * 8, stream)) || (rc = idx.alloc(n_hdr * 4, stream)) ||
       (rc = idx2.alloc(n_hdr * 4, stream)) || (rc = dup.alloc(n_hdr, stream)) || (rc = out_len.alloc((n_hdr + 1) * 8, stream)) ||
       (rc = out_off.alloc((n_hdr + 1) * 8, stream)) || (rc = counters.alloc(16, stream)))
     return rc;
+  mark("alloc scratch");
   DCHK(hipMemsetAsync(counters.p, 0, 16, stream));
   const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
   static const uint32_t hash_bits = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); int v = e ? std::atoi(e) : 64; return (uint32_t)std::min(64, std::max(1, v)); }();
   hipLaunchKernelGGL(dd_hash_headers, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
                      0x5CF0DED0B1A5ull, hash_bits, keys.as<uint64_t>(), idx.as<uint32_t>());
   DCHK(hipGetLastError());
+  mark("hash headers");
   size_t tmp_bytes = 0;
   DCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(),
                                           idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
@@ -236,9 +285,12 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   if ((rc = tmp.alloc(std::max(tmp_bytes, scan_bytes), stream))) return rc;
   DCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(),
                                           idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
+  mark("radix sort");
+  DCHK(hipMemsetAsync(dup.p, 0, n_hdr, stream));
   hipLaunchKernelGGL(dd_mark_duplicates, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
                      keys2.as<uint64_t>(), idx2.as<uint32_t>(), dup.as<uint8_t>(), counters.as<unsigned long long>());
   DCHK(hipGetLastError());
+  mark("mark duplicates");
   hipLaunchKernelGGL(dd_record_lengths, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
                      dup.as<uint8_t>(), out_len.as<uint64_t>());
   DCHK(hipGetLastError());
@@ -248,6 +300,7 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   DCHK(hipMemcpyAsync(&h[0], out_off.as<uint64_t>() + n_hdr, 8, hipMemcpyDeviceToHost, stream));
   DCHK(hipMemcpyAsync(&h[1], counters.p, 16, hipMemcpyDeviceToHost, stream));
   DCHK(hipStreamSynchronize(stream));
+  mark("lengths + scan + readback");
   st->duplicates = h[1];
   st->hash_collisions = h[2];
   st->records_out = n_hdr - h[1];
@@ -263,10 +316,12 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   } else if (user_cap < h[0]) {
     return SCFQ_EARG;
   }
-  hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_hdr + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+  const uint64_t n_groups = (n_hdr + kGatherGroup - 1) / kGatherGroup;
+  hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
                      out_off.as<uint64_t>(), out_len.as<uint64_t>(), o);
   DCHK(hipGetLastError());
   DCHK(hipStreamSynchronize(stream));
+  mark("gather");
   if (!user_out) *d_out = static_cast<uint8_t*>(own.release());
   return SCFQ_OK;
 }

@@ -125,3 +125,43 @@ def test_header_is_plain_c_and_example_builds(tmp_path):
     if torch.cuda.is_available():
         r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "sra.fq"), "5"], capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout == "2\t0.4305555555555556\t62\t0\t144\n"
+
+
+def test_hist_class_algebra(scfq):
+    """scfq_partial.hist_class through combine / finalize (host code): which class histograms of a combined partial are
+    complete when the shards came from the speculative K3 form (0 = all four, k+1 = only class k, 5 = none)"""
+    def shard(nl, hist_class, bytes_=100):
+        p = scfq.identity()
+        p.nl, p.bytes, p.hist_class, p.last_byte = nl, bytes_, hist_class, 10
+        return p
+
+    h = (ctypes.c_uint64 * scfq.HIST_WORDS)()
+    # complete + complete stays complete; the identity takes over the other side's restriction
+    acc = scfq.identity()
+    scfq.combine(acc, shard(7, 0))
+    scfq.combine(acc, shard(3, 0))
+    assert acc.hist_class == 0
+    # a shard restricted to class k lands on class (k + nl_before) & 3 of the result
+    for nl_before in range(8):
+        for k in range(4):
+            acc = scfq.identity()
+            scfq.combine(acc, shard(nl_before, 0))
+            scfq.combine(acc, shard(5, k + 1))
+            assert acc.hist_class == ((k + nl_before) & 3) + 1, (nl_before, k)
+    # two restricted shards that agree (after rotation) stay restricted, two that disagree leave nothing valid
+    acc = scfq.identity()
+    scfq.combine(acc, shard(6, 4))           # class 3 of the result
+    scfq.combine(acc, shard(2, 2))           # class 1 of the shard -> (1 + 6) & 3 = 3: agrees
+    assert acc.hist_class == 4
+    assert scfq.finalize(acc, h).reads >= 0  # class 3 is the quality class: finalize accepts
+    scfq.combine(acc, shard(1, 1))           # class 0 of the shard -> (0 + 8) & 3 = 0: disagrees
+    assert acc.hist_class == 5
+    with pytest.raises(scfq.ScfqError) as e:
+        scfq.finalize(acc, h)
+    assert e.value.rc == scfq.SCFQ_ESPEC
+    scfq.finalize(acc)                       # without a histogram the counters finalize as always
+    # a restriction to a class other than 3 cannot serve the quality histogram either
+    acc = scfq.identity()
+    scfq.combine(acc, shard(4, 2))
+    with pytest.raises(scfq.ScfqError):
+        scfq.finalize(acc, h)
