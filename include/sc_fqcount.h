@@ -209,6 +209,10 @@ int  scfq_debug_partial_simple(const void* device_ptr, uint64_t n, int prev_byte
 /* Diagnostic only: the byte stream scfq_count_file() would scan for `path` (plain pread, BGZF block-parallel
  * inflate, or serial gzread), produced on the host without any device. Returns bytes written or a negative code. */
 int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk_bytes);
+/* Diagnostic only: inflate a whole BGZF image (host memory) with the device-side inflate kernel, result to host memory.
+ * Returns the inflated size, SCFQ_EARG when the image is not pure BGZF or does not fit into cap, SCFQ_EGZ for a corrupt
+ * member (deflate data, ISIZE or CRC-32). */
+int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64_t cap);
 /* Diagnostic only: milliseconds (best of `reps`) the scan kernel's LOAD STRUCTURE alone (same ranges, same non-temporal
  * LDS-DMA ring, no classification / accounting) needs for the whole tiles of a 4 KiB-aligned device buffer: the
  * practical read-stream ceiling on this device, reported next to the roofline by bench.py. Negative on error. */

@@ -12,6 +12,7 @@
 #include "fq_scan_kernels.hpp"
 #include "scfq_bgzf.hpp"
 #include "scfq_gzfast.hpp"
+#include "bgzf_inflate_kernel.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -1030,6 +1031,83 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
 int scfq_device_free(void* dptr) {
   if (dptr) HIPCHK(hipFree(dptr));
   return SCFQ_OK;
+}
+
+// ---- device-side BGZF inflate ---------------------------------------------------------------------------------------
+// Walks the members of a BGZF image on the host (header fields only): fills the block table for the members whose
+// inflated bytes fit into out_cap, starting at byte `pos`.  Returns the number of bytes consumed, 0 at the end of the
+// image (or at a clean end-of-file marker run), -1 when the bytes at pos are not a BGZF member (caller falls back to the
+// host path) and -2 for a truncated member.
+static int64_t bgzf_plan(const uint8_t* img, uint64_t n, uint64_t pos, uint64_t out_cap, uint64_t comp_cap,
+                         std::vector<scfq_dinflate::Block>* blocks, uint64_t* out_bytes) {
+  blocks->clear();
+  uint64_t p = pos, out = 0;
+  while (p < n) {
+    uint32_t hl = 0;
+    const uint32_t bs = scfq_bgzf::block_size(img + p, n - p, &hl);
+    if (!bs) { if (p == pos) return -1; break; }        // something else follows: this chunk ends here, the next call reports it
+    if (p + bs > n) return -2;
+    const uint32_t isize = scfq_bgzf::rd32(img + p + bs - 4);
+    if (isize > (1u << 16)) { if (p == pos) return -1; break; }
+    if (out + isize > out_cap || (p + bs - pos) > comp_cap) break;
+    scfq_dinflate::Block b;
+    b.in_off = (uint32_t)(p - pos + hl);
+    b.in_len = bs - hl - 8;
+    b.out_off = (uint32_t)out;
+    b.isize = isize;
+    b.crc = scfq_bgzf::rd32(img + p + bs - 8);
+    blocks->push_back(b);
+    out += isize;
+    p += bs;
+  }
+  *out_bytes = out;
+  return (int64_t)(p - pos);
+}
+
+// Diagnostic / test entry: inflate a whole BGZF image (host memory) on the device, result to host memory.
+// Returns the inflated size, SCFQ_EARG when the image is not pure BGZF or does not fit, SCFQ_EGZ for a corrupt member.
+int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64_t cap) {
+  if ((!image && n) || (!out && cap)) return SCFQ_EARG;
+  Ctx* c = nullptr;
+  SessionLock sl;
+  int rc = get_ctx(&c, sl);
+  if (rc) return rc;
+  const uint8_t* img = static_cast<const uint8_t*>(image);
+  std::vector<scfq_dinflate::Block> blocks;
+  uint64_t total = 0, pos = 0;
+  uint8_t *d_comp = nullptr, *d_out = nullptr;
+  scfq_dinflate::Block* d_blocks = nullptr;
+  uint32_t* d_status = nullptr;
+  const uint64_t kChunk = 64ull << 20;
+  HIPCHK(hipMalloc(&d_comp, kChunk + 64));
+  HIPCHK(hipMalloc(&d_out, kChunk));
+  HIPCHK(hipMalloc(&d_blocks, (kChunk / 64 + 16) * sizeof(scfq_dinflate::Block)));
+  HIPCHK(hipMalloc(&d_status, 4));
+  struct Free { uint8_t* a; uint8_t* b; void* c; void* d; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } fr{d_comp, d_out, d_blocks, d_status};
+  HIPCHK(hipMemsetAsync(d_status, 0, 4, c->compute));
+  while (pos < n) {
+    uint64_t ob = 0;
+    const int64_t used = bgzf_plan(img, n, pos, kChunk, kChunk, &blocks, &ob);
+    if (used == -2) return SCFQ_EGZ;
+    if (used < 0 || blocks.size() > kChunk / 64) return SCFQ_EARG;
+    if (used == 0) break;
+    if (total + ob > cap) return SCFQ_EARG;
+    HIPCHK(hipMemcpyAsync(d_comp, img + pos, (size_t)used, hipMemcpyHostToDevice, c->compute));
+    HIPCHK(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->compute));
+    const unsigned nb = (unsigned)blocks.size();
+    hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
+                       dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsHalfwords * 2, c->compute,
+                       d_comp, d_blocks, nb, d_out, d_status);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(out) + total, d_out, (size_t)ob, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    total += ob;
+    pos += (uint64_t)used;
+  }
+  uint32_t st = 0;
+  HIPCHK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
+  if (st) { std::snprintf(g_err, sizeof g_err, "device inflate: error mask 0x%x (2 = corrupt deflate data, 4 = length, 8 = CRC-32)", st); return SCFQ_EGZ; }
+  return (int64_t)total;
 }
 
 // ---- K5: line index of a device-resident input ------------------------------------------------------------------

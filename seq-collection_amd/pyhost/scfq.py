@@ -32,7 +32,7 @@ EXPORTS = [
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
     "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
     "scfq_index_lines", "scfq_dedup_buffer", "scfq_dedup_file", "scfq_dedup_error_detail", "scfq_stage_file",
-    "scfq_device_free", "scfq_meta_header", "scfq_meta_file_tsv",
+    "scfq_device_free", "scfq_meta_header", "scfq_meta_file_tsv", "scfq_debug_bgzf_inflate",
 ]
 
 
@@ -131,6 +131,8 @@ def lib():
         L.scfq_device_free.argtypes = [ctypes.c_void_p]
         L.scfq_meta_header.restype = ctypes.c_char_p
         L.scfq_meta_file_tsv.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint64]
+        L.scfq_debug_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+        L.scfq_debug_bgzf_inflate.restype = ctypes.c_int64
         L.scfq_index_lines.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64)]
         L.scfq_debug_stream_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
@@ -275,6 +277,16 @@ def meta_file_tsv(path, sample_n=100, flags=0):
     buf = ctypes.create_string_buffer(4096)
     _check(min(0, lib().scfq_meta_file_tsv(os.fsencode(path), sample_n, flags, buf, 4096)), "scfq_meta_file_tsv")
     return buf.value.decode()
+
+
+def debug_bgzf_inflate(image, cap):
+    """device-side inflate of a BGZF image held in host memory (bytes) -> bytes"""
+    addr, n, keep = _host_ptr(image)
+    out = (ctypes.c_uint8 * max(cap, 1))()
+    r = lib().scfq_debug_bgzf_inflate(addr, n, out, cap)
+    if r < 0:
+        raise ScfqError(int(r), "scfq_debug_bgzf_inflate", lib().scfq_last_error_detail().decode())
+    return ctypes.string_at(out, r)
 
 
 def hist_stats():

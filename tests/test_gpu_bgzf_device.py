@@ -1,0 +1,77 @@
+"""Device-side BGZF inflate (csrc/bgzf_inflate_kernel.hpp) against zlib: same bytes for valid images, SCFQ_EGZ for corrupt ones."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from test_ingest_sources import bgzf_block, bgzf_file, fastq_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def raw_block(data, payload):
+    bsize = 18 + len(payload) + 8
+    hdr = b"\x1f\x8b\x08\x04" + b"\x00\x00\x00\x00" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+    return hdr + payload + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+
+def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    return co.compress(data) + co.flush()
+
+
+def test_small_images_first(gpu, scfq):
+    """tiny inputs first: a kernel fault shows up here before anything large runs"""
+    for data in (b"", b"a", b"hello hello hello hello\n", b"@r\nACGT\n+\nIIII\n" * 10, bytes(1000), bytes(range(256)) * 4):
+        for level in (0, 1, 6, 9):
+            img = bgzf_block(data, level)
+            assert gzip.decompress(img) == data
+            assert scfq.debug_bgzf_inflate(img, len(data) + 16) == data, (data[:10], level)
+
+
+def test_corpora_levels_strategies(gpu, scfq):
+    rng = np.random.default_rng(3)
+    corpora = {
+        "fastq": fastq_bytes(3_000_000, seed=5),
+        "random": rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes(),
+        "zeros": bytes(400_000),
+        "short_period": (b"ACGTN" * 7 + b"\n") * 9_000,
+        "two_symbols": bytes(rng.choice(np.frombuffer(b"AB", dtype=np.uint8), 200_000)),
+        "skewed": bytes(rng.choice(np.arange(256, dtype=np.uint8), 300_000, p=np.r_[np.full(16, 0.05), np.full(240, 0.2 / 240)])),
+    }
+    for name, data in corpora.items():
+        for level in (1, 6, 9):
+            img = b"".join(bgzf_block(data[i:i + 0xff00], level) for i in range(0, len(data), 0xff00)) + bgzf_block(b"")
+            assert scfq.debug_bgzf_inflate(img, len(data) + 16) == data, (name, level)
+        for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+            img = b"".join(raw_block(data[i:i + 60000], deflate(data[i:i + 60000], 6, strategy)) for i in range(0, len(data), 60000))
+            assert scfq.debug_bgzf_inflate(img, len(data) + 16) == data, (name, strategy)
+        img = bgzf_file(data, block=997)                    # thousands of tiny members
+        assert scfq.debug_bgzf_inflate(img, len(data) + 16) == data, (name, "tiny blocks")
+
+
+def test_corrupt_members_are_rejected(gpu, scfq):
+    data = fastq_bytes(500_000, seed=9)
+    img = bytearray(bgzf_file(data))
+    rng = np.random.default_rng(4)
+    rejected = 0
+    for trial in range(40):
+        bad = bytearray(img)
+        pos = int(rng.integers(18, len(bad) - 28))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            want = gzip.decompress(bytes(bad))
+        except Exception:
+            want = None
+        try:
+            got = scfq.debug_bgzf_inflate(bytes(bad), len(data) + 65536)
+        except scfq.ScfqError as e:
+            assert e.rc in (scfq.SCFQ_EGZ, scfq.SCFQ_EARG), e.rc      # EARG: the flip hit a header field (no longer BGZF)
+            got = None
+            rejected += 1
+        assert got == want, (trial, pos)
+    assert rejected >= 30
+    with pytest.raises(scfq.ScfqError):
+        scfq.debug_bgzf_inflate(bytes(img[: len(img) // 2]), len(data) + 16)
