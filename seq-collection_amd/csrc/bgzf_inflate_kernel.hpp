@@ -124,13 +124,17 @@ __device__ inline uint32_t x_pow_8n(uint32_t n) {      // x^(8 n) mod P, n < 2^2
   return p;
 }
 
+// An LDS read whose address is wave-uniform returns the same value in every lane; saying so (v_readfirstlane) lets the
+// compiler keep everything computed from it — the bit buffer, positions, every branch — on the scalar unit instead of
+// doing it 64 times over on the vector ALU with exec-mask bookkeeping around every check.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks,
                                                                 uint32_t n_blocks, uint8_t* out, uint32_t* status /* one word, OR of (1 << error) */) {
   extern __shared__ uint16_t lds[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t b = blockIdx.x * kWavesPerWg + wave;
-  if (b >= n_blocks) return;
   uint16_t* lit = lds + wave * kWaveLdsHalfwords;
   uint16_t* dist = lit + kLitEntries;
   uint8_t* lens = reinterpret_cast<uint8_t*>(dist + kDistEntries);      // 320 bytes
@@ -139,6 +143,14 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   uint16_t* count = sorted + 320;
   uint16_t* offs = count + 16;
   __shared__ uint32_t build_ok[kWavesPerWg];
+  // length / distance base and extra-bit tables: LDS copies (a lookup in the global-memory constants costs an L2 round
+  // trip per match, four times)
+  __shared__ uint16_t s_len_base[32], s_dist_base[32];
+  __shared__ uint8_t s_len_extra[32], s_dist_extra[32];
+  if (threadIdx.x < 29) { s_len_base[threadIdx.x] = kLenBase[threadIdx.x]; s_len_extra[threadIdx.x] = kLenExtra[threadIdx.x]; }
+  if (threadIdx.x < 30) { s_dist_base[threadIdx.x] = kDistBase[threadIdx.x]; s_dist_extra[threadIdx.x] = kDistExtra[threadIdx.x]; }
+  __syncthreads();
+  if (b >= n_blocks) return;
 
   const Block blk = blocks[b];
   const uint8_t* in = comp + blk.in_off;
@@ -149,24 +161,28 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   uint32_t bc = 0, pos = 0, err = kOk;
   bool last = false;
 
-  auto refill = [&]() {
-    // the 8-byte gzip trailer follows the deflate data, so an 8-byte load that starts inside the data stays in the chunk
-    if (in < in_end) {
-      uint64_t w;
-      __builtin_memcpy(&w, in, 8);
-      const uint32_t avail = (uint32_t)(in_end - in);
-      if (avail < 8) w &= (1ull << (8 * avail)) - 1;
-      bb |= w << bc;
-      uint32_t take = (63 - bc) >> 3;
-      if (take > avail) take = avail;
-      in += take;
-      bc += take * 8;
-    }
-  };
+  // the 8-byte gzip trailer follows the deflate data, so an 8-byte load that starts inside the data stays in the chunk.
+  // (A macro, not a lambda: captured-by-reference state ended up in scratch memory, which made every value derived from
+  // it per-lane.)
+#define SCFQ_DREFILL()                                                                         \
+  do {                                                                                         \
+    if (in < in_end) {                                                                         \
+      uint64_t w_;                                                                             \
+      __builtin_memcpy(&w_, in, 8);                                                            \
+      w_ = ((uint64_t)uni((uint32_t)(w_ >> 32)) << 32) | uni((uint32_t)w_);                    \
+      const uint32_t avail_ = (uint32_t)(in_end - in);                                         \
+      if (avail_ < 8) w_ &= (1ull << (8 * avail_)) - 1;                                        \
+      bb |= w_ << bc;                                                                          \
+      uint32_t take_ = (63 - bc) >> 3;                                                         \
+      if (take_ > avail_) take_ = avail_;                                                      \
+      in += take_;                                                                             \
+      bc += take_ * 8;                                                                         \
+    }                                                                                          \
+  } while (0)
 
   uint32_t guard = 0;                                  // every pass of every loop below consumes input bits or ends
   while (!last && err == kOk) {
-    refill();
+    SCFQ_DREFILL();
     if (bc < 3) { err = kErrData; break; }
     last = bb & 1;
     const uint32_t type = (uint32_t)(bb >> 1) & 3u;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     if (type == 0) {
       // stored: to the byte boundary, LEN / NLEN, then a plain copy (all lanes)
       const uint32_t drop = bc & 7; bb >>= drop; bc -= drop;
-      refill();
+      SCFQ_DREFILL();
       if (bc < 32) { err = kErrData; break; }
       const uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
       bb >>= 32; bc -= 32;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
         build_ok[wave] = ok ? 1u : 0u;
       }
     } else {
-      refill();
+      SCFQ_DREFILL();
       if (bc < 14) { err = kErrData; break; }
       const uint32_t hlit = ((uint32_t)bb & 31) + 257, hdist = ((uint32_t)(bb >> 5) & 31) + 1, hclen = ((uint32_t)(bb >> 10) & 15) + 4;
       bb >>= 14; bc -= 14;
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       // walk the bits together, lane 0 writes
       if (lane == 0) for (int k = 0; k < 19; ++k) lens[k] = 0;
       for (uint32_t k = 0; k < hclen; ++k) {
-        refill();
+        SCFQ_DREFILL();
         if (bc < 3) { err = kErrData; break; }
         if (lane == 0) lens[kClOrder[k]] = (uint8_t)(bb & 7);
         bb >>= 3; bc -= 3;
@@ -222,8 +238,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       const uint32_t total = hlit + hdist;
       while (k < total) {
         if (++guard > (1u << 20)) { err = kErrData; break; }
-        refill();
-        const uint32_t e = cltab[bb & 127];
+        SCFQ_DREFILL();
+        const uint32_t e = uni(cltab[bb & 127]);
         const uint32_t len = e & 15;
         if (len == 0 || len > bc) { err = kErrData; break; }
         bb >>= len; bc -= len;
@@ -253,10 +269,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     // ---- symbols --------------------------------------------------------------------------------------------------
     for (;;) {
       if (++guard > (1u << 22)) { err = kErrData; break; }
-      refill();
-      uint32_t e = lit[bb & ((1u << kLitRoot) - 1)];
+      if (bc < 48) SCFQ_DREFILL();          // a literal/length + distance pair needs at most 15 + 5 + 15 + 13 = 48 bits
+      uint32_t e = uni(lit[bb & ((1u << kLitRoot) - 1)]);
       if (e & 0x8000u) {
-        e = lit[((e >> 4) & 0x7FF) + ((uint32_t)(bb >> kLitRoot) & ((1u << (e & 15)) - 1))];
+        e = uni(lit[((e >> 4) & 0x7FF) + ((uint32_t)(bb >> kLitRoot) & ((1u << (e & 15)) - 1))]);
         bb >>= kLitRoot; bc -= kLitRoot;
       }
       const uint32_t len = e & 15;
@@ -271,14 +287,14 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       }
       if (sym == 256) break;
       if (sym > 285) { err = kErrData; break; }
-      const uint32_t lx = kLenExtra[sym - 257];
+      const uint32_t lx = uni(s_len_extra[sym - 257]);
       if (lx > bc) { err = kErrData; break; }
-      const uint32_t mlen = kLenBase[sym - 257] + ((uint32_t)bb & ((1u << lx) - 1));
+      const uint32_t mlen = uni(s_len_base[sym - 257]) + ((uint32_t)bb & ((1u << lx) - 1));
       bb >>= lx; bc -= lx;
-      refill();
-      uint32_t d = dist[bb & ((1u << kDistRoot) - 1)];
+      if (bc < 28) SCFQ_DREFILL();
+      uint32_t d = uni(dist[bb & ((1u << kDistRoot) - 1)]);
       if (d & 0x8000u) {
-        d = dist[((d >> 4) & 0x7FF) + ((uint32_t)(bb >> kDistRoot) & ((1u << (d & 15)) - 1))];
+        d = uni(dist[((d >> 4) & 0x7FF) + ((uint32_t)(bb >> kDistRoot) & ((1u << (d & 15)) - 1))]);
         bb >>= kDistRoot; bc -= kDistRoot;
       }
       const uint32_t dl = d & 15;
@@ -286,16 +302,22 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       bb >>= dl; bc -= dl;
       const uint32_t dsym = (d >> 4) & 0x1FF;
       if (dsym >= 30) { err = kErrData; break; }
-      const uint32_t dx = kDistExtra[dsym];
+      const uint32_t dx = uni(s_dist_extra[dsym]);
       if (dx > bc) { err = kErrData; break; }
-      const uint32_t off = kDistBase[dsym] + ((uint32_t)bb & ((1u << dx) - 1));
+      const uint32_t off = uni(s_dist_base[dsym]) + ((uint32_t)bb & ((1u << dx) - 1));
       bb >>= dx; bc -= dx;
       if (off > pos) { err = kErrData; break; }          // a BGZF member starts with an empty window
       if (pos + mlen > isize) { err = kErrLength; break; }
-      // the bytes the match reads were stored by this wave (lane 0's literals, other lanes' earlier copies): make them
-      // visible before reading them back
+      // The bytes the match reads were stored by this same wave (lane 0's literals, other lanes' earlier copies).  Vector
+      // memory instructions of one wave reach the CU's L1 in issue order and the write-through L1 serves later loads of
+      // the same CU coherently (the workgroup-scope rule of the AMDGPU memory model: no cache maintenance inside a CU), so
+      // no s_waitcnt vmcnt(0) is needed here — with it, every match waited ~2 us for the wave's outstanding stores and
+      // the kernel ran 10x slower.  SCFQ_DINFLATE_FENCE builds the conservative form; every member's CRC-32 is verified
+      // on the device either way.
+#ifdef SCFQ_DINFLATE_FENCE
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
       const uint8_t* src = o + pos - off;
       for (uint32_t k = lane; k < mlen; k += 64) {
         const uint32_t j = (off >= mlen) ? k : (off == 1 ? 0u : k % off);
@@ -325,6 +347,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     }
     if (total != blk.crc) err = kErrCrc;
   }
+#undef SCFQ_DREFILL
   if (lane == 0 && err) atomicOr(status, 1u << err);      // one word for the whole launch: bit k = some block ended with error k
 }
 

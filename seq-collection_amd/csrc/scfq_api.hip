@@ -82,6 +82,14 @@ struct Ctx {
   bool fresh = true;                   // no scan folded into d_state yet in this session
   // staging (host buffers / files)
   uint8_t* d_stage[2] = {nullptr, nullptr};
+  // device-side BGZF inflate: compressed chunk, block table (device + pinned), error word
+  uint8_t* d_comp[2] = {nullptr, nullptr};
+  scfq_dinflate::Block* d_blk[2] = {nullptr, nullptr};
+  scfq_dinflate::Block* h_blk[2] = {nullptr, nullptr};
+  uint8_t* h_comp[2] = {nullptr, nullptr};
+  uint8_t* d_inf[2] = {nullptr, nullptr};      // inflated chunks (kStagePad + inf_cap each)
+  uint32_t* d_dstatus = nullptr;
+  uint64_t comp_cap = 0, inf_cap = 0;
   uint8_t* h_pin[2] = {nullptr, nullptr};
   uint64_t stage_cap = 0;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
@@ -671,6 +679,132 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
   return SCFQ_OK;
 }
 
+// ---- BGZF with device-side inflate: the host only walks the member headers and moves COMPRESSED bytes ---------------
+constexpr uint32_t kMaxBlocksPerChunk = 1u << 18;
+constexpr int kFallbackToHost = 1;        // ingest_bgzf_device: could not set up, nothing queued
+constexpr uint64_t kStagePad = 4096;      // inflated chunks start one tile into their buffer: byte [-1] carries the look-behind
+
+static int64_t bgzf_plan(const uint8_t* img, uint64_t n, uint64_t pos, uint64_t out_cap, uint64_t comp_cap, uint32_t max_blocks,
+                         scfq_dinflate::Block* blocks, uint32_t* n_blocks, uint64_t* out_bytes);
+
+bool bgzf_device_enabled() {
+  static const bool v = [] { const char* e = std::getenv("SCFQ_BGZF_DEVICE"); return e ? e[0] != '0' : true; }();
+  return v;
+}
+
+// true when [img, img + n) is nothing but BGZF members of at most 64 KiB (what the device kernel takes)
+bool bgzf_is_pure(const uint8_t* img, uint64_t n) {
+  uint64_t p = 0;
+  while (p < n) {
+    uint32_t hl = 0;
+    const uint32_t bs = scfq_bgzf::block_size(img + p, n - p, &hl);
+    if (!bs || p + bs > n || scfq_bgzf::rd32(img + p + bs - 4) > (1u << 16)) return false;
+    p += bs;
+  }
+  return n > 0;
+}
+
+int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing) {
+  // One wave inflates one member and a member is slow on its own (a serial bit stream): the kernel needs thousands of
+  // members per launch to fill 256 CUs, so the device path works in large inflated chunks (up to 1 GiB, i.e. ~16 K
+  // members) whatever the staging chunk of the host path is; compressed chunks are a third to a quarter of that.
+  static const uint64_t max_inf = (uint64_t)std::max(64, env_int("SCFQ_BGZF_DEVICE_CHUNK_MB", 1024)) << 20;
+  const uint64_t want_inf = std::min<uint64_t>(max_inf, std::max<uint64_t>(64ull << 20, (fsize * 5 + 4095) & ~4095ull));
+  const uint64_t want_comp = std::min<uint64_t>(want_inf / 2, std::max<uint64_t>(32ull << 20, (fsize + 4095) & ~4095ull));
+  int rc = SCFQ_OK;
+  if (c->comp_cap < want_comp || c->inf_cap < want_inf) {
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipStreamSynchronize(c->copy));
+    for (int b = 0; b < 2; ++b) {
+      if (c->d_comp[b]) HIPCHK(hipFree(c->d_comp[b]));
+      if (c->d_inf[b]) HIPCHK(hipFree(c->d_inf[b]));
+      if (c->h_comp[b]) HIPCHK(hipHostFree(c->h_comp[b]));
+      c->d_comp[b] = nullptr; c->d_inf[b] = nullptr; c->h_comp[b] = nullptr;
+    }
+    c->comp_cap = c->inf_cap = 0;
+    bool ok = true;
+    for (int b = 0; b < 2 && ok; ++b) {
+      ok = hipMalloc(&c->d_comp[b], want_comp + 64) == hipSuccess && hipMalloc(&c->d_inf[b], want_inf + kStagePad) == hipSuccess &&
+           hipHostMalloc(&c->h_comp[b], want_comp, hipHostMallocDefault) == hipSuccess;
+      if (ok && !c->d_blk[b]) ok = hipMalloc(&c->d_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block)) == hipSuccess;
+      if (ok && !c->h_blk[b]) ok = hipHostMalloc(&c->h_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block), hipHostMallocDefault) == hipSuccess;
+    }
+    if (ok && !c->d_dstatus) ok = hipMalloc(&c->d_dstatus, sizeof(uint32_t)) == hipSuccess;
+    if (!ok) {
+      // not enough device / pinned memory for the big chunks (many concurrent sessions): nothing was queued yet, so the
+      // caller can still take the host inflate path
+      (void)hipGetLastError();
+      for (int b = 0; b < 2; ++b) {
+        if (c->d_comp[b]) (void)hipFree(c->d_comp[b]);
+        if (c->d_inf[b]) (void)hipFree(c->d_inf[b]);
+        if (c->h_comp[b]) (void)hipHostFree(c->h_comp[b]);
+        c->d_comp[b] = nullptr; c->d_inf[b] = nullptr; c->h_comp[b] = nullptr;
+      }
+      return kFallbackToHost;
+    }
+    c->comp_cap = want_comp;
+    c->inf_cap = want_inf;
+  }
+  const uint64_t chunk = c->inf_cap, comp_chunk = c->comp_cap;
+  HIPCHK(hipMemsetAsync(c->d_dstatus, 0, sizeof(uint32_t), c->compute));
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
+  double fill_ms = 0;
+  struct Fin {
+    Ctx* c; clk::time_point t0; double* fill;
+    ~Fin() { c->timing.host_fill_ms += *fill; c->timing.ingest_wall_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+  } fin{c, t_begin, &fill_ms};
+  uint64_t pos = 0;
+  const uint8_t* prev_base = nullptr;
+  uint64_t prev_n = 0;
+  for (unsigned it = 0; pos < fsize; ++it) {
+    const int b = it & 1;
+    if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));      // pinned buffer + pinned table b are free again
+    const auto tf = clk::now();
+    uint32_t nb = 0;
+    uint64_t ob = 0;
+    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, kMaxBlocksPerChunk, c->h_blk[b], &nb, &ob);
+    if (used < 0) return SCFQ_EGZ;
+    if (used == 0) break;
+    const uint8_t* src = img + pos;
+    parallel_pieces((uint64_t)used, [&](uint64_t o, uint64_t len) { std::memcpy(c->h_comp[b] + o, src + o, len); return 0; });
+    fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
+    c->timing.h2d_bytes += (uint64_t)used;
+    if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));       // device buffers b were consumed
+    if (timing) {
+      while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
+      HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
+    }
+    HIPCHK(hipMemcpyAsync(c->d_comp[b], c->h_comp[b], (size_t)used, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
+    if (timing) { HIPCHK(hipEventRecord(c->cp_pool[c->cp_used + 1], c->copy)); c->cp_used += 2; }
+    HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
+    HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));
+    uint8_t* base = c->d_inf[b] + kStagePad;
+    if (prev_base) HIPCHK(hipMemcpyAsync(base - 1, prev_base + prev_n - 1, 1, hipMemcpyDeviceToDevice, c->compute));
+    if (nb) {
+      hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
+                         dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsHalfwords * 2, c->compute,
+                         c->d_comp[b], c->d_blk[b], nb, base, c->d_dstatus);
+      HIPCHK(hipGetLastError());
+    }
+    if (ob) {
+      rc = scan_async(c, base, ob, prev_base ? -2 : -1, flags & ~SCFQ_PREV_IN_MEMORY, timing);
+      if (rc) return rc;
+      prev_base = base;
+      prev_n = ob;
+    }
+    HIPCHK(hipEventRecord(c->ev_scanned[b], c->compute));
+    pos += (uint64_t)used;
+  }
+  uint32_t st = 0;
+  HIPCHK(hipMemcpyAsync(c->h_state + kStateWords - 1, c->d_dstatus, sizeof(uint32_t), hipMemcpyDeviceToHost, c->compute));
+  HIPCHK(hipStreamSynchronize(c->compute));
+  std::memcpy(&st, c->h_state + kStateWords - 1, sizeof st);
+  if (st) { std::snprintf(g_err, sizeof g_err, "device inflate: error mask 0x%x (2 = corrupt deflate data, 4 = length, 8 = CRC-32)", st); return SCFQ_EGZ; }
+  return SCFQ_OK;
+}
+
 int partial_on_current_device(const void* ptr, uint64_t n, int is_device, int prev_byte, const scfq_opts* opts,
                               scfq_partial* out, uint64_t* hist) {
   Ctx* c = nullptr;
@@ -824,7 +958,21 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
         SessionLock sl;
         rc = get_ctx(&c, sl);
         if (!rc) rc = begin_session(c, true);
-        if (!rc) {
+        bool on_device = false;
+        if (!rc && bgzf_device_enabled() && bsb.st_size > 0) {
+          // pure BGZF (every member <= 64 KiB with its size in the header): compressed bytes over PCIe, inflate on the device
+          void* m = mmap(nullptr, (size_t)bsb.st_size, PROT_READ, MAP_PRIVATE, bfd, 0);
+          if (m != MAP_FAILED) {
+            (void)madvise(m, (size_t)bsb.st_size, MADV_SEQUENTIAL);
+            if (bgzf_is_pure(static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size)) {
+              rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing);
+              on_device = (rc != kFallbackToHost);
+              if (!on_device) rc = SCFQ_OK;
+            }
+            munmap(m, (size_t)bsb.st_size);
+          }
+        }
+        if (!rc && !on_device) {
           BgzfSource src(bfd, (uint64_t)bsb.st_size);
           rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
         }
@@ -942,6 +1090,14 @@ int scfq_shutdown(void) {
     if (c->d_guess) (void)hipFree(c->d_guess);
     if (c->d_hist_wg) (void)hipFree(c->d_hist_wg);
     if (c->d_first_ord) (void)hipFree(c->d_first_ord);
+    for (int b = 0; b < 2; ++b) {
+      if (c->d_comp[b]) (void)hipFree(c->d_comp[b]);
+      if (c->d_inf[b]) (void)hipFree(c->d_inf[b]);
+      if (c->d_blk[b]) (void)hipFree(c->d_blk[b]);
+      if (c->h_blk[b]) (void)hipHostFree(c->h_blk[b]);
+      if (c->h_comp[b]) (void)hipHostFree(c->h_comp[b]);
+    }
+    if (c->d_dstatus) (void)hipFree(c->d_dstatus);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1038,11 +1194,13 @@ int scfq_device_free(void* dptr) {
 // inflated bytes fit into out_cap, starting at byte `pos`.  Returns the number of bytes consumed, 0 at the end of the
 // image (or at a clean end-of-file marker run), -1 when the bytes at pos are not a BGZF member (caller falls back to the
 // host path) and -2 for a truncated member.
-static int64_t bgzf_plan(const uint8_t* img, uint64_t n, uint64_t pos, uint64_t out_cap, uint64_t comp_cap,
-                         std::vector<scfq_dinflate::Block>* blocks, uint64_t* out_bytes) {
-  blocks->clear();
+}  // extern "C"
+namespace {
+int64_t bgzf_plan(const uint8_t* img, uint64_t n, uint64_t pos, uint64_t out_cap, uint64_t comp_cap, uint32_t max_blocks,
+                  scfq_dinflate::Block* blocks, uint32_t* n_blocks, uint64_t* out_bytes) {
   uint64_t p = pos, out = 0;
-  while (p < n) {
+  uint32_t nb = 0;
+  while (p < n && nb < max_blocks) {
     uint32_t hl = 0;
     const uint32_t bs = scfq_bgzf::block_size(img + p, n - p, &hl);
     if (!bs) { if (p == pos) return -1; break; }        // something else follows: this chunk ends here, the next call reports it
@@ -1056,13 +1214,16 @@ static int64_t bgzf_plan(const uint8_t* img, uint64_t n, uint64_t pos, uint64_t 
     b.out_off = (uint32_t)out;
     b.isize = isize;
     b.crc = scfq_bgzf::rd32(img + p + bs - 8);
-    blocks->push_back(b);
+    blocks[nb++] = b;
     out += isize;
     p += bs;
   }
+  *n_blocks = nb;
   *out_bytes = out;
   return (int64_t)(p - pos);
 }
+}  // namespace
+extern "C" {
 
 // Diagnostic / test entry: inflate a whole BGZF image (host memory) on the device, result to host memory.
 // Returns the inflated size, SCFQ_EARG when the image is not pure BGZF or does not fit, SCFQ_EGZ for a corrupt member.
@@ -1073,7 +1234,7 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
   int rc = get_ctx(&c, sl);
   if (rc) return rc;
   const uint8_t* img = static_cast<const uint8_t*>(image);
-  std::vector<scfq_dinflate::Block> blocks;
+  std::vector<scfq_dinflate::Block> blocks(1u << 20);
   uint64_t total = 0, pos = 0;
   uint8_t *d_comp = nullptr, *d_out = nullptr;
   scfq_dinflate::Block* d_blocks = nullptr;
@@ -1087,14 +1248,14 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
   HIPCHK(hipMemsetAsync(d_status, 0, 4, c->compute));
   while (pos < n) {
     uint64_t ob = 0;
-    const int64_t used = bgzf_plan(img, n, pos, kChunk, kChunk, &blocks, &ob);
+    uint32_t nb = 0;
+    const int64_t used = bgzf_plan(img, n, pos, kChunk, kChunk, (uint32_t)(kChunk / 64), blocks.data(), &nb, &ob);
     if (used == -2) return SCFQ_EGZ;
-    if (used < 0 || blocks.size() > kChunk / 64) return SCFQ_EARG;
+    if (used < 0) return SCFQ_EARG;
     if (used == 0) break;
     if (total + ob > cap) return SCFQ_EARG;
     HIPCHK(hipMemcpyAsync(d_comp, img + pos, (size_t)used, hipMemcpyHostToDevice, c->compute));
-    HIPCHK(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->compute));
-    const unsigned nb = (unsigned)blocks.size();
+    HIPCHK(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->compute));
     hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
                        dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsHalfwords * 2, c->compute,
                        d_comp, d_blocks, nb, d_out, d_status);

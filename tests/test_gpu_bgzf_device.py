@@ -75,3 +75,35 @@ def test_corrupt_members_are_rejected(gpu, scfq):
     assert rejected >= 30
     with pytest.raises(scfq.ScfqError):
         scfq.debug_bgzf_inflate(bytes(img[: len(img) // 2]), len(data) + 16)
+
+
+def test_count_file_with_device_inflate(gpu, scfq, oracle, tmp_path):
+    """scfq_count_file on BGZF files: device-side inflate (default) == host inflate == oracle, incl. quality histogram,
+    small chunks (members spread over many chunks, look-behind byte carried on the device) and CRLF line ends"""
+    import os
+    import subprocess
+    import sys
+    data = fastq_bytes(6_000_000, seed=21).replace(b"\n", b"\r\n")
+    a = np.frombuffer(data, dtype=np.uint8)
+    oc = oracle.count(a)
+    for name, blob in (("x.fq.gz", bgzf_file(data)), ("tiny.fq.gz", bgzf_file(data, block=3001)), ("noeof.fq.gz", bgzf_file(data, eof_marker=False))):
+        f = tmp_path / name
+        f.write_bytes(blob)
+        for chunk in (0, 1 << 20, 1 << 16):
+            c = scfq.count_file(str(f), flags=scfq.SCFQ_QUAL_HIST | scfq.SCFQ_STRUCT_CHECK, chunk_bytes=chunk)
+            for fld in ("reads", "gc_bases", "n_bases", "bases", "lines", "newlines", "input_bytes", "bad_at", "bad_plus"):
+                assert getattr(c, fld) == getattr(oc, fld), (name, chunk, fld)
+            assert list(c.qual_hist) == list(oc.qual_hist), (name, chunk)
+    # the host path on the same file, in a fresh process (the switch is read once)
+    code = ("import sys; sys.path.insert(0, %r); import scfq; c = scfq.count_file(%r); print(c.reads, c.gc_bases, c.n_bases, c.bases)"
+            % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seq-collection_amd", "pyhost"), str(tmp_path / "x.fq.gz")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCFQ_BGZF_DEVICE="0"), capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == [str(oc.reads), str(oc.gc_bases), str(oc.n_bases), str(oc.bases)], r.stderr
+    # a corrupt member is an error, not a wrong count
+    bad = bytearray(bgzf_file(data))
+    bad[len(bad) // 2] ^= 0x10
+    g = tmp_path / "bad.fq.gz"
+    g.write_bytes(bytes(bad))
+    with pytest.raises(scfq.ScfqError) as e:
+        scfq.count_file(str(g))
+    assert e.value.rc == scfq.SCFQ_EGZ
