@@ -266,6 +266,84 @@ struct Decoder {
     } while (0)
 #define SCFQ_DROP(n) do { bb >>= (n); bc -= (uint32_t)(n); } while (0)
 #define SCFQ_FAIL() do { result = (in >= iend) ? (int)kErrTruncated : (int)kErrData; goto done; } while (0)
+    // ---- fast loop: while at least 8 input bytes and kOutSlack output bytes remain, a refill is one unconditional load
+    //      and leaves >= 56 bits: enough for a whole literal/length + distance pair (15 + 5 + 15 + 13 = 48), so none of
+    //      the "do I have the bits" checks of the careful loop below are needed
+    if (iend - in >= 16) {
+      const uint8_t* const in_fast = iend - 8;
+      uint8_t* const out_fast = out_end - kOutSlack;
+      while (in <= in_fast && out <= out_fast) {
+        {
+          uint64_t w_;
+          std::memcpy(&w_, in, 8);
+          bb |= w_ << bc;
+          in += (63 - bc) >> 3;
+          bc |= 56;
+        }
+        uint32_t e = lt[bb & ((1u << kLitRoot) - 1)];
+        if (e & F_LITERAL) {
+          SCFQ_DROP(e_len(e));
+          *out++ = (uint8_t)e_val(e);
+          e = lt[bb & ((1u << kLitRoot) - 1)];
+          if (e & F_LITERAL) {
+            SCFQ_DROP(e_len(e));
+            *out++ = (uint8_t)e_val(e);
+            e = lt[bb & ((1u << kLitRoot) - 1)];
+            if (e & F_LITERAL) {
+              SCFQ_DROP(e_len(e));
+              *out++ = (uint8_t)e_val(e);
+              e = lt[bb & ((1u << kLitRoot) - 1)];
+              if (e & F_LITERAL) {                 // a fourth: 4 x 11 = 44 <= 56 bits, first-level codes only
+                SCFQ_DROP(e_len(e));
+                *out++ = (uint8_t)e_val(e);
+              }
+            }
+          }
+          continue;
+        }
+        if (e & F_SUB) {
+          e = lt[e_val(e) + ((bb >> kLitRoot) & ((1u << e_extra(e)) - 1))];
+          SCFQ_DROP(kLitRoot);
+          if (e & F_LITERAL) { SCFQ_DROP(e_len(e)); *out++ = (uint8_t)e_val(e); continue; }
+        }
+        if (e_len(e) == 0) { result = kErrData; goto done; }
+        SCFQ_DROP(e_len(e));
+        if (e & F_EOB) { state = last_block ? kDone : kHeader; result = kBlockEnd; goto done; }
+        const uint32_t lx = e_extra(e);
+        const uint32_t mlen = e_val(e) + (uint32_t)(bb & ((1ull << lx) - 1));
+        SCFQ_DROP(lx);
+        uint32_t d = dt[bb & ((1u << kDistRoot) - 1)];
+        if (d & F_SUB) {
+          d = dt[e_val(d) + ((bb >> kDistRoot) & ((1u << e_extra(d)) - 1))];
+          SCFQ_DROP(kDistRoot);
+        }
+        if (e_len(d) == 0) { result = kErrData; goto done; }
+        SCFQ_DROP(e_len(d));
+        const uint32_t dx = e_extra(d);
+        const uint32_t off = e_val(d) + (uint32_t)(bb & ((1ull << dx) - 1));
+        SCFQ_DROP(dx);
+        if (off > total_at_entry + (uint64_t)(out - run_start)) { result = kErrData; goto done; }
+        const uint8_t* src = out - off;
+        uint8_t* dst = out;
+        out += mlen;
+        if (off >= 8) {
+          // most matches are short: two unconditional words, then the rest
+          uint64_t w0, w1;
+          std::memcpy(&w0, src, 8); std::memcpy(dst, &w0, 8);
+          std::memcpy(&w1, src + 8, 8); std::memcpy(dst + 8, &w1, 8);
+          if (mlen > 16) {
+            uint8_t* const stop = dst + mlen;
+            src += 16; dst += 16;
+            do { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < stop);
+          }
+        } else if (off == 1) {
+          std::memset(dst, *src, mlen);
+        } else {
+          for (uint32_t k = 0; k < mlen; ++k) dst[k] = src[k];
+        }
+      }
+    }
+    // ---- careful loop: the last bytes of the input / of the output buffer -----------------------------------------
     for (;;) {
       if ((uint64_t)(out_end - out) < kOutSlack) { result = kNeedOutput; goto done; }
       SCFQ_REFILL();
