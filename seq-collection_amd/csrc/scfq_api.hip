@@ -704,14 +704,14 @@ bool bgzf_is_pure(const uint8_t* img, uint64_t n) {
   return n > 0;
 }
 
-int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing) {
+// buffers of the device-inflate path; kFallbackToHost when they cannot be had (nothing queued yet)
+int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
   // One wave inflates one member and a member is slow on its own (a serial bit stream): the kernel needs thousands of
   // members per launch to fill 256 CUs, so the device path works in large inflated chunks (up to 1 GiB, i.e. ~16 K
   // members) whatever the staging chunk of the host path is; compressed chunks are a third to a quarter of that.
   static const uint64_t max_inf = (uint64_t)std::max(64, env_int("SCFQ_BGZF_DEVICE_CHUNK_MB", 1024)) << 20;
   const uint64_t want_inf = std::min<uint64_t>(max_inf, std::max<uint64_t>(64ull << 20, (fsize * 5 + 4095) & ~4095ull));
   const uint64_t want_comp = std::min<uint64_t>(want_inf / 2, std::max<uint64_t>(32ull << 20, (fsize + 4095) & ~4095ull));
-  int rc = SCFQ_OK;
   if (c->comp_cap < want_comp || c->inf_cap < want_inf) {
     HIPCHK(hipStreamSynchronize(c->compute));
     HIPCHK(hipStreamSynchronize(c->copy));
@@ -745,6 +745,12 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
     c->comp_cap = want_comp;
     c->inf_cap = want_inf;
   }
+  return SCFQ_OK;
+}
+
+int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing) {
+  int rc = ensure_bgzf_device_buffers(c, fsize);
+  if (rc) return rc;
   const uint64_t chunk = c->inf_cap, comp_chunk = c->comp_cap;
   HIPCHK(hipMemsetAsync(c->d_dstatus, 0, sizeof(uint32_t), c->compute));
   using clk = std::chrono::steady_clock;
@@ -1106,6 +1112,11 @@ int scfq_shutdown(void) {
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
   }
+  // fq-dedup keeps its scratch in the devices' stream-ordered pools (release threshold raised): give it back
+  for (auto& kv : g_ctx) {
+    hipMemPool_t pool;
+    if (hipSetDevice(kv.first) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, kv.first) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+  }
   g_ctx.clear();
   return SCFQ_OK;
 }
@@ -1127,6 +1138,77 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
   uint64_t hint = 64ull << 20;
   struct Closer { int* fd; gzFile* gz; std::unique_ptr<Source>* s; ~Closer() { s->reset(); if (*gz) gzclose(*gz); if (*fd >= 0) close(*fd); } } closer{&fd, &gz, &src};
   struct stat sb;
+  if (is_gz && bgzf_device_enabled()) {
+    // pure BGZF: the inflated size is the sum of the ISIZE fields, and the members are inflated on the device straight
+    // into the result buffer
+    const int bfd = open(path, O_RDONLY);
+    struct stat bsb;
+    if (bfd >= 0 && fstat(bfd, &bsb) == 0 && S_ISREG(bsb.st_mode) && bsb.st_size > 0 && !std::getenv("SCFQ_NO_BGZF") && scfq_bgzf::probe(bfd)) {
+      void* m = mmap(nullptr, (size_t)bsb.st_size, PROT_READ, MAP_PRIVATE, bfd, 0);
+      if (m != MAP_FAILED) {
+        struct Unmap { void* m; size_t n; int fd; ~Unmap() { munmap(m, n); close(fd); } } um{m, (size_t)bsb.st_size, bfd};
+        const uint8_t* img = static_cast<const uint8_t*>(m);
+        const uint64_t fsize = (uint64_t)bsb.st_size;
+        if (bgzf_is_pure(img, fsize)) {
+          uint64_t total = 0;
+          for (uint64_t q = 0; q < fsize;) { uint32_t hl; const uint32_t bs = scfq_bgzf::block_size(img + q, fsize - q, &hl); total += scfq_bgzf::rd32(img + q + bs - 4); q += bs; }
+          if (opts && opts->n_devices >= 1) HIPCHK(hipSetDevice(opts->device_ids[0]));
+          Ctx* c = nullptr;
+          SessionLock sl;
+          rc = get_ctx(&c, sl);
+          if (rc) return rc;
+          rc = ensure_bgzf_device_buffers(c, fsize);
+          if (rc == SCFQ_OK) {
+            uint8_t* d_buf = nullptr;
+            HIPCHK(hipMalloc(&d_buf, std::max<uint64_t>(total, 16)));
+            struct BufGuard { uint8_t** p; ~BufGuard() { if (*p) (void)hipFree(*p); } } bg{&d_buf};
+            HIPCHK(hipMemsetAsync(c->d_dstatus, 0, sizeof(uint32_t), c->compute));
+            uint64_t pos = 0, off = 0;
+            for (unsigned it = 0; pos < fsize; ++it) {
+              const int b = it & 1;
+              if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));
+              uint32_t nb = 0;
+              uint64_t ob = 0;
+              const int64_t used = bgzf_plan(img, fsize, pos, c->inf_cap, c->comp_cap, kMaxBlocksPerChunk, c->h_blk[b], &nb, &ob);
+              if (used < 0) return SCFQ_EGZ;
+              if (used == 0) break;
+              const uint8_t* src = img + pos;
+              parallel_pieces((uint64_t)used, [&](uint64_t o, uint64_t len) { std::memcpy(c->h_comp[b] + o, src + o, len); return 0; });
+              if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));
+              HIPCHK(hipMemcpyAsync(c->d_comp[b], c->h_comp[b], (size_t)used, hipMemcpyHostToDevice, c->copy));
+              HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
+              HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
+              HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));
+              if (nb) {
+                hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
+                                   dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsHalfwords * 2,
+                                   c->compute, c->d_comp[b], c->d_blk[b], nb, d_buf + off, c->d_dstatus);
+                HIPCHK(hipGetLastError());
+              }
+              HIPCHK(hipEventRecord(c->ev_scanned[b], c->compute));
+              pos += (uint64_t)used;
+              off += ob;
+            }
+            uint32_t st = 0;
+            HIPCHK(hipMemcpyAsync(c->h_state + kStateWords - 1, c->d_dstatus, sizeof(uint32_t), hipMemcpyDeviceToHost, c->compute));
+            HIPCHK(hipStreamSynchronize(c->compute));
+            std::memcpy(&st, c->h_state + kStateWords - 1, sizeof st);
+            if (st || off != total) { std::snprintf(g_err, sizeof g_err, "device inflate: error mask 0x%x", st); return SCFQ_EGZ; }
+            *dptr_out = d_buf;
+            *n_out = total;
+            d_buf = nullptr;
+            return SCFQ_OK;
+          }
+          if (rc != kFallbackToHost) return rc;
+          rc = SCFQ_OK;
+        }
+      } else {
+        close(bfd);
+      }
+    } else if (bfd >= 0) {
+      close(bfd);
+    }
+  }
   if (is_gz) {
     fd = open(path, O_RDONLY);
     if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) hint = std::max<uint64_t>(hint, 4 * (uint64_t)sb.st_size);

@@ -107,3 +107,23 @@ def test_count_file_with_device_inflate(gpu, scfq, oracle, tmp_path):
     with pytest.raises(scfq.ScfqError) as e:
         scfq.count_file(str(g))
     assert e.value.rc == scfq.SCFQ_EGZ
+
+
+def test_dedup_of_a_bgzf_file_is_staged_by_the_device_inflate(gpu, scfq, oracle, tmp_path):
+    data = fastq_bytes(3_000_000, seed=31)
+    data = data + data[: len(data) // 3]                 # the first third again: duplicates (cut mid-record on purpose)
+    want, ost = oracle.dedup(np.frombuffer(data, dtype=np.uint8))
+    for name, blob in (("d.fq.gz", bgzf_file(data)), ("d_tiny.fq.gz", bgzf_file(data, block=2000))):
+        f = tmp_path / name
+        f.write_bytes(blob)
+        out = tmp_path / "out.fq"
+        with open(out, "wb") as fh:
+            st = scfq.dedup_file(str(f), fh.fileno())
+        assert out.read_bytes() == want and (st.duplicates, st.total_reads) == (ost.duplicates, ost.total_reads), name
+    bad = bytearray(bgzf_file(data))
+    bad[len(bad) // 2] ^= 4
+    g = tmp_path / "bad.fq.gz"
+    g.write_bytes(bytes(bad))
+    with pytest.raises(scfq.ScfqError) as e:
+        scfq.dedup_file(str(g), -1)
+    assert e.value.rc == scfq.SCFQ_EGZ
