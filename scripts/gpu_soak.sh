@@ -42,3 +42,38 @@ print("tiles_per_range", os.environ["SCFQ_TILES_PER_RANGE"], "ok (", (plan.bytes
 PY
 done
 echo SOAK OK
+# speculative K3 under repetition and concurrency: the verify / redo hand-off and the shared workgroup histogram
+python - <<'PY'
+import sys, threading
+sys.path.insert(0, "seq-collection_amd/pyhost")
+import torch, scfq
+plan = scfq.synth_plan(0, 11, 1_000_000_000)
+buf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda")
+info = scfq.synth_device(0, 11, plan.records, buf.data_ptr(), plan.bytes)
+ref = scfq.count_device(buf.data_ptr(), plan.bytes, flags=scfq.SCFQ_QUAL_HIST | scfq.SCFQ_HIST_EXACT)
+want = list(ref.qual_hist)
+assert sum(want) == info.bases
+bad = 0
+for rep in range(100):
+    c = scfq.count_device(buf.data_ptr(), plan.bytes, flags=scfq.SCFQ_QUAL_HIST)
+    bad += list(c.qual_hist) != want
+print("100 repeated 1 GB speculative histograms, mismatches:", bad)
+errs = []
+def worker(k):
+    for rep in range(15):
+        c = scfq.count_device(buf.data_ptr(), plan.bytes, flags=scfq.SCFQ_QUAL_HIST | (scfq.SCFQ_STRUCT_CHECK if k & 1 else 0))
+        if list(c.qual_hist) != want: errs.append((k, rep))
+ts = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("6 threads x 15 concurrent speculative histograms, mismatches:", len(errs))
+# fq-dedup repeated (pool reuse) and the device inflate on a BGZF image, repeated
+a, _ = scfq.synth_host(0, 13, scfq.synth_plan(0, 13, 64 << 20).records)
+import numpy as np
+two = np.concatenate([a, a])
+first = scfq.dedup_host(two)[0]
+for rep in range(10):
+    assert scfq.dedup_host(two)[0] == first
+assert first == a.tobytes()
+print("10 repeated de-duplications identical")
+assert bad == 0 and not errs
+PY
