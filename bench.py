@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo backend); the number is not a scaling result")
+    ap.add_argument("--exchange-at-1", action="store_true",
+                    help="rehearsal only: run the N>1 exchange path (helper thread + collective) with a single rank")
     args = ap.parse_args()
 
     import torch
@@ -100,11 +102,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     xdev = dev if args.backend == "nccl" else None     # gloo exchanges CPU tensors
+    exchange = world > 1 or args.exchange_at_1
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    elif exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=0, world_size=1, **kw)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
     kind = 0 if args.workload == "illumina" else 1
@@ -132,34 +140,81 @@ def main():
 
     flags = scfq.SCFQ_TIMING | args.flags
 
+    class Exchanger:
+        """the exchange + rank-ordered fold of a step's partial on ONE persistent helper thread: all_gather, device->host copy
+        and the host fold of step k run while the main thread is inside the (GIL-free) C call that scans step k+1"""
+        def __init__(self):
+            import queue
+            import threading
+            self.q_in, self.q_out = queue.SimpleQueue(), queue.SimpleQueue()
+            self.t = threading.Thread(target=self._run, daemon=True)
+            self.t.start()
+
+        def _run(self):
+            torch.cuda.set_device(dev)          # the current device is thread-local
+            self.dx = scfq_dist.DeviceExchange(dev) if xdev is not None else None
+            while True:
+                partial = self.q_in.get()
+                if partial is None:
+                    return
+                try:
+                    if self.dx is not None:          # RCCL: asynchronous calls only (scfq_dist.DeviceExchange)
+                        self.dx.start(partial)
+                        acc = self.dx.finish()
+                    else:
+                        acc, _ = scfq_dist.finish_exchange(scfq_dist.start_exchange(partial, device=xdev))
+                    self.q_out.put(scfq.finalize(acc))
+                except BaseException as e:      # surfaces in wait()
+                    self.q_out.put(e)
+
+        def submit(self, partial):
+            self.q_in.put(partial)
+            return self
+
+        def wait(self):
+            r = self.q_out.get()
+            if isinstance(r, BaseException):
+                raise r
+            return r
+
+    exchanger = Exchanger() if exchange else None
+
     def step(pending):
-        """one pass over this rank's shard; the exchange of the PREVIOUS step's partial (an RCCL all_gather started right
-        after that step) completes while this step's kernel runs, so only its enqueue cost is on the critical path"""
+        """one pass over this rank's shard.  The exchange of a step's partial (an RCCL all_gather issued right after that
+        step, on the helper thread) overlaps the following scans: its kernel only gets CUs when the scan it overlaps drains
+        (the scan fills every CU), so it completes just AFTER that scan; results are therefore collected two steps late and
+        nothing of the exchange is on the critical path except the last two, which are drained inside the timed region"""
         p = scfq.partial_device(shard_ptr, shard_n, prev_byte, flags=flags)
         t = scfq.last_timing()
-        if world == 1:
-            return scfq.finalize(p), t, None
+        if not exchange:
+            return scfq.finalize(p), t, pending
         done = None
-        if pending is not None:
-            acc, _ = scfq_dist.finish_exchange(pending)
-            done = scfq.finalize(acc)
-        return done, t, scfq_dist.start_exchange(p, device=xdev)
+        if len(pending) >= 2:
+            pending.pop(0)
+            done = exchanger.wait()
+        exchanger.submit(p)
+        pending.append(1)
+        return done, t, pending
 
     def drain(pending):
-        acc, _ = scfq_dist.finish_exchange(pending)
-        return scfq.finalize(acc)
+        out = None
+        while pending:
+            pending.pop(0)
+            out = exchanger.wait()
+        return out
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    pending = None
+    pending = []
     for _ in range(args.warmup):
-        counts, _t, pending = step(pending)
-    if pending is not None:
+        c_done, _t, pending = step(pending)
+        if c_done is not None:
+            counts = c_done
+    if pending:
         counts = drain(pending)
-        pending = None
     barrier()
     t_start = time.perf_counter()
     kern_ms = 0.0
@@ -172,9 +227,8 @@ def main():
         if c_done is not None:
             counts = c_done
             seen.add((counts.reads, counts.gc_bases, counts.n_bases, counts.bases, counts.lines))
-    if pending is not None:      # the last step's exchange finishes inside the timed region
+    if pending:                   # the exchanges still in flight finish inside the timed region
         counts = drain(pending)
-        pending = None
         seen.add((counts.reads, counts.gc_bases, counts.n_bases, counts.bases, counts.lines))
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -291,7 +345,9 @@ def main():
                                 "note": "optimised CPU restatement: byte-range shards + the same ordered fold, byte-serial scan per shard"}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if exchange:
+        exchanger.q_in.put(None)
+        exchanger.t.join()
         dist.destroy_process_group()
 
 

@@ -86,3 +86,39 @@ def exchange_partials(partial, device=None, group=None, hist=None):
         h = (ctypes.c_uint64 * scfq.HIST_WORDS)(*_from_i64(rows[r][scfq.PARTIAL_WORDS:])) if hist is not None else None
         scfq.combine(acc, p, acc_h, h)
     return acc, acc_h
+
+
+class DeviceExchange:
+    """The same exchange for a host that keeps scanning while it runs (bench.py's helper thread): every HIP call it makes is
+    asynchronous (pinned staging, a side stream, event polling with short sleeps), because a blocking call issued from a
+    second thread (torch.tensor(list, device=...), .cpu()) was measured to delay the scanning thread's own launches by
+    ~0.1 ms per step through the runtime's locks."""
+
+    def __init__(self, device, group=None, width=scfq.PARTIAL_WORDS):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.width = width
+        self.stream = torch.cuda.Stream(device=device)
+        self.h_in = torch.empty(width, dtype=torch.int64).pin_memory()
+        self.h_out = torch.empty(self.world * width, dtype=torch.int64).pin_memory()
+        self.d_in = torch.empty(width, dtype=torch.int64, device=device)
+        self.d_out = torch.empty(self.world * width, dtype=torch.int64, device=device)
+        self.done = torch.cuda.Event()
+
+    def start(self, partial):
+        self.h_in.copy_(torch.tensor(_to_i64(partial.words()), dtype=torch.int64))
+        with torch.cuda.stream(self.stream):
+            self.d_in.copy_(self.h_in, non_blocking=True)
+            dist.all_gather_into_tensor(self.d_out, self.d_in, group=self.group)     # enqueued behind the copy on this stream
+            self.h_out.copy_(self.d_out, non_blocking=True)
+            self.done.record(self.stream)
+
+    def finish(self, poll_s=5e-5):
+        import time
+        while not self.done.query():
+            time.sleep(poll_s)
+        rows = self.h_out.view(self.world, self.width).tolist()
+        acc = scfq.identity()
+        for r in range(self.world):
+            scfq.combine(acc, scfq.Partial.from_words(_from_i64(rows[r])))
+        return acc
