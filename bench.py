@@ -172,7 +172,7 @@ def main():
             return self
 
         def wait(self):
-            r = self.q_out.get()
+            r = self.q_out.get(timeout=300)     # a stuck collective fails the run instead of hanging it
             if isinstance(r, BaseException):
                 raise r
             return r
