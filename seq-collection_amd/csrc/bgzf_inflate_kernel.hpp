@@ -268,7 +268,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     if (!__builtin_amdgcn_readfirstlane((int)build_ok[wave])) { err = kErrData; break; }
     // ---- symbols --------------------------------------------------------------------------------------------------
     for (;;) {
-      if (++guard > (1u << 22)) { err = kErrData; break; }
       if (bc < 48) SCFQ_DREFILL();          // a literal/length + distance pair needs at most 15 + 5 + 15 + 13 = 48 bits
       uint32_t e = uni(lit[bb & ((1u << kLitRoot) - 1)]);
       if (e & 0x8000u) {
@@ -276,19 +275,19 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
         bb >>= kLitRoot; bc -= kLitRoot;
       }
       const uint32_t len = e & 15;
-      if (len == 0 || len > bc) { err = kErrData; break; }
+      if (len == 0 || len > bc) { err = kErrData; goto decode_done; }
       bb >>= len; bc -= len;
       const uint32_t sym = (e >> 4) & 0x1FF;
       if (sym < 256) {
-        if (pos >= isize) { err = kErrLength; break; }
+        if (pos >= isize) { err = kErrLength; goto decode_done; }
         if (lane == 0) o[pos] = (uint8_t)sym;
         ++pos;
         continue;
       }
       if (sym == 256) break;
-      if (sym > 285) { err = kErrData; break; }
+      if (sym > 285) { err = kErrData; goto decode_done; }
       const uint32_t lx = uni(s_len_extra[sym - 257]);
-      if (lx > bc) { err = kErrData; break; }
+      if (lx > bc) { err = kErrData; goto decode_done; }
       const uint32_t mlen = uni(s_len_base[sym - 257]) + ((uint32_t)bb & ((1u << lx) - 1));
       bb >>= lx; bc -= lx;
       if (bc < 28) SCFQ_DREFILL();
@@ -298,22 +297,21 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
         bb >>= kDistRoot; bc -= kDistRoot;
       }
       const uint32_t dl = d & 15;
-      if (dl == 0 || dl > bc) { err = kErrData; break; }
+      if (dl == 0 || dl > bc) { err = kErrData; goto decode_done; }
       bb >>= dl; bc -= dl;
       const uint32_t dsym = (d >> 4) & 0x1FF;
-      if (dsym >= 30) { err = kErrData; break; }
+      if (dsym >= 30) { err = kErrData; goto decode_done; }
       const uint32_t dx = uni(s_dist_extra[dsym]);
-      if (dx > bc) { err = kErrData; break; }
+      if (dx > bc) { err = kErrData; goto decode_done; }
       const uint32_t off = uni(s_dist_base[dsym]) + ((uint32_t)bb & ((1u << dx) - 1));
       bb >>= dx; bc -= dx;
-      if (off > pos) { err = kErrData; break; }          // a BGZF member starts with an empty window
-      if (pos + mlen > isize) { err = kErrLength; break; }
+      if (off > pos) { err = kErrData; goto decode_done; }          // a BGZF member starts with an empty window
+      if (pos + mlen > isize) { err = kErrLength; goto decode_done; }
       // The bytes the match reads were stored by this same wave (lane 0's literals, other lanes' earlier copies).  Vector
       // memory instructions of one wave reach the CU's L1 in issue order and the write-through L1 serves later loads of
       // the same CU coherently (the workgroup-scope rule of the AMDGPU memory model: no cache maintenance inside a CU), so
-      // no s_waitcnt vmcnt(0) is needed here — with it, every match waited ~2 us for the wave's outstanding stores and
-      // the kernel ran 10x slower.  SCFQ_DINFLATE_FENCE builds the conservative form; every member's CRC-32 is verified
-      // on the device either way.
+      // no s_waitcnt vmcnt(0) is needed here.  SCFQ_DINFLATE_FENCE builds the conservative form (measured: same speed,
+      // the kernel is bound by scalar instruction issue); every member's CRC-32 is verified on the device either way.
 #ifdef SCFQ_DINFLATE_FENCE
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -326,6 +324,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       pos += mlen;
     }
   }
+decode_done:
   if (err == kOk && pos != isize) err = kErrLength;
   // ---- CRC-32 of the member: every lane the standard CRC of a contiguous slice, then 63 combines ------------------------
   if (err == kOk) {
