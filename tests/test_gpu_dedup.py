@@ -129,3 +129,28 @@ def test_hash_collisions_are_resolved_exactly(gpu, scfq, oracle):
     env = dict(os.environ, SCFQ_DEDUP_HASH_BITS="4")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "collisions ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_large_input_properties(gpu, scfq):
+    """size-independent properties at a few GB (no oracle needed): doubling the input changes nothing but the statistics,
+    de-duplication is idempotent, and every record is either echoed or counted as a duplicate"""
+    torch = gpu
+    plan = scfq.synth_plan(0, 20260101, 1 << 30)
+    n1 = plan.bytes
+    buf = torch.empty(3 * n1 + 4096, dtype=torch.uint8, device="cuda")
+    scfq.synth_device(0, 20260101, plan.records, buf.data_ptr(), n1)
+    buf[n1:2 * n1] = buf[:n1]
+    buf[2 * n1:3 * n1] = buf[:n1]
+    out1 = torch.empty(n1 + 4096, dtype=torch.uint8, device="cuda")
+    out3 = torch.empty(n1 + 4096, dtype=torch.uint8, device="cuda")
+    nb1, st1 = scfq.dedup_device(buf.data_ptr(), n1, out1.data_ptr(), n1)
+    nb3, st3 = scfq.dedup_device(buf.data_ptr(), 3 * n1, out3.data_ptr(), n1)
+    assert st1.total_reads == plan.records and st3.total_reads == 3 * plan.records
+    assert st1.records_out + st1.duplicates == plan.records and st3.records_out + st3.duplicates == 3 * plan.records
+    assert nb3 == nb1 and st3.records_out == st1.records_out and st3.duplicates == st1.duplicates + 2 * plan.records
+    assert torch.equal(out1[:nb1], out3[:nb3])                       # the copies add nothing
+    again = torch.empty(nb1 + 4096, dtype=torch.uint8, device="cuda")
+    nb2, st2 = scfq.dedup_device(out1.data_ptr(), nb1, again.data_ptr(), nb1)
+    assert nb2 == nb1 and st2.duplicates == 0 and torch.equal(again[:nb2], out1[:nb1])     # idempotent
+    # the generator's IDs are nearly unique: what is dropped from a single copy is a handful of chance repeats
+    assert st1.duplicates < plan.records // 1000
