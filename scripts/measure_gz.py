@@ -43,8 +43,9 @@ with open(bgz, "wb") as f:
     for b in blobs: f.write(b)
 expect = [plan.records, info.gc_bases, info.n_bases, info.bases]
 for label, path in (("gzip -6, one member", plain + ".gz"), ("BGZF", bgz)):
-    for mode in ("own", "zlib") + (("device",) if label == "BGZF" else ()):
-        env = dict(os.environ, SCFQ_INFLATE="own" if mode == "device" else mode, SCFQ_BGZF_DEVICE="1" if mode == "device" else "0")
+    for mode in ("own", "zlib") + (("device",) if label == "BGZF" else ("own, one thread",)):
+        env = dict(os.environ, SCFQ_INFLATE="zlib" if mode == "zlib" else "own", SCFQ_BGZF_DEVICE="1" if mode == "device" else "0",
+                   SCFQ_PGZ="0" if mode == "own, one thread" else "1")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", path], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         j = json.loads(r.stdout.strip().splitlines()[-1])

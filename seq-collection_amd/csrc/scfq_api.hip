@@ -12,6 +12,7 @@
 #include "fq_scan_kernels.hpp"
 #include "scfq_bgzf.hpp"
 #include "scfq_gzfast.hpp"
+#include "scfq_pgz.hpp"
 #include "bgzf_inflate_kernel.hpp"
 
 #include <fcntl.h>

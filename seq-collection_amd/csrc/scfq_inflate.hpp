@@ -32,7 +32,7 @@ static const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 
 static const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-enum Status { kNeedOutput = 0, kStreamEnd = 1, kErrData = -1, kErrTruncated = -2 };
+enum Status { kNeedOutput = 0, kStreamEnd = 1, kAtBoundary = 3, kErrData = -1, kErrTruncated = -2 };
 
 struct Decoder {
   // ---- input: the whole compressed stream is addressable (mmap / buffer); `in_safe` = last address from which an 8-byte
@@ -49,9 +49,21 @@ struct Decoder {
   uint32_t lit[kLitSize];
   uint32_t dist[kDistSize];
 
+  const uint8_t* in_base = nullptr;   // bit positions are counted from here
+  uint64_t stop_bit = ~0ull;          // run16: return kAtBoundary at the first block boundary at or after this bit
+
   void begin(const uint8_t* p, const uint8_t* end) {
-    in_next = p; in_end = end; bitbuf = 0; bitcnt = 0; state = kHeader; last_block = false; stored_left = 0; total_out = 0;
+    in_base = p; in_next = p; in_end = end; bitbuf = 0; bitcnt = 0; state = kHeader; last_block = false; stored_left = 0; total_out = 0;
+    stop_bit = ~0ull;
   }
+  // start in the middle of a stream: `bit` is the position, relative to base, of a block header
+  void begin_at_bit(const uint8_t* base, const uint8_t* end, uint64_t bit) {
+    begin(base, end);
+    in_next = base + (bit >> 3);
+    refill();
+    drop((int)(bit & 7));
+  }
+  uint64_t bitpos() const { return (uint64_t)(in_next - in_base) * 8 - bitcnt; }
   // first byte after the deflate stream (valid after kStreamEnd): whole unread bytes of the bit buffer are given back
   const uint8_t* end_of_stream() const { return in_next - (bitcnt >> 3); }
 
@@ -417,6 +429,99 @@ struct Decoder {
     bitbuf = bb;
     bitcnt = bc;
     return result;
+  }
+
+  // ---- symbol output (scfq_pgz.hpp): the same stream decoded into 16-bit symbols.  The caller places 32768 symbols in
+  // front of the output (markers 0x8000 | k for "byte k of the window I do not know yet", or the real bytes) and sets
+  // total_out = 32768, so back-references copy symbols, known or not, and are resolved later.  Stops with kAtBoundary at the
+  // first block boundary whose bit position is >= stop_bit.  Plain careful loop: this path is run by many threads at once.
+  int run16(uint16_t*& out_next, uint16_t* out_end) {
+    for (;;) {
+      if (state == kDone) return kStreamEnd;
+      if (state == kHeader) {
+        if (bitpos() >= stop_bit) return kAtBoundary;
+        refill();
+        if (bitcnt < 3) return kErrTruncated;
+        last_block = peek(1); drop(1);
+        const uint32_t type = peek(2); drop(2);
+        if (type == 0) {
+          drop((int)(bitcnt & 7));
+          refill();
+          if (bitcnt < 32) return kErrTruncated;
+          const uint32_t len = peek(16), nlen = (uint32_t)((bitbuf >> 16) & 0xFFFF);
+          if ((len ^ nlen) != 0xFFFF) return kErrData;
+          drop(32);
+          in_next -= bitcnt >> 3;
+          bitbuf = 0; bitcnt = 0;
+          stored_left = len;
+          state = kStored;
+        } else if (type == 1) { load_fixed(); state = kHuff; }
+        else if (type == 2) { if (!read_dynamic_header()) return kErrData; state = kHuff; }
+        else return kErrData;
+      }
+      if (state == kStored) {
+        const uint64_t room = (uint64_t)(out_end - out_next), avail = (uint64_t)(in_end - in_next);
+        uint64_t k = stored_left;
+        if (k > room) k = room;
+        if (k > avail) k = avail;
+        for (uint64_t i = 0; i < k; ++i) out_next[i] = in_next[i];
+        out_next += k; in_next += k; stored_left -= (uint32_t)k; total_out += k;
+        if (stored_left) {
+          if (in_next == in_end) return kErrTruncated;
+          return kNeedOutput;
+        }
+        state = last_block ? kDone : kHeader;
+        continue;
+      }
+      uint16_t* out = out_next;
+      int result = kBlockEnd;
+      for (;;) {
+        if ((uint64_t)(out_end - out) < kOutSlack) { result = kNeedOutput; break; }
+        refill();
+        uint32_t e = lit[bitbuf & ((1u << kLitRoot) - 1)];
+        if (e & F_SUB) {
+          e = lit[e_val(e) + ((bitbuf >> kLitRoot) & ((1u << e_extra(e)) - 1))];
+          drop(kLitRoot);
+        }
+        const uint32_t len = e_len(e);
+        if (len == 0) { result = kErrData; break; }
+        if (len > bitcnt) { result = bitcnt_error(); break; }
+        drop((int)len);
+        if (e & F_LITERAL) { *out++ = (uint16_t)e_val(e); continue; }
+        if (e & F_EOB) { state = last_block ? kDone : kHeader; break; }
+        const uint32_t lx = e_extra(e);
+        if (lx > bitcnt) { result = bitcnt_error(); break; }
+        const uint32_t mlen = e_val(e) + peek((int)lx);
+        drop((int)lx);
+        if (bitcnt < 15 + 13) refill();
+        uint32_t d = dist[bitbuf & ((1u << kDistRoot) - 1)];
+        if (d & F_SUB) {
+          d = dist[e_val(d) + ((bitbuf >> kDistRoot) & ((1u << e_extra(d)) - 1))];
+          drop(kDistRoot);
+        }
+        const uint32_t dl = e_len(d);
+        if (dl == 0) { result = kErrData; break; }
+        if (dl > bitcnt) { result = bitcnt_error(); break; }
+        drop((int)dl);
+        const uint32_t dx = e_extra(d);
+        if (dx > bitcnt) { result = bitcnt_error(); break; }
+        const uint32_t off = e_val(d) + peek((int)dx);
+        drop((int)dx);
+        if (off > total_out + (uint64_t)(out - out_next)) { result = kErrData; break; }
+        const uint16_t* src = out - off;
+        uint16_t* dst = out;
+        out += mlen;
+        if (off >= 4) {
+          uint16_t* const stop = dst + mlen;
+          do { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); src += 4; dst += 4; } while (dst < stop);
+        } else {
+          for (uint32_t k = 0; k < mlen; ++k) dst[k] = src[k];
+        }
+      }
+      total_out += (uint64_t)(out - out_next);
+      out_next = out;
+      if (result != kBlockEnd) return result;
+    }
   }
 
   int bitcnt_error() const { return in_next >= in_end ? kErrTruncated : kErrData; }

@@ -100,6 +100,15 @@ struct FastGzSource : Source {
   }
 };
 
+// the same stream inflated by many threads (scfq_pgz.hpp); files of 8 MiB and more, SCFQ_PGZ=0 keeps the serial reader
+struct ParallelGzSource : Source {
+  scfq_pgz::Stream st;
+  int64_t fill(uint8_t* dst, uint64_t cap) override {
+    const int64_t r = st.next_chunk(dst, cap);
+    return r < 0 ? (int64_t)SCFQ_EGZ : r;
+  }
+};
+
 bool use_own_inflate() {
   static const bool v = [] { const char* e = std::getenv("SCFQ_INFLATE"); return !(e && e[0] == 'z'); }();
   return v;
@@ -111,6 +120,11 @@ bool use_own_inflate() {
 std::unique_ptr<Source> open_gz_source(const char* path, uint64_t chunk, gzFile* gz_out) {
   *gz_out = nullptr;
   if (use_own_inflate() && chunk >= (1u << 16)) {
+    static const bool pgz = [] { const char* e = std::getenv("SCFQ_PGZ"); return !(e && e[0] == '0'); }();
+    if (pgz) {
+      auto pz = std::make_unique<ParallelGzSource>();
+      if (pz->st.open(path)) return pz;
+    }
     auto f = std::make_unique<FastGzSource>();
     if (f->st.open(path)) return f;
   }

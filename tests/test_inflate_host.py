@@ -154,3 +154,74 @@ def test_zlib_switch_gives_the_same_bytes(scfq, tmp_path):
     for mode in ("zlib", "own"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SCFQ_INFLATE=mode), capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.strip() == hashlib.sha256(data).hexdigest(), (mode, r.stderr)
+
+
+def pgz_env(**kw):
+    """the parallel single-member reader (csrc/scfq_pgz.hpp) on test-sized files: tiny segments, no minimum file size"""
+    env = {"SCFQ_PGZ_MIN_MB": "0", "SCFQ_PGZ_SEGMENT_MB": "1"}
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+class EnvPatch:
+    def __init__(self, env):
+        self.env = env
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_parallel_single_member_equals_zlib(scfq, tmp_path):
+    """many threads on ONE member: sync search, marker symbols, window resolution, CRC by pieces"""
+    rng = np.random.default_rng(17)
+    big = fastq_bytes(40_000_000, seed=3)
+    cases = {
+        "fastq level 6": gzip.compress(big, compresslevel=6, mtime=0),
+        "fastq level 1": gzip.compress(big, compresslevel=1, mtime=0),
+        "fastq level 9": gzip.compress(big[:12_000_000], compresslevel=9, mtime=0),
+        "long matches": gzip.compress((b"ACGTN" * 7 + b"\n") * 400_000, mtime=0),
+        "zeros": gzip.compress(bytes(30_000_000), mtime=0),
+        "stored (incompressible)": gzip.compress(rng.integers(0, 256, 6_000_000, dtype=np.uint8).tobytes(), mtime=0),
+        "fixed huffman": gz_member(big[:5_000_000], raw_deflate(big[:5_000_000], 6, zlib.Z_FIXED)),
+        "members": gzip.compress(big[:9_000_000], mtime=0) + gzip.compress(big[9_000_000:20_000_000], compresslevel=1, mtime=0)
+                   + gz_member(b"") + gzip.compress(big[20_000_000:], mtime=0) + b"trailing garbage",
+    }
+    with EnvPatch(pgz_env()):
+        for name, blob in cases.items():
+            want = gzip.decompress(blob[:-16] if name == "members" else blob) if name != "members" else big
+            for chunk in (1 << 16, 1 << 22, 0):
+                assert read(scfq, tmp_path, blob, len(want) + 16, chunk) == want, (name, chunk)
+    with EnvPatch(pgz_env(SCFQ_PGZ_SEGMENT_MB=3)):
+        assert read(scfq, tmp_path, cases["fastq level 6"], len(big) + 16, 1 << 20) == big
+
+
+def test_parallel_reader_rejects_what_zlib_rejects(scfq, tmp_path):
+    data = fastq_bytes(12_000_000, seed=8)
+    good = bytearray(gzip.compress(data, mtime=0))
+    rng = np.random.default_rng(5)
+    with EnvPatch(pgz_env()):
+        for trial in range(25):
+            blob = bytearray(good)
+            pos = int(rng.integers(10, len(blob)))
+            blob[pos] ^= 1 << int(rng.integers(0, 8))
+            try:
+                want = gzip.decompress(bytes(blob))
+            except Exception:
+                want = None
+            try:
+                got = read(scfq, tmp_path, bytes(blob), len(data) + 65536, 1 << 20)
+            except scfq.ScfqError as e:
+                assert e.rc == scfq.SCFQ_EGZ
+                got = None
+            assert got == want, (trial, pos)
+        for cut in (len(good) // 3, len(good) - 5):
+            with pytest.raises(scfq.ScfqError):
+                read(scfq, tmp_path, bytes(good[:cut]), len(data) + 16, 1 << 20)
