@@ -13,6 +13,7 @@ python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload nanopore 2>/d
 python scripts/measure_ingest.py 2e9 /tmp > gpurun_out/$TAG/ingest.jsonl 2>gpurun_out/$TAG/ingest.err
 python scripts/measure_gz.py 2e9 /tmp > gpurun_out/$TAG/gz_inflate.jsonl 2>gpurun_out/$TAG/gz.err
 python scripts/measure_bgzf_device.py 4e9 > gpurun_out/$TAG/bgzf_device.jsonl 2>gpurun_out/$TAG/bgzf.err
+python scripts/measure_pgz.py 6e9 > gpurun_out/$TAG/gz_single_member_parallel.jsonl 2>gpurun_out/$TAG/pgz.err
 cat gpurun_out/$TAG/bench_dedup.json
 for f in struct hist hist_exact hist_nanopore nanopore; do python -c "import json;d=json.load(open('gpurun_out/$TAG/bench_$f.json'));print('$f',d['value'],d['roofline'])"; done
 cat gpurun_out/$TAG/ingest.jsonl gpurun_out/$TAG/gz_inflate.jsonl gpurun_out/$TAG/bgzf_device.jsonl

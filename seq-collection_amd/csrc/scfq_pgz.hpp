@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -52,7 +53,8 @@ inline bool plausible_block(scfq_inflate::Decoder& d, const uint8_t* base, const
 
 struct Segment {
   uint64_t start_bit = 0, end_bit = 0;               // relative to the member's deflate data
-  std::vector<uint16_t> sym;                         // [kWindow markers or bytes | symbols]
+  std::unique_ptr<uint16_t[]> sym;                   // [kWindow markers or bytes | symbols], never value-initialised
+  size_t cap = 0;
   uint64_t n = 0;                                    // symbols produced
   bool synced = false, ok = false, member_end = false;
 };
@@ -88,9 +90,9 @@ class Stream {
   int64_t next_chunk(uint8_t* dst, uint64_t cap) {
     if (!started_) { started_ = true; th_ = std::thread([this] { produce(); }); }
     for (;;) {
-      if (cur_ && cur_off_ < cur_->bytes.size()) {
-        const uint64_t k = std::min<uint64_t>(cap, cur_->bytes.size() - cur_off_);
-        std::memcpy(dst, cur_->bytes.data() + cur_off_, k);
+      if (cur_ && cur_off_ < cur_->n) {
+        const uint64_t k = std::min<uint64_t>(cap, cur_->n - cur_off_);
+        copy_pieces(dst, cur_->buf.get() + cur_off_, k);
         cur_off_ += k;
         return (int64_t)k;
       }
@@ -113,13 +115,29 @@ class Stream {
  private:
   struct Batch {
     enum State { kFree, kReady } state = kFree;
-    std::vector<uint8_t> bytes;
+    std::unique_ptr<uint8_t[]> buf;                    // never value-initialised (a vector resize zero-fills half a GB per batch)
+    size_t cap = 0;
+    size_t n = 0;                                      // valid bytes
     int status = 0;                                    // 0 more, 1 end of stream, -1 error
   };
 
+  // CPUs this process may really use: the cgroup's CPU quota when there is one (a box shared between GPUs hands each
+  // tenant a slice of its cores; running more threads than the quota gets the whole group throttled for the rest of the
+  // scheduler period, measured here as 3x slower phases), else the hardware count
+  static int usable_cpus() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long quota = 0, period = 0;
+      char q[32] = {0};
+      if (std::fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0) { quota = std::atoll(q); if (quota > 0) n = std::min<int>(n, (int)((quota + period - 1) / period)); }
+      std::fclose(f);
+    }
+    return n;
+  }
   static int n_threads() {
     static const int n = [] { const char* e = std::getenv("SCFQ_INFLATE_THREADS"); int v = e ? std::atoi(e) : 0;
-                              if (v <= 0) v = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())); return std::min(v, 64); }();
+                              if (v <= 0) v = std::max(1, std::min(16, usable_cpus()) - 4);     // room for the ingest thread and its copies
+                              return std::min(v, 64); }();
     return n;
   }
 
@@ -142,9 +160,10 @@ class Stream {
     const uint8_t* data = member + h;                  // deflate data of the current member
     uint64_t bit = 0;                                  // exact position of the next block header, relative to data
     const int T = n_threads();
-    const uint64_t seg_bytes = (uint64_t)std::max(1, env_mb("SCFQ_PGZ_SEGMENT_MB", 8)) << 20;
+    const uint64_t seg_bytes = (uint64_t)std::max(1, env_mb("SCFQ_PGZ_SEGMENT_MB", 4)) << 20;
     const uint64_t search_bytes = std::min<uint64_t>(seg_bytes, 1u << 20);   // a dynamic block starts every few 10 KB in practice
-    std::vector<std::vector<uint16_t>> symbuf((size_t)T);                      // reused from batch to batch
+    std::vector<std::unique_ptr<uint16_t[]>> symbuf((size_t)T);                // reused from batch to batch
+    std::vector<size_t> symcap((size_t)T, 0);
     for (;;) {
       Batch* B = &batches_[put];
       {
@@ -152,8 +171,16 @@ class Stream {
         cv_.wait(lk, [&] { return stop_ || B->state == Batch::kFree; });
         if (stop_) return;
       }
-      B->bytes.clear();
+      B->n = 0;
       B->status = 0;
+      const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
+      auto t_mark = std::chrono::steady_clock::now();
+      auto lap = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "scfq pgz:   %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+        t_mark = now;
+      };
       // ---- plan: segment k starts at the first plausible block at or after data + bit/8 + k * seg_bytes ----------------
       std::vector<Segment> seg((size_t)T);
       const uint64_t base_byte = bit >> 3;
@@ -172,6 +199,7 @@ class Stream {
           if (plausible_block(*d, data, file_end, b, scratch)) { seg[k].start_bit = b; seg[k].synced = true; return; }
         }
       });
+      lap("sync search");
       // segments are only usable as an unbroken chain from segment 0
       int n_seg = 1;
       while (n_seg < T && seg[n_seg].synced) ++n_seg;
@@ -183,23 +211,29 @@ class Stream {
         d->total_out = (k == 0) ? window_valid : kWindow;       // segment 0 knows how much history really exists
         d->stop_bit = (k + 1 < n_seg) ? seg[k + 1].start_bit : (base_byte + (uint64_t)(k + 1) * seg_bytes) * 8;
         S.sym.swap(symbuf[(size_t)k]);
-        if (S.sym.size() < kWindow + (size_t)seg_bytes * 5 + scfq_inflate::kOutSlack) S.sym.resize(kWindow + (size_t)seg_bytes * 5 + scfq_inflate::kOutSlack);
+        S.cap = symcap[(size_t)k];
+        if (S.cap < kWindow + (size_t)seg_bytes * 5 + scfq_inflate::kOutSlack) {
+          S.cap = kWindow + (size_t)seg_bytes * 5 + scfq_inflate::kOutSlack;
+          S.sym.reset(new uint16_t[S.cap]);
+        }
         if (k == 0) {
           for (uint32_t i = 0; i < kWindow; ++i) S.sym[i] = window[i];                    // exact window: plain bytes
         } else {
           for (uint32_t i = 0; i < kWindow; ++i) S.sym[i] = (uint16_t)(0x8000u | i);      // markers
         }
-        uint16_t* out = S.sym.data() + kWindow;
+        uint16_t* out = S.sym.get() + kWindow;
         for (;;) {
-          // the first block header of a segment must be consumed even when stop_bit <= start (k+1's start > k's start always)
-          const int r = d->run16(out, S.sym.data() + S.sym.size());
-          if (r == scfq_inflate::kNeedOutput) {
-            const size_t used = (size_t)(out - S.sym.data());
-            S.sym.resize(S.sym.size() * 2);
-            out = S.sym.data() + used;
+          const int r = d->run16(out, S.sym.get() + S.cap);
+          if (r == scfq_inflate::kNeedOutput) {              // better compression than planned for: a bigger buffer
+            const size_t used = (size_t)(out - S.sym.get());
+            std::unique_ptr<uint16_t[]> bigger(new uint16_t[S.cap * 2]);
+            std::memcpy(bigger.get(), S.sym.get(), used * sizeof(uint16_t));
+            S.sym.swap(bigger);
+            S.cap *= 2;
+            out = S.sym.get() + used;
             continue;
           }
-          S.n = (uint64_t)(out - (S.sym.data() + kWindow));
+          S.n = (uint64_t)(out - (S.sym.get() + kWindow));
           S.end_bit = d->bitpos();
           if (r == scfq_inflate::kAtBoundary) S.ok = true;
           else if (r == scfq_inflate::kStreamEnd) { S.ok = true; S.member_end = true; end_ptr_[k] = d->end_of_stream(); }
@@ -207,6 +241,7 @@ class Stream {
           return;
         }
       });
+      lap("decode to symbols");
       // ---- keep the unbroken, consistent prefix of the chain ------------------------------------------------------------
       int good = 0;
       bool member_end = false;
@@ -227,7 +262,7 @@ class Stream {
         const Segment& S = seg[k];
         off[k + 1] = off[k] + S.n;
         // tail of (window_k ++ symbols_k), resolved through window_k
-        const uint16_t* all = S.sym.data();                // [kWindow | n]: position p of the concatenation
+        const uint16_t* all = S.sym.get();                 // [kWindow | n]: position p of the concatenation
         const uint64_t total = kWindow + S.n;
         for (uint32_t i = 0; i < kWindow; ++i) {
           const uint16_t v = all[total - kWindow + i];
@@ -235,10 +270,12 @@ class Stream {
         }
         if (k == 0) continue;
       }
+      lap("window tails");
       // a marker that points into a part of the window that does not exist (before the member's start) is corrupt data
       // (the serial decoder's "distance too far back"): checked per segment below with window_valid
       // ---- resolve + CRC, in parallel ---------------------------------------------------------------------------------------
-      B->bytes.resize((size_t)off[good]);
+      if (B->cap < off[good]) { B->cap = (size_t)off[good] + (size_t)(off[good] >> 3); B->buf.reset(new uint8_t[B->cap]); }
+      B->n = (size_t)off[good];
       std::vector<uint32_t> part_crc((size_t)good, 0);
       std::atomic<int> bad{0};
       std::vector<uint64_t> valid((size_t)good + 1, 0);
@@ -246,19 +283,42 @@ class Stream {
       for (int k = 0; k < good; ++k) valid[k + 1] = std::min<uint64_t>(kWindow, valid[k] + seg[k].n);
       parallel(good, [&](int k) {
         const Segment& S = seg[k];
-        uint8_t* o = B->bytes.data() + off[k];
-        const uint16_t* s = S.sym.data() + kWindow;
+        uint8_t* o = B->buf.get() + off[k];
+        const uint16_t* s = S.sym.get() + kWindow;
         const uint8_t* w = win[k].data();
         const uint32_t missing = (uint32_t)(kWindow - valid[k]);       // window slots [0, missing) do not exist
         uint32_t or_bad = 0;
-        for (uint64_t i = 0; i < S.n; ++i) {
+        uint64_t i = 0;
+        // markers are rare once the first 32 KiB of a segment have been written: 16 symbols at a time, the scalar path only
+        // for groups that contain one
+        for (; i + 16 <= S.n; i += 16) {
+          uint64_t w0, w1, w2, w3;
+          std::memcpy(&w0, s + i, 8); std::memcpy(&w1, s + i + 4, 8); std::memcpy(&w2, s + i + 8, 8); std::memcpy(&w3, s + i + 12, 8);
+          if (((w0 | w1 | w2 | w3) & 0x8000800080008000ull) == 0) {
+            // pack the low bytes of 4 x u16 into 4 bytes, four times
+            auto pack = [](uint64_t x) { x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull; return (uint32_t)((x | (x >> 16)) & 0xFFFFFFFFull); };
+            const uint32_t p0 = pack(w0), p1 = pack(w1), p2 = pack(w2), p3 = pack(w3);
+            std::memcpy(o + i, &p0, 4); std::memcpy(o + i + 4, &p1, 4); std::memcpy(o + i + 8, &p2, 4); std::memcpy(o + i + 12, &p3, 4);
+          } else {
+            for (uint64_t j = i; j < i + 16; ++j) {
+              const uint16_t v = s[j];
+              if (v & 0x8000u) { const uint32_t idx = v & 0x7FFFu; or_bad |= (idx < missing); o[j] = w[idx]; }
+              else o[j] = (uint8_t)v;
+            }
+          }
+        }
+        for (; i < S.n; ++i) {
           const uint16_t v = s[i];
           if (v & 0x8000u) { const uint32_t idx = v & 0x7FFFu; or_bad |= (idx < missing); o[i] = w[idx]; }
           else o[i] = (uint8_t)v;
         }
         if (or_bad) bad = 1;
+        const auto tc0 = std::chrono::steady_clock::now();
         part_crc[k] = (uint32_t)crc32_z(0L, o, (size_t)S.n);
+        if (verbose && k == 1) std::fprintf(stderr, "scfq pgz:     (segment 1: %llu bytes, crc32 alone %.1f ms)\n", (unsigned long long)S.n,
+                                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
       });
+      lap("resolve + crc");
       if (bad) { B->status = -1; publish(B); return; }
       for (int k = 0; k < good; ++k) {
         crc = (uint32_t)crc32_combine(crc, part_crc[k], (z_off_t)seg[k].n);
@@ -267,7 +327,7 @@ class Stream {
       window = win[good];
       window_valid = valid[good];
       bit = seg[good - 1].end_bit;
-      for (int k = 0; k < n_seg; ++k) symbuf[(size_t)k].swap(seg[(size_t)k].sym);
+      for (int k = 0; k < n_seg; ++k) { symbuf[(size_t)k].swap(seg[(size_t)k].sym); symcap[(size_t)k] = seg[(size_t)k].cap; }
       if (member_end) {
         // trailer, then another member or the end (gzread: trailing garbage is ignored)
         if (!end_ptr || end_ptr > file_end || file_end - end_ptr < 8) { B->status = -1; publish(B); return; }
@@ -292,6 +352,12 @@ class Stream {
   void publish(Batch* B) {
     { std::lock_guard<std::mutex> lk(mu_); B->state = Batch::kReady; }
     cv_.notify_all();
+  }
+
+  // the consumer's copy into the staging buffer, split over a few threads (one core moves ~10 GB/s)
+  static void copy_pieces(uint8_t* dst, const uint8_t* src, uint64_t n) {
+    if (n < (8u << 20)) { std::memcpy(dst, src, n); return; }
+    parallel(2, [&](int k) { const uint64_t lo = n * (uint64_t)k / 2, hi = n * (uint64_t)(k + 1) / 2; std::memcpy(dst + lo, src + lo, hi - lo); });
   }
 
   static int env_mb(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
