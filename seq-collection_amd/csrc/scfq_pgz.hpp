@@ -59,11 +59,16 @@ struct Segment {
   bool synced = false, ok = false, member_end = false;
 };
 
+// streams open at the same time in this process (sc fq-count --jobs=N): they share the CPU budget
+inline std::atomic<int>& active_streams() { static std::atomic<int> n{0}; return n; }
+
 class Stream {
  public:
   ~Stream() { close(); }
 
   bool open(const char* path) {
+    // fewer than 4 threads per stream left: the serial reader (one decoder thread + the ingest thread) is the better use
+    if ((active_streams().load() + 1) * 4 > n_threads()) return false;
     fd_ = ::open(path, O_RDONLY);
     if (fd_ < 0) return false;
     struct stat sb;
@@ -73,10 +78,13 @@ class Stream {
     if (m == MAP_FAILED) { close(); return false; }
     map_ = static_cast<const uint8_t*>(m);
     if (member_header(map_, n_) <= 0) { close(); return false; }
+    counted_ = true;
+    active_streams()++;
     return true;
   }
 
   void close() {
+    if (counted_) { active_streams()--; counted_ = false; }
     if (th_.joinable()) {
       { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
       cv_.notify_all();
@@ -159,11 +167,11 @@ class Stream {
     long h = member_header(member, (size_t)(file_end - member));
     const uint8_t* data = member + h;                  // deflate data of the current member
     uint64_t bit = 0;                                  // exact position of the next block header, relative to data
-    const int T = n_threads();
+    const int T_max = n_threads();
     const uint64_t seg_bytes = (uint64_t)std::max(1, env_mb("SCFQ_PGZ_SEGMENT_MB", 4)) << 20;
     const uint64_t search_bytes = std::min<uint64_t>(seg_bytes, 1u << 20);   // a dynamic block starts every few 10 KB in practice
-    std::vector<std::unique_ptr<uint16_t[]>> symbuf((size_t)T);                // reused from batch to batch
-    std::vector<size_t> symcap((size_t)T, 0);
+    std::vector<std::unique_ptr<uint16_t[]>> symbuf((size_t)T_max);            // reused from batch to batch
+    std::vector<size_t> symcap((size_t)T_max, 0);
     for (;;) {
       Batch* B = &batches_[put];
       {
@@ -173,6 +181,7 @@ class Stream {
       }
       B->n = 0;
       B->status = 0;
+      const int T = std::max(2, T_max / std::max(1, active_streams().load()));      // this batch's share of the CPU budget
       const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
       auto t_mark = std::chrono::steady_clock::now();
       auto lap = [&](const char* what) {
@@ -372,7 +381,7 @@ class Stream {
   std::thread th_;
   std::mutex mu_;
   std::condition_variable cv_;
-  bool stop_ = false, started_ = false, finished_ = false, failed_ = false;
+  bool stop_ = false, started_ = false, finished_ = false, failed_ = false, counted_ = false;
   int take_ = 0;
 };
 
