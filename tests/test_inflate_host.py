@@ -225,3 +225,29 @@ def test_parallel_reader_rejects_what_zlib_rejects(scfq, tmp_path):
         for cut in (len(good) // 3, len(good) - 5):
             with pytest.raises(scfq.ScfqError):
                 read(scfq, tmp_path, bytes(good[:cut]), len(data) + 16, 1 << 20)
+
+
+def test_parallel_reader_false_syncs_and_thread_counts(scfq, tmp_path):
+    """(a) a stored (level 0) member whose payload is itself a deflate stream: every sync search lands on a REAL block header
+    that belongs to the inner stream, not to the member being read — the chain check (the segment before must end exactly
+    there) has to throw those away; (b) odd thread counts and segment sizes, in fresh processes (the thread count is read once)"""
+    inner_plain = fastq_bytes(14_000_000, seed=13)
+    inner = gzip.compress(inner_plain, compresslevel=6, mtime=0)           # ~3.5 MB of dynamic blocks
+    payload = inner * 4 + inner_plain[:3_000_000]
+    outer = gz_member(payload, raw_deflate(payload, 0))                     # stored blocks only
+    assert gzip.decompress(outer) == payload
+    with EnvPatch(pgz_env()):
+        assert read(scfq, tmp_path, outer, len(payload) + 16, 1 << 20) == payload
+    mixed = gzip.compress(inner_plain[:6_000_000], mtime=0)[:-8]            # a member cut before its trailer ...
+    data = fastq_bytes(20_000_000, seed=14)
+    f = tmp_path / "t.fq.gz"
+    f.write_bytes(gzip.compress(data, compresslevel=6, mtime=0))
+    code = ("import sys; sys.path.insert(0, %r); import scfq, hashlib; "
+            "print(hashlib.sha256(scfq.debug_read_file(%r, %d, 1 << 21)).hexdigest())") % (
+        os.path.join(os.path.dirname(HERE), "seq-collection_amd", "pyhost"), str(f), len(data) + 16)
+    import hashlib
+    want = hashlib.sha256(data).hexdigest()
+    for threads, seg in ((2, 1), (7, 1), (5, 2), (16, 1)):
+        env = dict(os.environ, **pgz_env(SCFQ_INFLATE_THREADS=threads, SCFQ_PGZ_SEGMENT_MB=seg))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == want, (threads, seg, r.stderr[-300:])
