@@ -11,6 +11,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "scfq_crc32.hpp"
 #include "scfq_inflate.hpp"
 
 #include <algorithm>
@@ -72,7 +73,7 @@ inline int inflate_blocks(const uint8_t* cbuf, const std::vector<Block>& blocks,
     uint8_t* out = scratch.data();
     const int r = dec->run(out, scratch.data() + scratch.size());
     if (r != scfq_inflate::kStreamEnd || (uint32_t)(out - scratch.data()) != b.isize) return -1;
-    if ((uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), scratch.data(), b.isize) != b.crc) return -1;
+    if (scfq_crc::crc32(0u, scratch.data(), b.isize) != b.crc) return -1;
     std::memcpy(dst + b.out_off, scratch.data(), b.isize);
   }
   return 0;

@@ -9,6 +9,7 @@
 // three consecutive chunks overlap.  Files that do not start with a gzip member (zlib would pass them through
 // unchanged), FIFOs and anything that cannot be mmap'd are left to the zlib path by the caller (open() returns false).
 #pragma once
+#include "scfq_crc32.hpp"
 #include "scfq_inflate.hpp"
 
 #include <fcntl.h>
@@ -123,7 +124,7 @@ class Stream {
   static uint32_t crc_and_copy(uint32_t crc, const uint8_t* src, uint8_t* dst, size_t n) {
     if (n < (4u << 20)) {
       std::memcpy(dst, src, n);
-      return (uint32_t)crc32_z(crc, src, n);
+      return scfq_crc::crc32(crc, src, n);
     }
     uint32_t part[kPieces];
     size_t lo[kPieces + 1];
@@ -131,7 +132,7 @@ class Stream {
     std::thread th[kPieces - 1];
     auto work = [&](int k) {
       std::memcpy(dst + lo[k], src + lo[k], lo[k + 1] - lo[k]);
-      part[k] = (uint32_t)crc32_z(k == 0 ? crc : 0L, src + lo[k], lo[k + 1] - lo[k]);
+      part[k] = scfq_crc::crc32(k == 0 ? crc : 0u, src + lo[k], lo[k + 1] - lo[k]);
     };
     for (int k = 1; k < kPieces; ++k) th[k - 1] = std::thread(work, k);
     work(0);

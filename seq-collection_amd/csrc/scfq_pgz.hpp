@@ -323,7 +323,7 @@ class Stream {
         }
         if (or_bad) bad = 1;
         const auto tc0 = std::chrono::steady_clock::now();
-        part_crc[k] = (uint32_t)crc32_z(0L, o, (size_t)S.n);
+        part_crc[k] = scfq_crc::crc32(0u, o, (size_t)S.n);
         if (verbose && k == 1) std::fprintf(stderr, "scfq pgz:     (segment 1: %llu bytes, crc32 alone %.1f ms)\n", (unsigned long long)S.n,
                                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
       });
