@@ -234,6 +234,10 @@ class Stream {
         for (;;) {
           const int r = d->run16(out, S.sym.get() + S.cap);
           if (r == scfq_inflate::kNeedOutput) {              // better compression than planned for: a bigger buffer
+            // ... and past 64 M symbols the segment ends at its next block boundary instead of at the planned one
+            // (highly compressible input, e.g. runs of one byte at 1000:1): the chain is cut there, memory stays bounded
+            // by one block more, the next batch continues from that exact position
+            if (S.cap >= (64u << 20)) d->stop_bit = 0;
             const size_t used = (size_t)(out - S.sym.get());
             std::unique_ptr<uint16_t[]> bigger(new uint16_t[S.cap * 2]);
             std::memcpy(bigger.get(), S.sym.get(), used * sizeof(uint16_t));
