@@ -253,9 +253,12 @@ struct Decoder {
 
   static constexpr int kBlockEnd = 2;
 
-  int huffman_block(uint8_t*& out_ref, uint8_t* const out_end) {
-    uint8_t* out = out_ref;
-    uint8_t* const run_start = out;
+  // T = uint8_t (bytes) or uint16_t (symbols for the parallel reader: literals and window markers)
+  template <typename T>
+  int huffman_block_t(T*& out_ref, T* const out_end) {
+    constexpr int kPer = 8 / (int)sizeof(T);          // symbols per 64-bit word
+    T* out = out_ref;
+    T* const run_start = out;
     const uint64_t total_at_entry = total_out;
     const uint8_t* in = in_next;
     const uint8_t* const iend = in_end;
@@ -283,7 +286,7 @@ struct Decoder {
     //      the "do I have the bits" checks of the careful loop below are needed
     if (iend - in >= 16) {
       const uint8_t* const in_fast = iend - 8;
-      uint8_t* const out_fast = out_end - kOutSlack;
+      T* const out_fast = out_end - kOutSlack;
       while (in <= in_fast && out <= out_fast) {
         {
           uint64_t w_;
@@ -295,19 +298,19 @@ struct Decoder {
         uint32_t e = lt[bb & ((1u << kLitRoot) - 1)];
         if (e & F_LITERAL) {
           SCFQ_DROP(e_len(e));
-          *out++ = (uint8_t)e_val(e);
+          *out++ = (T)e_val(e);
           e = lt[bb & ((1u << kLitRoot) - 1)];
           if (e & F_LITERAL) {
             SCFQ_DROP(e_len(e));
-            *out++ = (uint8_t)e_val(e);
+            *out++ = (T)e_val(e);
             e = lt[bb & ((1u << kLitRoot) - 1)];
             if (e & F_LITERAL) {
               SCFQ_DROP(e_len(e));
-              *out++ = (uint8_t)e_val(e);
+              *out++ = (T)e_val(e);
               e = lt[bb & ((1u << kLitRoot) - 1)];
               if (e & F_LITERAL) {                 // a fourth: 4 x 11 = 44 <= 56 bits, first-level codes only
                 SCFQ_DROP(e_len(e));
-                *out++ = (uint8_t)e_val(e);
+                *out++ = (T)e_val(e);
               }
             }
           }
@@ -316,7 +319,7 @@ struct Decoder {
         if (e & F_SUB) {
           e = lt[e_val(e) + ((bb >> kLitRoot) & ((1u << e_extra(e)) - 1))];
           SCFQ_DROP(kLitRoot);
-          if (e & F_LITERAL) { SCFQ_DROP(e_len(e)); *out++ = (uint8_t)e_val(e); continue; }
+          if (e & F_LITERAL) { SCFQ_DROP(e_len(e)); *out++ = (T)e_val(e); continue; }
         }
         if (e_len(e) == 0) { result = kErrData; goto done; }
         SCFQ_DROP(e_len(e));
@@ -335,21 +338,22 @@ struct Decoder {
         const uint32_t off = e_val(d) + (uint32_t)(bb & ((1ull << dx) - 1));
         SCFQ_DROP(dx);
         if (off > total_at_entry + (uint64_t)(out - run_start)) { result = kErrData; goto done; }
-        const uint8_t* src = out - off;
-        uint8_t* dst = out;
+        const T* src = out - off;
+        T* dst = out;
         out += mlen;
-        if (off >= 8) {
+        if (off >= (uint32_t)kPer) {
           // most matches are short: two unconditional words, then the rest
           uint64_t w0, w1;
           std::memcpy(&w0, src, 8); std::memcpy(dst, &w0, 8);
-          std::memcpy(&w1, src + 8, 8); std::memcpy(dst + 8, &w1, 8);
-          if (mlen > 16) {
-            uint8_t* const stop = dst + mlen;
-            src += 16; dst += 16;
-            do { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < stop);
+          std::memcpy(&w1, src + kPer, 8); std::memcpy(dst + kPer, &w1, 8);
+          if (mlen > 2u * kPer) {
+            T* const stop = dst + mlen;
+            src += 2 * kPer; dst += 2 * kPer;
+            do { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); src += kPer; dst += kPer; } while (dst < stop);
           }
         } else if (off == 1) {
-          std::memset(dst, *src, mlen);
+          const T v = *src;
+          for (uint32_t k = 0; k < mlen; ++k) dst[k] = v;
         } else {
           for (uint32_t k = 0; k < mlen; ++k) dst[k] = src[k];
         }
@@ -368,16 +372,16 @@ struct Decoder {
       if (len > bc) SCFQ_FAIL();
       if (e & F_LITERAL) {
         SCFQ_DROP(len);
-        *out++ = (uint8_t)e_val(e);
+        *out++ = (T)e_val(e);
         // a second and third literal usually fit in the bits already loaded
         e = lt[bb & ((1u << kLitRoot) - 1)];
         if ((e & F_LITERAL) && e_len(e) <= bc) {
           SCFQ_DROP(e_len(e));
-          *out++ = (uint8_t)e_val(e);
+          *out++ = (T)e_val(e);
           e = lt[bb & ((1u << kLitRoot) - 1)];
           if ((e & F_LITERAL) && e_len(e) <= bc) {
             SCFQ_DROP(e_len(e));
-            *out++ = (uint8_t)e_val(e);
+            *out++ = (T)e_val(e);
           }
         }
         continue;
@@ -406,14 +410,15 @@ struct Decoder {
         const uint32_t off = e_val(d) + (uint32_t)(bb & ((1ull << dx) - 1));
         SCFQ_DROP(dx);
         if (off > total_at_entry + (uint64_t)(out - run_start)) { result = kErrData; goto done; }   // before the start of the stream
-        const uint8_t* src = out - off;
-        uint8_t* dst = out;
+        const T* src = out - off;
+        T* dst = out;
         out += mlen;
-        if (off >= 8) {
-          uint8_t* const stop = dst + mlen;
-          do { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < stop);
+        if (off >= (uint32_t)kPer) {
+          T* const stop = dst + mlen;
+          do { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); src += kPer; dst += kPer; } while (dst < stop);
         } else if (off == 1) {
-          std::memset(dst, *src, mlen);
+          const T v = *src;
+          for (uint32_t k = 0; k < mlen; ++k) dst[k] = v;
         } else {
           for (uint32_t k = 0; k < mlen; ++k) dst[k] = src[k];
         }
@@ -430,6 +435,8 @@ struct Decoder {
     bitcnt = bc;
     return result;
   }
+
+  int huffman_block(uint8_t*& out_ref, uint8_t* const out_end) { return huffman_block_t<uint8_t>(out_ref, out_end); }
 
   // ---- symbol output (scfq_pgz.hpp): the same stream decoded into 16-bit symbols.  The caller places 32768 symbols in
   // front of the output (markers 0x8000 | k for "byte k of the window I do not know yet", or the real bytes) and sets
@@ -473,54 +480,10 @@ struct Decoder {
         state = last_block ? kDone : kHeader;
         continue;
       }
-      uint16_t* out = out_next;
-      int result = kBlockEnd;
-      for (;;) {
-        if ((uint64_t)(out_end - out) < kOutSlack) { result = kNeedOutput; break; }
-        refill();
-        uint32_t e = lit[bitbuf & ((1u << kLitRoot) - 1)];
-        if (e & F_SUB) {
-          e = lit[e_val(e) + ((bitbuf >> kLitRoot) & ((1u << e_extra(e)) - 1))];
-          drop(kLitRoot);
-        }
-        const uint32_t len = e_len(e);
-        if (len == 0) { result = kErrData; break; }
-        if (len > bitcnt) { result = bitcnt_error(); break; }
-        drop((int)len);
-        if (e & F_LITERAL) { *out++ = (uint16_t)e_val(e); continue; }
-        if (e & F_EOB) { state = last_block ? kDone : kHeader; break; }
-        const uint32_t lx = e_extra(e);
-        if (lx > bitcnt) { result = bitcnt_error(); break; }
-        const uint32_t mlen = e_val(e) + peek((int)lx);
-        drop((int)lx);
-        if (bitcnt < 15 + 13) refill();
-        uint32_t d = dist[bitbuf & ((1u << kDistRoot) - 1)];
-        if (d & F_SUB) {
-          d = dist[e_val(d) + ((bitbuf >> kDistRoot) & ((1u << e_extra(d)) - 1))];
-          drop(kDistRoot);
-        }
-        const uint32_t dl = e_len(d);
-        if (dl == 0) { result = kErrData; break; }
-        if (dl > bitcnt) { result = bitcnt_error(); break; }
-        drop((int)dl);
-        const uint32_t dx = e_extra(d);
-        if (dx > bitcnt) { result = bitcnt_error(); break; }
-        const uint32_t off = e_val(d) + peek((int)dx);
-        drop((int)dx);
-        if (off > total_out + (uint64_t)(out - out_next)) { result = kErrData; break; }
-        const uint16_t* src = out - off;
-        uint16_t* dst = out;
-        out += mlen;
-        if (off >= 4) {
-          uint16_t* const stop = dst + mlen;
-          do { uint64_t w; std::memcpy(&w, src, 8); std::memcpy(dst, &w, 8); src += 4; dst += 4; } while (dst < stop);
-        } else {
-          for (uint32_t k = 0; k < mlen; ++k) dst[k] = src[k];
-        }
+      {
+        const int r = huffman_block_t<uint16_t>(out_next, out_end);
+        if (r != kBlockEnd) return r;
       }
-      total_out += (uint64_t)(out - out_next);
-      out_next = out;
-      if (result != kBlockEnd) return result;
     }
   }
 
