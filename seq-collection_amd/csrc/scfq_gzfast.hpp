@@ -49,18 +49,20 @@ class Stream {
  public:
   ~Stream() { close(); }
 
-  // true: `path` is a regular file that starts with a gzip member and is now mapped
-  bool open(const char* path) {
+  // true: `path` is a regular file that has a gzip member at byte `start` (0: the usual case; scfq_pgz.hpp hands the rest of
+  // a many-member file over at a member boundary) and is now mapped
+  bool open(const char* path, size_t start = 0) {
+    start_ = start;
     fd_ = ::open(path, O_RDONLY);
     if (fd_ < 0) return false;
     struct stat sb;
-    if (fstat(fd_, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) { close(); return false; }
+    if (fstat(fd_, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18 || (size_t)sb.st_size <= start) { close(); return false; }
     n_ = (size_t)sb.st_size;
     void* m = mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd_, 0);
     if (m == MAP_FAILED) { close(); return false; }
     map_ = static_cast<const uint8_t*>(m);
     (void)madvise(m, n_, MADV_SEQUENTIAL);
-    if (member_header(map_, n_) <= 0) { close(); return false; }
+    if (member_header(map_ + start_, n_ - start_) <= 0) { close(); return false; }
     return true;
   }
 
@@ -155,8 +157,8 @@ class Stream {
   void decode_loop() {
     auto dec = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
     const uint8_t* end = map_ + n_;
-    const long h = member_header(map_, n_);
-    dec->begin(map_ + h, end);
+    const long h = member_header(map_ + start_, n_ - start_);
+    dec->begin(map_ + start_ + h, end);
     std::vector<uint8_t> window(kWindow, 0);
     int put = 0;
     for (;;) {
@@ -210,7 +212,7 @@ class Stream {
 
   int fd_ = -1;
   const uint8_t* map_ = nullptr;
-  size_t n_ = 0, cap_ = 0;
+  size_t n_ = 0, cap_ = 0, start_ = 0;
   Slot slots_[kSlots];
   std::thread th_;
   std::mutex mu_;

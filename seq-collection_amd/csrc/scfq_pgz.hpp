@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 namespace scfq_pgz {
 
@@ -78,6 +79,7 @@ class Stream {
     if (m == MAP_FAILED) { close(); return false; }
     map_ = static_cast<const uint8_t*>(m);
     if (member_header(map_, n_) <= 0) { close(); return false; }
+    path_ = path;
     counted_ = true;
     active_streams()++;
     return true;
@@ -96,6 +98,7 @@ class Stream {
 
   // up to cap bytes of the inflated stream; 0 at the end, -1 on a corrupt stream
   int64_t next_chunk(uint8_t* dst, uint64_t cap) {
+    if (serial_) return serial_->next_chunk(dst, cap);
     if (!started_) { started_ = true; th_ = std::thread([this] { produce(); }); }
     for (;;) {
       if (cur_ && cur_off_ < cur_->n) {
@@ -109,6 +112,13 @@ class Stream {
         { std::lock_guard<std::mutex> lk(mu_); cur_->state = Batch::kFree; }
         cv_.notify_all();
         cur_ = nullptr;
+        if (st == 2) {
+          // a file of many small members (cat of small .gz files, BGZF read as plain gzip): one member is not enough work to
+          // split, so the rest goes through the serial reader, which starts at the next member
+          serial_.reset(new scfq_gzfast::Stream());
+          if (!serial_->open(path_.c_str(), handoff_)) { serial_.reset(); finished_ = failed_ = true; return -1; }
+          return serial_->next_chunk(dst, cap);
+        }
         if (st != 0) { finished_ = true; failed_ = st < 0; }
       }
       if (finished_) return failed_ ? -1 : 0;
@@ -347,10 +357,17 @@ class Stream {
         const uint32_t want_crc = (uint32_t)end_ptr[0] | ((uint32_t)end_ptr[1] << 8) | ((uint32_t)end_ptr[2] << 16) | ((uint32_t)end_ptr[3] << 24);
         const uint32_t want_len = (uint32_t)end_ptr[4] | ((uint32_t)end_ptr[5] << 8) | ((uint32_t)end_ptr[6] << 16) | ((uint32_t)end_ptr[7] << 24);
         if (want_crc != crc || want_len != isize) { B->status = -1; publish(B); return; }
+        const uint8_t* const member_start = member;
         member = end_ptr + 8;
         h = member_header(member, (size_t)(file_end - member));
         if (h == 0) { B->status = 1; publish(B); return; }
         if (h < 0) { B->status = -1; publish(B); return; }
+        if ((uint64_t)(member - member_start) < 2 * seg_bytes) {          // small member, and more follow: serial from here
+          handoff_ = (size_t)(member - map_);
+          B->status = 2;
+          publish(B);
+          return;
+        }
         data = member + h;
         bit = 0;
         crc = 0; isize = 0;
@@ -377,7 +394,9 @@ class Stream {
 
   int fd_ = -1;
   const uint8_t* map_ = nullptr;
-  size_t n_ = 0;
+  size_t n_ = 0, handoff_ = 0;
+  std::string path_;
+  std::unique_ptr<scfq_gzfast::Stream> serial_;
   Batch batches_[2];
   Batch* cur_ = nullptr;
   uint64_t cur_off_ = 0;

@@ -251,3 +251,17 @@ def test_parallel_reader_false_syncs_and_thread_counts(scfq, tmp_path):
         env = dict(os.environ, **pgz_env(SCFQ_INFLATE_THREADS=threads, SCFQ_PGZ_SEGMENT_MB=seg))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.strip() == want, (threads, seg, r.stderr[-300:])
+
+
+def test_parallel_reader_hands_many_small_members_to_the_serial_reader(scfq, tmp_path):
+    """a BGZF-like file read as plain gzip (thousands of 64 KiB members) must not start a thread batch per member"""
+    import time
+    from test_ingest_sources import bgzf_file
+    data = fastq_bytes(24_000_000, seed=23)
+    blob = bgzf_file(data)                                      # ~370 members
+    big_then_small = gzip.compress(data[:16_000_000], mtime=0) + bgzf_file(data[16_000_000:])
+    with EnvPatch(dict(pgz_env(), SCFQ_NO_BGZF="1")):
+        t = time.time()
+        assert read(scfq, tmp_path, blob, len(data) + 16, 1 << 20) == data
+        assert read(scfq, tmp_path, big_then_small, len(data) + 16, 1 << 20) == data
+        assert time.time() - t < 20
