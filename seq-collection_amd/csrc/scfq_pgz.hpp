@@ -191,7 +191,7 @@ class Stream {
       }
       B->n = 0;
       B->status = 0;
-      const int T = std::max(2, T_max / std::max(1, active_streams().load()));      // this batch's share of the CPU budget
+      const int T = std::min(T_max, std::max(2, T_max / std::max(1, active_streams().load())));   // this batch's share of the CPU budget
       const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
       auto t_mark = std::chrono::steady_clock::now();
       auto lap = [&](const char* what) {
