@@ -466,6 +466,8 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
   const uint64_t xb = (i0 == 0) ? x0 : (i0 == 1) ? x1 : (i0 == 2) ? x2 : x3;    // begins with newline i0
   const uint32_t a = (i0 == 0) ? 0u : (xa ? (uint32_t)__builtin_ctzll(xa) + 1u : 65u);   // 65: the lane has no such segment
   const uint32_t b = xb ? (uint32_t)__builtin_ctzll(xb) : 64u;
+  // long reads: most tiles lie entirely inside a header / sequence / separator line and hold no quality byte at all
+  if (__builtin_amdgcn_ballot_w64(a < b || cnt >= i0 + 4u) == 0) return;
   const uint32_t A = (a + 3u) >> 2, Bd = b >> 2;
   const uint32_t width = (Bd > A) ? Bd - A : 0u;
   // Pivot: quality strings are dominated by one value (one byte is ~90 % of an Illumina quality line), which would
