@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <new>
 #include <string>
 
 namespace scfq_pgz {
@@ -52,9 +53,21 @@ inline bool plausible_block(scfq_inflate::Decoder& d, const uint8_t* base, const
   return r == scfq_inflate::kAtBoundary || r == scfq_inflate::kStreamEnd || (r == scfq_inflate::kNeedOutput && (uint64_t)(out - (scratch.data() + kWindow)) >= kTrialSymbols);
 }
 
+// Large scratch buffers: 2 MiB-aligned and advised as huge pages, never value-initialised.  A dozen threads first-touching
+// 80 MB each through 4 KiB faults serialise on the address-space lock (the first batch took 3x as long as later ones).
+struct BigFree { void operator()(void* p) const { std::free(p); } };
+template <typename T> using BigBuf = std::unique_ptr<T[], BigFree>;
+template <typename T> inline BigBuf<T> big_alloc(size_t n) {
+  void* p = nullptr;
+  const size_t bytes = ((n * sizeof(T) + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
+  if (posix_memalign(&p, 2u << 20, bytes) != 0) throw std::bad_alloc();
+  (void)madvise(p, bytes, MADV_HUGEPAGE);
+  return BigBuf<T>(static_cast<T*>(p));
+}
+
 struct Segment {
   uint64_t start_bit = 0, end_bit = 0;               // relative to the member's deflate data
-  std::unique_ptr<uint16_t[]> sym;                   // [kWindow markers or bytes | symbols], never value-initialised
+  BigBuf<uint16_t> sym;                              // [kWindow markers or bytes | symbols], never value-initialised
   size_t cap = 0;
   uint64_t n = 0;                                    // symbols produced
   bool synced = false, ok = false, member_end = false;
@@ -133,7 +146,7 @@ class Stream {
  private:
   struct Batch {
     enum State { kFree, kReady } state = kFree;
-    std::unique_ptr<uint8_t[]> buf;                    // never value-initialised (a vector resize zero-fills half a GB per batch)
+    BigBuf<uint8_t> buf;                               // never value-initialised (a vector resize zero-fills half a GB per batch)
     size_t cap = 0;
     size_t n = 0;                                      // valid bytes
     int status = 0;                                    // 0 more, 1 end of stream, -1 error
@@ -180,7 +193,7 @@ class Stream {
     const int T_max = n_threads();
     const uint64_t seg_bytes = (uint64_t)std::max(1, env_mb("SCFQ_PGZ_SEGMENT_MB", 4)) << 20;
     const uint64_t search_bytes = std::min<uint64_t>(seg_bytes, 1u << 20);   // a dynamic block starts every few 10 KB in practice
-    std::vector<std::unique_ptr<uint16_t[]>> symbuf((size_t)T_max);            // reused from batch to batch
+    std::vector<BigBuf<uint16_t>> symbuf((size_t)T_max);            // reused from batch to batch
     std::vector<size_t> symcap((size_t)T_max, 0);
     for (;;) {
       Batch* B = &batches_[put];
@@ -233,7 +246,7 @@ class Stream {
         S.cap = symcap[(size_t)k];
         if (S.cap < kWindow + (size_t)seg_bytes * 5 + scfq_inflate::kOutSlack) {
           S.cap = kWindow + (size_t)seg_bytes * 5 + scfq_inflate::kOutSlack;
-          S.sym.reset(new uint16_t[S.cap]);
+          S.sym = big_alloc<uint16_t>(S.cap);
         }
         if (k == 0) {
           for (uint32_t i = 0; i < kWindow; ++i) S.sym[i] = window[i];                    // exact window: plain bytes
@@ -249,7 +262,7 @@ class Stream {
             // by one block more, the next batch continues from that exact position
             if (S.cap >= (64u << 20)) d->stop_bit = 0;
             const size_t used = (size_t)(out - S.sym.get());
-            std::unique_ptr<uint16_t[]> bigger(new uint16_t[S.cap * 2]);
+            BigBuf<uint16_t> bigger = big_alloc<uint16_t>(S.cap * 2);
             std::memcpy(bigger.get(), S.sym.get(), used * sizeof(uint16_t));
             S.sym.swap(bigger);
             S.cap *= 2;
@@ -297,7 +310,7 @@ class Stream {
       // a marker that points into a part of the window that does not exist (before the member's start) is corrupt data
       // (the serial decoder's "distance too far back"): checked per segment below with window_valid
       // ---- resolve + CRC, in parallel ---------------------------------------------------------------------------------------
-      if (B->cap < off[good]) { B->cap = (size_t)off[good] + (size_t)(off[good] >> 3); B->buf.reset(new uint8_t[B->cap]); }
+      if (B->cap < off[good]) { B->cap = (size_t)off[good] + (size_t)(off[good] >> 3); B->buf = big_alloc<uint8_t>(B->cap); }
       B->n = (size_t)off[good];
       std::vector<uint32_t> part_crc((size_t)good, 0);
       std::atomic<int> bad{0};
