@@ -191,8 +191,8 @@ class Stream {
     const uint8_t* data = member + h;                  // deflate data of the current member
     uint64_t bit = 0;                                  // exact position of the next block header, relative to data
     const int T_max = n_threads();
-    const uint64_t seg_bytes = (uint64_t)std::max(1, env_mb("SCFQ_PGZ_SEGMENT_MB", 4)) << 20;
-    const uint64_t search_bytes = std::min<uint64_t>(seg_bytes, 1u << 20);   // a dynamic block starts every few 10 KB in practice
+    const uint64_t seg_default = (uint64_t)std::max(1, env_mb("SCFQ_PGZ_SEGMENT_MB", 4)) << 20;
+    uint64_t seg_bytes = seg_default;       // shrinks when members turn out to be smaller than a batch (see the end of a member)
     std::vector<BigBuf<uint16_t>> symbuf((size_t)T_max);            // reused from batch to batch
     std::vector<size_t> symcap((size_t)T_max, 0);
     for (;;) {
@@ -204,6 +204,7 @@ class Stream {
       }
       B->n = 0;
       B->status = 0;
+      const uint64_t search_bytes = std::min<uint64_t>(seg_bytes, 1u << 20);   // a dynamic block starts every few 10 KB in practice
       const int T = std::min(T_max, std::max(2, T_max / std::max(1, active_streams().load())));   // this batch's share of the CPU budget
       const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
       auto t_mark = std::chrono::steady_clock::now();
@@ -375,12 +376,16 @@ class Stream {
         h = member_header(member, (size_t)(file_end - member));
         if (h == 0) { B->status = 1; publish(B); return; }
         if (h < 0) { B->status = -1; publish(B); return; }
-        if ((uint64_t)(member - member_start) < 2 * seg_bytes) {          // small member, and more follow: serial from here
+        const uint64_t member_size = (uint64_t)(member - member_start);
+        if (member_size < (2u << 20)) {                                   // small members, and more follow: serial from here
           handoff_ = (size_t)(member - map_);
           B->status = 2;
           publish(B);
           return;
         }
+        // members smaller than a batch (files concatenated from many mid-sized .gz): one member per batch, cut so that
+        // every thread gets a segment of it
+        seg_bytes = std::min<uint64_t>(seg_default, std::max<uint64_t>(512u << 10, member_size / (uint64_t)T_max + 1));
         data = member + h;
         bit = 0;
         crc = 0; isize = 0;
