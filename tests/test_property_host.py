@@ -102,3 +102,35 @@ def test_gzip_readers_equal_zlib(scfq, tmp_path_factory, seed, level, strategy, 
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def count_reference(data: bytes):
+    """src/fq_count.nim:38-45, transliterated (1-based line counter, `count` of the single letters G, C and N)"""
+    reads = gc = n = bases = 0
+    for i, line in enumerate(nim_lines(data), start=1):
+        if i % 4 == 1:
+            reads += 1
+        if i % 4 == 2:
+            gc += line.count(b"G") + line.count(b"C")
+            n += line.count(b"N")
+            bases += len(line)
+    return reads, gc, n, bases
+
+
+seq_st = st.text(alphabet="ACGTNacgtn\r @+", max_size=20).map(str.encode)
+
+
+@st.composite
+def ragged_text(draw):
+    lines = draw(st.lists(seq_st, max_size=24))
+    blob = b"".join(l + draw(eol_st) for l in lines)
+    return blob[:-1] if blob and draw(st.booleans()) else blob
+
+
+@settings(max_examples=400, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(ragged_text())
+def test_count_oracle_equals_the_transliteration(oracle, data):
+    want = count_reference(data)
+    for which in ("bytes", "lines"):
+        c = oracle.count(data, which)
+        assert (c.reads, c.gc_bases, c.n_bases, c.bases) == want, which
