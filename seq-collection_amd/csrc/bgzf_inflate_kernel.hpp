@@ -21,6 +21,10 @@
 
 namespace scfq_dinflate {
 
+#ifndef SCFQ_DABLATE
+#define SCFQ_DABLATE 0      // measurement builds only (scripts/gpu_dinflate_ablate.sh): 1 no match copies, 2 no CRC, 4 no literal stores
+#endif
+
 struct Block {              // offsets are relative to the chunk's compressed / inflated buffers
   uint32_t in_off;          // first byte of the member's deflate data
   uint32_t in_len;          // bytes of deflate data (member size - header - 8-byte trailer)
@@ -30,6 +34,7 @@ struct Block {              // offsets are relative to the chunk's compressed / 
 };
 
 enum : uint32_t { kOk = 0, kErrData = 1, kErrLength = 2, kErrCrc = 3 };
+constexpr uint32_t kInvalid = 0xFFFFu;        // table slot of a code that is not assigned (bit 15 set like a second-level pointer: one test for both)
 
 constexpr int kLitRoot = 10, kDistRoot = 8;
 constexpr int kLitEntries = 2048, kDistEntries = 768;                   // first level + second-level space
@@ -37,7 +42,7 @@ constexpr int kWaveLdsHalfwords = kLitEntries + kDistEntries + 160 /*lens[320] a
                                   320 /*sorted*/ + 32 /*count, offs*/;
 constexpr int kWavesPerWg = 4;
 
-// u16 entry: bits 0..3 code length (0 = unassigned), 4..12 symbol; second-level pointer: bit 15, bits 0..3 index bits,
+// u16 entry: bits 0..3 code length, 4..12 symbol (kInvalid = unassigned); second-level pointer: bit 15, bits 0..3 index bits,
 // bits 4..14 start of the second-level table
 __device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -54,7 +59,7 @@ __device__ inline bool build_table(const uint8_t* lens, int n, bool is_codelen, 
   int max = 15;
   while (max >= 1 && !count[max]) --max;
   const int first = 1 << root;
-  for (int k = 0; k < first; ++k) tab[k] = 0;
+  for (int k = 0; k < first; ++k) tab[k] = (uint16_t)kInvalid;
   if (max == 0) return true;                         // no codes: every lookup fails (zlib: error on use)
   int left = 1;
   for (int len = 1; len <= 15; ++len) { left = (left << 1) - (int)count[len]; if (left < 0) return false; }
@@ -83,7 +88,7 @@ __device__ inline bool build_table(const uint8_t* lens, int n, bool is_codelen, 
           sub_start = next_free;
           next_free += 1 << sub_bits;
           if (next_free > cap) return false;
-          for (int k = sub_start; k < next_free; ++k) tab[k] = 0;
+          for (int k = sub_start; k < next_free; ++k) tab[k] = (uint16_t)kInvalid;
           tab[prefix] = (uint16_t)(0x8000u | ((uint32_t)sub_start << 4) | (uint32_t)sub_bits);
           cur_prefix = prefix;
         }
@@ -144,21 +149,29 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   uint16_t* offs = count + 16;
   __shared__ uint32_t build_ok[kWavesPerWg];
   // length / distance base and extra-bit tables: LDS copies (a lookup in the global-memory constants costs an L2 round
-  // trip per match, four times)
-  __shared__ uint16_t s_len_base[32], s_dist_base[32];
-  __shared__ uint8_t s_len_extra[32], s_dist_extra[32];
-  if (threadIdx.x < 29) { s_len_base[threadIdx.x] = kLenBase[threadIdx.x]; s_len_extra[threadIdx.x] = kLenExtra[threadIdx.x]; }
-  if (threadIdx.x < 30) { s_dist_base[threadIdx.x] = kDistBase[threadIdx.x]; s_dist_extra[threadIdx.x] = kDistExtra[threadIdx.x]; }
+  // trip per match)
+  __shared__ uint32_t s_len[32], s_dist[32];           // base | extra bits << 16
+  if (threadIdx.x < 29) s_len[threadIdx.x] = kLenBase[threadIdx.x] | ((uint32_t)kLenExtra[threadIdx.x] << 16);
+  if (threadIdx.x >= 30 && threadIdx.x < 32) s_dist[threadIdx.x] = 0;
+  if (threadIdx.x < 30) s_dist[threadIdx.x] = kDistBase[threadIdx.x] | ((uint32_t)kDistExtra[threadIdx.x] << 16);
   __syncthreads();
   if (b >= n_blocks) return;
 
   const Block blk = blocks[b];
-  const uint8_t* in = comp + blk.in_off;
-  const uint8_t* const in_end = in + blk.in_len;
+  const uint8_t* const in = comp + blk.in_off;      // wave-uniform base; the read position is the 32-bit offset `ip`
+  const uint32_t ip_end = blk.in_len;
+  uint32_t ip = 0;
   uint8_t* const o = out + blk.out_off;
   const uint32_t isize = blk.isize;
+  // the member's output as a buffer descriptor: an offset outside [0, isize) is dropped (store) or reads 0 (load)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)isize, 0x00020000);
+  const uint32_t not_lane0 = lane == 0 ? 0u : 0xFFFFFFFFu;
   uint64_t bb = 0;
-  uint32_t bc = 0, pos = 0, err = kOk;
+  int32_t bc = 0;                                      // bits in bb; negative once a malformed stream has run past its end
+  uint32_t pos = 0, err = kOk;
+#ifdef SCFQ_DSTATS
+  uint32_t n_blk = 0, n_lit = 0, n_match = 0, n_mbytes = 0, n_overlap = 0, n_long = 0;
+#endif
   bool last = false;
 
   // the 8-byte gzip trailer follows the deflate data, so an 8-byte load that starts inside the data stays in the chunk.
@@ -166,16 +179,16 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   // it per-lane.)
 #define SCFQ_DREFILL()                                                                         \
   do {                                                                                         \
-    if (in < in_end) {                                                                         \
+    if (ip < ip_end) {                                                                         \
       uint64_t w_;                                                                             \
-      __builtin_memcpy(&w_, in, 8);                                                            \
+      __builtin_memcpy(&w_, in + ip, 8);                                                       \
       w_ = ((uint64_t)uni((uint32_t)(w_ >> 32)) << 32) | uni((uint32_t)w_);                    \
-      const uint32_t avail_ = (uint32_t)(in_end - in);                                         \
+      const int32_t avail_ = (int32_t)(ip_end - ip);                                           \
       if (avail_ < 8) w_ &= (1ull << (8 * avail_)) - 1;                                        \
       bb |= w_ << bc;                                                                          \
-      uint32_t take_ = (63 - bc) >> 3;                                                         \
+      int32_t take_ = (63 - bc) >> 3;                                                          \
       if (take_ > avail_) take_ = avail_;                                                      \
-      in += take_;                                                                             \
+      ip += (uint32_t)take_;                                                                   \
       bc += take_ * 8;                                                                         \
     }                                                                                          \
   } while (0)
@@ -195,11 +208,11 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       const uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
       bb >>= 32; bc -= 32;
       if ((len ^ nlen) != 0xFFFF) { err = kErrData; break; }
-      in -= bc >> 3;                                   // whole bytes go back to the byte stream
+      ip -= (uint32_t)bc >> 3;                                 // whole bytes go back to the byte stream
       bb = 0; bc = 0;
-      if ((uint32_t)(in_end - in) < len || pos + len > isize) { err = kErrData; break; }
-      for (uint32_t k = lane; k < len; k += 64) o[pos + k] = in[k];
-      in += len; pos += len;
+      if (ip_end - ip < len || pos + len > isize) { err = kErrData; break; }
+      for (uint32_t k = lane; k < len; k += 64) o[pos + k] = in[ip + k];
+      ip += len; pos += len;
       continue;
     }
     if (type == 3) { err = kErrData; break; }
@@ -241,9 +254,9 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
         SCFQ_DREFILL();
         const uint32_t e = uni(cltab[bb & 127]);
         const uint32_t len = e & 15;
-        if (len == 0 || len > bc) { err = kErrData; break; }
-        bb >>= len; bc -= len;
-        const uint32_t sym = (e >> 4) & 0x1FF;
+        if (e == kInvalid || (int32_t)len > bc) { err = kErrData; break; }
+        bb >>= len; bc -= (int32_t)len;
+        const uint32_t sym = e >> 4;
         uint32_t rep = 1, val = sym;
         if (sym == 16) { if (k == 0 || bc < 2) { err = kErrData; break; } val = prev; rep = 3 + ((uint32_t)bb & 3); bb >>= 2; bc -= 2; }
         else if (sym == 17) { if (bc < 3) { err = kErrData; break; } val = 0; rep = 3 + ((uint32_t)bb & 7); bb >>= 3; bc -= 3; }
@@ -267,67 +280,105 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     __builtin_amdgcn_wave_barrier();
     if (!__builtin_amdgcn_readfirstlane((int)build_ok[wave])) { err = kErrData; break; }
     // ---- symbols --------------------------------------------------------------------------------------------------
-    for (;;) {
-      if (bc < 48) SCFQ_DREFILL();          // a literal/length + distance pair needs at most 15 + 5 + 15 + 13 = 48 bits
-      uint32_t e = uni(lit[bb & ((1u << kLitRoot) - 1)]);
-      if (e & 0x8000u) {
-        e = uni(lit[((e >> 4) & 0x7FF) + ((uint32_t)(bb >> kLitRoot) & ((1u << (e & 15)) - 1))]);
-        bb >>= kLitRoot; bc -= kLitRoot;
-      }
-      const uint32_t len = e & 15;
-      if (len == 0 || len > bc) { err = kErrData; goto decode_done; }
-      bb >>= len; bc -= len;
-      const uint32_t sym = (e >> 4) & 0x1FF;
-      if (sym < 256) {
-        if (pos >= isize) { err = kErrLength; goto decode_done; }
-        if (lane == 0) o[pos] = (uint8_t)sym;
-        ++pos;
-        continue;
-      }
-      if (sym == 256) break;
-      if (sym > 285) { err = kErrData; goto decode_done; }
-      const uint32_t lx = uni(s_len_extra[sym - 257]);
-      if (lx > bc) { err = kErrData; goto decode_done; }
-      const uint32_t mlen = uni(s_len_base[sym - 257]) + ((uint32_t)bb & ((1u << lx) - 1));
-      bb >>= lx; bc -= lx;
-      if (bc < 28) SCFQ_DREFILL();
-      uint32_t d = uni(dist[bb & ((1u << kDistRoot) - 1)]);
-      if (d & 0x8000u) {
-        d = uni(dist[((d >> 4) & 0x7FF) + ((uint32_t)(bb >> kDistRoot) & ((1u << (d & 15)) - 1))]);
-        bb >>= kDistRoot; bc -= kDistRoot;
-      }
-      const uint32_t dl = d & 15;
-      if (dl == 0 || dl > bc) { err = kErrData; goto decode_done; }
-      bb >>= dl; bc -= dl;
-      const uint32_t dsym = (d >> 4) & 0x1FF;
-      if (dsym >= 30) { err = kErrData; goto decode_done; }
-      const uint32_t dx = uni(s_dist_extra[dsym]);
-      if (dx > bc) { err = kErrData; goto decode_done; }
-      const uint32_t off = uni(s_dist_base[dsym]) + ((uint32_t)bb & ((1u << dx) - 1));
-      bb >>= dx; bc -= dx;
-      if (off > pos) { err = kErrData; goto decode_done; }          // a BGZF member starts with an empty window
-      if (pos + mlen > isize) { err = kErrLength; goto decode_done; }
-      // The bytes the match reads were stored by this same wave (lane 0's literals, other lanes' earlier copies).  Vector
-      // memory instructions of one wave reach the CU's L1 in issue order and the write-through L1 serves later loads of
-      // the same CU coherently (the workgroup-scope rule of the AMDGPU memory model: no cache maintenance inside a CU), so
-      // no s_waitcnt vmcnt(0) is needed here.  SCFQ_DINFLATE_FENCE builds the conservative form (measured: same speed,
-      // the kernel is bound by scalar instruction issue); every member's CRC-32 is verified on the device either way.
-#ifdef SCFQ_DINFLATE_FENCE
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // The loop holds no divergent branch: stores are predicated through the buffer descriptor (a lane that must not write
+    // gets an out-of-range offset, which the hardware drops), so every branch below is a scalar branch on wave-uniform
+    // state and the compiler emits the loop as written (with `if (lane == 0)` regions inside, the CFG structuriser wrapped
+    // every exit of the loop in a state machine: about 35 scalar instructions per literal on top of the decode).
+    // Checks are lazy where the hardware already bounds the access: writes beyond ISIZE are dropped by the descriptor
+    // and found by `pos != isize` afterwards; bits consumed beyond the member's end make `bc` negative, which the refill
+    // branch (taken on every pass once the input is exhausted) turns into an error.
+    // Written with ONE exit at the bottom (`done`) and if/else instead of break/continue: a loop with several exits is
+    // rewritten by the compiler's exit unification into the same kind of state machine.
+    uint32_t done = 0;
+#ifdef SCFQ_DSTATS
+    ++n_blk;
 #endif
-      const uint8_t* src = o + pos - off;
-      for (uint32_t k = lane; k < mlen; k += 64) {
-        const uint32_t j = (off >= mlen) ? k : (off == 1 ? 0u : k % off);
-        o[pos + k] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    do {
+      if (bc < 48) {
+        SCFQ_DREFILL();
+        if (bc < 0) { err = kErrData; done = 1; }
+        if (pos > isize) { err = kErrLength; done = 1; }
       }
-      pos += mlen;
-    }
+      uint32_t e = uni(lit[bb & ((1u << kLitRoot) - 1)]);
+      if (e & 0x8000u) {                     // second level, or an unassigned code (kInvalid carries the same flag)
+        if (e != kInvalid) {
+          e = uni(lit[((e >> 4) & 0x7FF) + ((uint32_t)(bb >> kLitRoot) & ((1u << (e & 15)) - 1))]);
+          bb >>= kLitRoot; bc -= kLitRoot;
+        }
+      }
+      const uint32_t len = e & 15;           // kInvalid: 15 bits and "symbol" 0xFFF, which the range check below rejects
+      bb >>= len; bc -= (int32_t)len;
+      const uint32_t sym = e >> 4;
+      if (sym < 256) {
+        if (!(SCFQ_DABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)sym, orsrc, pos | not_lane0, 0, 0);
+        ++pos;
+#ifdef SCFQ_DSTATS
+        ++n_lit;
+#endif
+      } else if (sym == 256) {
+        if (bc < 0) err = kErrData;
+        done = 1;
+      } else if (sym > 285) {
+        err = kErrData; done = 1;
+      } else {
+        const uint32_t lb = uni(s_len[sym - 257]);               // base | extra bits << 16
+        const uint32_t lx = lb >> 16;
+        const uint32_t mlen = (lb & 0xFFFF) + ((uint32_t)bb & ((1u << lx) - 1));
+        bb >>= lx; bc -= (int32_t)lx;
+        if (bc < 28) SCFQ_DREFILL();         // distance code + extra bits: at most 15 + 13
+        uint32_t d = uni(dist[bb & ((1u << kDistRoot) - 1)]);
+        if (d & 0x8000u) {
+          if (d != kInvalid) {
+            d = uni(dist[((d >> 4) & 0x7FF) + ((uint32_t)(bb >> kDistRoot) & ((1u << (d & 15)) - 1))]);
+            bb >>= kDistRoot; bc -= kDistRoot;
+          }
+        }
+        const uint32_t dl = d & 15;
+        bb >>= dl; bc -= (int32_t)dl;
+        const uint32_t dsym = d >> 4;
+        const uint32_t db = uni(s_dist[dsym & 31]);              // base | extra bits << 16 (entries 30, 31: zero)
+        const uint32_t dx = db >> 16;
+        const uint32_t off = (db & 0xFFFF) + ((uint32_t)bb & ((1u << dx) - 1));
+        bb >>= dx; bc -= (int32_t)dx;
+        if (dsym >= 30 || off > pos) {       // (a BGZF member starts with an empty window)
+          err = kErrData; done = 1;
+        } else {
+          // The bytes the match reads were stored by this same wave (lane 0's literals, other lanes' earlier copies).
+          // Vector memory instructions of one wave reach the CU's L1 in issue order and the write-through L1 serves later
+          // loads of the same CU coherently (the workgroup-scope rule of the AMDGPU memory model: no cache maintenance
+          // inside a CU), so no s_waitcnt vmcnt(0) is needed here.  SCFQ_DINFLATE_FENCE builds the conservative form
+          // (measured: same speed); every member's CRC-32 is verified on the device either way.
+#ifdef SCFQ_DINFLATE_FENCE
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+          const uint32_t src0 = pos - off;
+          if (SCFQ_DABLATE & 1) {
+          } else if (off >= mlen) {
+            for (uint32_t base = 0; base < mlen; base += 64) {
+              const uint32_t k = base + lane;
+              const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + k, 0, 1 /*sc0*/);
+              __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, k < mlen ? pos + k : 0xFFFFFFFFu, 0, 0);
+            }
+          } else {                           // the match overlaps its own output: period `off`
+            for (uint32_t base = 0; base < mlen; base += 64) {
+              const uint32_t k = base + lane;
+              const uint32_t j = off == 1 ? 0u : k % off;
+              const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + j, 0, 1 /*sc0*/);
+              __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, k < mlen ? pos + k : 0xFFFFFFFFu, 0, 0);
+            }
+          }
+          pos += mlen;
+#ifdef SCFQ_DSTATS
+          ++n_match; n_mbytes += mlen; n_overlap += off < mlen; n_long += mlen > 64;
+#endif
+        }
+      }
+    } while (!done);
   }
-decode_done:
   if (err == kOk && pos != isize) err = kErrLength;
   // ---- CRC-32 of the member: every lane the standard CRC of a contiguous slice, then 63 combines ------------------------
-  if (err == kOk) {
+  if (err == kOk && !(SCFQ_DABLATE & 2)) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t per = (isize + 63) / 64;
@@ -347,6 +398,9 @@ decode_done:
     if (total != blk.crc) err = kErrCrc;
   }
 #undef SCFQ_DREFILL
+#ifdef SCFQ_DSTATS
+  if (lane == 0) { atomicAdd(status + 1, n_blk); atomicAdd(status + 2, n_lit); atomicAdd(status + 3, n_match); atomicAdd(status + 4, n_mbytes >> 4); atomicAdd(status + 5, n_overlap); atomicAdd(status + 6, n_long); }
+#endif
   if (lane == 0 && err) atomicOr(status, 1u << err);      // one word for the whole launch: bit k = some block ended with error k
 }
 

@@ -1099,9 +1099,9 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
   HIPCHK(hipMalloc(&d_comp, kChunk + 64));
   HIPCHK(hipMalloc(&d_out, kChunk));
   HIPCHK(hipMalloc(&d_blocks, (kChunk / 64 + 16) * sizeof(scfq_dinflate::Block)));
-  HIPCHK(hipMalloc(&d_status, 4));
+  HIPCHK(hipMalloc(&d_status, 64));
   struct Free { uint8_t* a; uint8_t* b; void* c; void* d; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); } } fr{d_comp, d_out, d_blocks, d_status};
-  HIPCHK(hipMemsetAsync(d_status, 0, 4, c->compute));
+  HIPCHK(hipMemsetAsync(d_status, 0, 64, c->compute));
   while (pos < n) {
     uint64_t ob = 0;
     uint32_t nb = 0;
@@ -1123,6 +1123,10 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
   }
   uint32_t st = 0;
   HIPCHK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
+#ifdef SCFQ_DSTATS
+  { uint32_t w[8]; HIPCHK(hipMemcpy(w, d_status, 32, hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "dstats: deflate blocks %u literals %u matches %u match bytes %llu overlapping %u longer than 64: %u\n", w[1], w[2], w[3], (unsigned long long)w[4] << 4, w[5], w[6]); }
+#endif
   if (st) { std::snprintf(g_err, sizeof g_err, "device inflate: error mask 0x%x (2 = corrupt deflate data, 4 = length, 8 = CRC-32)", st); return SCFQ_EGZ; }
   return (int64_t)total;
 }
