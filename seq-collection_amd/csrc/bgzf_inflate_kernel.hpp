@@ -7,12 +7,16 @@
 // checked on the device.
 //
 // One WAVE per BGZF block.  DEFLATE is serial inside a block (every code's position depends on the previous code's
-// length), so the wave walks the bit stream as one: every lane holds the same bit buffer and takes the same branches
-// (the input pointer is wave-uniform, so refills are one broadcast load), the Huffman tables live in the wave's own slice
-// of LDS (two-level, 16-bit entries, built by lane 0 with the construction of zlib's inftrees), literals are stored by
-// lane 0, and the parallelism of the wave goes into the match copies (lane k copies byte k) and into the CRC (64 slices,
+// length), so the wave walks the bit stream as one: the bit buffer and every branch are wave-uniform and live on the
+// scalar unit, the compressed bytes arrive through the scalar cache, the Huffman tables live in the wave's own slice of
+// LDS (two-level, 32-bit entries that already hold base value and extra-bit count, built by lane 0 with the construction
+// of zlib's inftrees), literals are stored by lane 0, and the parallelism of the wave goes into the match copies (lane k
+// copies byte k; the store of a match is deferred behind the decoding of the next symbols) and into the CRC (64 slices,
 // one per lane, stitched with a precomputed GF(2) shift).  Throughput comes from the number of blocks in flight
-// (256 CUs x 24 waves), not from one block being fast.
+// (256 CUs x 16 waves), not from one block being fast.
+// What bounds it (measured): the CU's single scalar ALU — about 40 scalar instructions per literal and 90 per
+// match at ~0.8 issued per cycle and CU; more resident waves change nothing.  Level-6 FASTQ is 70 % matches (mean length
+// 10), i.e. ~9 K symbols per 64 KiB member.
 // Every loop is bounded by the block's input bits or output bytes; a malformed stream sets an error status and ends
 // the wave.
 #pragma once
@@ -34,36 +38,53 @@ struct Block {              // offsets are relative to the chunk's compressed / 
 };
 
 enum : uint32_t { kOk = 0, kErrData = 1, kErrLength = 2, kErrCrc = 3 };
-constexpr uint32_t kInvalid = 0xFFFFu;        // table slot of a code that is not assigned (bit 15 set like a second-level pointer: one test for both)
 
+// Decode tables: two levels, 32-bit entries with everything a symbol needs already in them (no second lookup for the
+// base / extra bits of a length or distance code):
+//   bits 0..3   bits this level consumes          bits 4..7   number of extra bits (length / distance codes),
+//                                                              or index bits of the second-level table (kSub)
+//   bits 8..11  kind: kLit, kEob, kVal (a length, a distance, a code-length symbol), kSub; none set = unassigned code
+//   bits 16..31 literal byte / base length / base distance / code-length symbol / start of the second-level table
+constexpr uint32_t kLit = 1u << 8, kEob = 1u << 9, kVal = 1u << 10, kSub = 1u << 11;
 constexpr int kLitRoot = 10, kDistRoot = 8;
-constexpr int kLitEntries = 2048, kDistEntries = 768;                   // first level + second-level space
-constexpr int kWaveLdsHalfwords = kLitEntries + kDistEntries + 160 /*lens[320] as bytes*/ + 128 /*code-length table*/ +
-                                  320 /*sorted*/ + 32 /*count, offs*/;
-constexpr int kWavesPerWg = 4;
+constexpr int kLitEntries = 1344, kDistEntries = 416;   // first + second level: `enough 288 10 15` = 1334, `enough 32 8 15` = 402
+constexpr int kWaveLdsBytes = 4 * (kLitEntries + kDistEntries + 128 /*code-length table*/) + 320 /*lens*/ + 2 * (320 /*sorted*/ + 32 /*count, offs*/);
+constexpr int kWavesPerWg = 4;      // 16 waves per CU (LDS); 18 waves (2 per workgroup, 5 per SIMD) measured the same: scalar-issue bound
+enum : int { kKindCodeLen = 0, kKindLitLen = 1, kKindDist = 2 };
 
-// u16 entry: bits 0..3 code length, 4..12 symbol (kInvalid = unassigned); second-level pointer: bit 15, bits 0..3 index bits,
-// bits 4..14 start of the second-level table
 __device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
 __device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 __device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// s_len / s_dist: the tables above as LDS words, base << 16 | extra bits << 4 | kVal
+__device__ inline uint32_t make_entry(int kind, uint32_t sym, uint32_t nbits, const uint32_t* s_len, const uint32_t* s_dist) {
+  if (kind == kKindCodeLen) return kVal | (sym << 16) | nbits;
+  if (kind == kKindLitLen) {
+    if (sym < 256) return kLit | (sym << 16) | nbits;
+    if (sym == 256) return kEob | nbits;
+    if (sym < 286) return s_len[sym - 257] | nbits;
+    return nbits;                                    // 286, 287: part of the fixed code, never valid in data
+  }
+  return sym < 30 ? (s_dist[sym] | nbits) : nbits;
+}
+
 // Canonical Huffman code -> two-level table in LDS (serial; called by lane 0 only).  lens: code length per symbol.
 // Returns false for an over-subscribed code or an incomplete one that zlib rejects.
-__device__ inline bool build_table(const uint8_t* lens, int n, bool is_codelen, uint16_t* tab, int root, int cap,
-                                   uint16_t* sorted, uint16_t* count /*[16]*/, uint16_t* offs /*[16]*/) {
+__device__ inline bool build_table(const uint8_t* lens, int n, int kind, uint32_t* tab, int root, int cap,
+                                   uint16_t* sorted, uint16_t* count /*[16]*/, uint16_t* offs /*[16]*/,
+                                   const uint32_t* s_len, const uint32_t* s_dist) {
   for (int k = 0; k < 16; ++k) count[k] = 0;
   for (int s = 0; s < n; ++s) count[lens[s]]++;
   int max = 15;
   while (max >= 1 && !count[max]) --max;
   const int first = 1 << root;
-  for (int k = 0; k < first; ++k) tab[k] = (uint16_t)kInvalid;
+  for (int k = 0; k < first; ++k) tab[k] = 0;
   if (max == 0) return true;                         // no codes: every lookup fails (zlib: error on use)
   int left = 1;
   for (int len = 1; len <= 15; ++len) { left = (left << 1) - (int)count[len]; if (left < 0) return false; }
-  if (left > 0 && (is_codelen || max != 1)) return false;
+  if (left > 0 && (kind == kKindCodeLen || max != 1)) return false;
   offs[1] = 0;
   for (int len = 1; len < 15; ++len) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
   for (int s = 0; s < n; ++s) if (lens[s]) sorted[offs[lens[s]]++] = (uint16_t)s;
@@ -74,8 +95,8 @@ __device__ inline bool build_table(const uint8_t* lens, int n, bool is_codelen, 
     for (int c = 0; c < cnt; ++c, ++sym_i) {
       const uint32_t sym = sorted[sym_i];
       uint32_t rev = __brev(code) >> (32 - len);
-      uint16_t e = (uint16_t)((sym << 4) | (uint32_t)len);
       if (len <= root) {
+        const uint32_t e = make_entry(kind, sym, (uint32_t)len, s_len, s_dist);
         for (uint32_t k = rev; k < (uint32_t)first; k += 1u << len) tab[k] = e;
       } else {
         const uint32_t prefix = rev & (uint32_t)(first - 1);
@@ -88,12 +109,12 @@ __device__ inline bool build_table(const uint8_t* lens, int n, bool is_codelen, 
           sub_start = next_free;
           next_free += 1 << sub_bits;
           if (next_free > cap) return false;
-          for (int k = sub_start; k < next_free; ++k) tab[k] = (uint16_t)kInvalid;
-          tab[prefix] = (uint16_t)(0x8000u | ((uint32_t)sub_start << 4) | (uint32_t)sub_bits);
+          for (int k = sub_start; k < next_free; ++k) tab[k] = 0;
+          tab[prefix] = kSub | ((uint32_t)sub_start << 16) | ((uint32_t)sub_bits << 4);
           cur_prefix = prefix;
         }
         const int hl = len - root;
-        e = (uint16_t)((sym << 4) | (uint32_t)hl);
+        const uint32_t e = make_entry(kind, sym, (uint32_t)hl, s_len, s_dist);
         for (uint32_t k = rev >> root; k < (1u << sub_bits); k += 1u << hl) tab[sub_start + k] = e;
       }
       ++code;
@@ -136,24 +157,21 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 
 __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks,
                                                                 uint32_t n_blocks, uint8_t* out, uint32_t* status /* one word, OR of (1 << error) */) {
-  extern __shared__ uint16_t lds[];
+  extern __shared__ uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t b = blockIdx.x * kWavesPerWg + wave;
-  uint16_t* lit = lds + wave * kWaveLdsHalfwords;
-  uint16_t* dist = lit + kLitEntries;
-  uint8_t* lens = reinterpret_cast<uint8_t*>(dist + kDistEntries);      // 320 bytes
-  uint16_t* cltab = dist + kDistEntries + 160;
-  uint16_t* sorted = cltab + 128;
+  uint32_t* lit = lds + wave * (kWaveLdsBytes / 4);
+  uint32_t* dist = lit + kLitEntries;
+  uint32_t* cltab = dist + kDistEntries;
+  uint8_t* lens = reinterpret_cast<uint8_t*>(cltab + 128);               // 320 bytes
+  uint16_t* sorted = reinterpret_cast<uint16_t*>(lens + 320);
   uint16_t* count = sorted + 320;
   uint16_t* offs = count + 16;
   __shared__ uint32_t build_ok[kWavesPerWg];
-  // length / distance base and extra-bit tables: LDS copies (a lookup in the global-memory constants costs an L2 round
-  // trip per match)
-  __shared__ uint32_t s_len[32], s_dist[32];           // base | extra bits << 16
-  if (threadIdx.x < 29) s_len[threadIdx.x] = kLenBase[threadIdx.x] | ((uint32_t)kLenExtra[threadIdx.x] << 16);
-  if (threadIdx.x >= 30 && threadIdx.x < 32) s_dist[threadIdx.x] = 0;
-  if (threadIdx.x < 30) s_dist[threadIdx.x] = kDistBase[threadIdx.x] | ((uint32_t)kDistExtra[threadIdx.x] << 16);
+  __shared__ uint32_t s_len[32], s_dist[32];           // base << 16 | extra bits << 4 | kVal: table entries minus the code length
+  if (threadIdx.x < 29) s_len[threadIdx.x] = ((uint32_t)kLenBase[threadIdx.x] << 16) | ((uint32_t)kLenExtra[threadIdx.x] << 4) | kVal;
+  if (threadIdx.x < 30) s_dist[threadIdx.x] = ((uint32_t)kDistBase[threadIdx.x] << 16) | ((uint32_t)kDistExtra[threadIdx.x] << 4) | kVal;
   __syncthreads();
   if (b >= n_blocks) return;
 
@@ -166,53 +184,70 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   // the member's output as a buffer descriptor: an offset outside [0, isize) is dropped (store) or reads 0 (load)
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)isize, 0x00020000);
   const uint32_t not_lane0 = lane == 0 ? 0u : 0xFFFFFFFFu;
+  uint32_t lane_zero;                                  // 0 in every lane, opaque to the compiler's uniformity analysis
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
   uint64_t bb = 0;
-  int32_t bc = 0;                                      // bits in bb; negative once a malformed stream has run past its end
+  uint32_t bc = 0;                                     // bits in bb: 56..63 after every refill
   uint32_t pos = 0, err = kOk;
 #ifdef SCFQ_DSTATS
   uint32_t n_blk = 0, n_lit = 0, n_match = 0, n_mbytes = 0, n_overlap = 0, n_long = 0;
 #endif
   bool last = false;
 
-  // the 8-byte gzip trailer follows the deflate data, so an 8-byte load that starts inside the data stays in the chunk.
-  // (A macro, not a lambda: captured-by-reference state ended up in scratch memory, which made every value derived from
-  // it per-lane.)
+  // The bit reader.  bb holds the next bc bits of the stream, ip is the offset of the first byte not yet in bb.  A refill
+  // is branch-free: OR in the 8 bytes at ip, advance ip by the whole bytes that fitted, and bc becomes bc | 56 (which is
+  // bc + 8 * bytes taken).  The bytes come through the SCALAR cache (s_load: the compressed chunk is constant for the
+  // kernel, `comp` is the base of a hipMalloc allocation and so dword-aligned): the aligned dwords that cover the 8
+  // bytes, funnel-shifted by the byte offset.  That keeps the input stream out of vmcnt — with vector loads every refill
+  // waited for the acknowledgement of the stores issued before it — and the dwords are requested one refill AHEAD
+  // (pf: issued when ip is known, read at the next refill).  The load address is clamped to the member's end (the
+  // 8-byte gzip trailer and at least 64 bytes of chunk padding follow the deflate data); ip itself is not, so that
+  // `ip * 8 - bc`, the exact bit position, tells afterwards whether a malformed stream ran past its end.
+  // (Macros, not lambdas: captured-by-reference state ended up in scratch memory, which made every derived value per-lane.)
+  typedef uint32_t dword4 __attribute__((ext_vector_type(4)));
+  typedef const dword4 __attribute__((address_space(4), aligned(4))) const_dword4;
+  typedef const uint8_t __attribute__((address_space(4))) const_byte;
+  const_byte* const in4 = (const_byte*)(uintptr_t)comp;
+  const uint32_t in_off = blk.in_off;
+  dword4 pf;                                           // one value, so that it stays in one register quad across the loop
+  uint32_t pf_sh;
+#define SCFQ_DPREFETCH()                                                                       \
+  do {                                                                                         \
+    const uint32_t a_ = in_off + (ip < ip_end ? ip : ip_end);                                  \
+    pf_sh = (a_ & 3u) << 3;                                                                    \
+    pf = *(const_dword4*)(in4 + (a_ & ~3u));                                                   \
+  } while (0)
 #define SCFQ_DREFILL()                                                                         \
   do {                                                                                         \
-    if (ip < ip_end) {                                                                         \
-      uint64_t w_;                                                                             \
-      __builtin_memcpy(&w_, in + ip, 8);                                                       \
-      w_ = ((uint64_t)uni((uint32_t)(w_ >> 32)) << 32) | uni((uint32_t)w_);                    \
-      const int32_t avail_ = (int32_t)(ip_end - ip);                                           \
-      if (avail_ < 8) w_ &= (1ull << (8 * avail_)) - 1;                                        \
-      bb |= w_ << bc;                                                                          \
-      int32_t take_ = (63 - bc) >> 3;                                                          \
-      if (take_ > avail_) take_ = avail_;                                                      \
-      ip += (uint32_t)take_;                                                                   \
-      bc += take_ * 8;                                                                         \
-    }                                                                                          \
+    const uint32_t up_ = 31u - pf_sh;           /* (x << 1) << up_ == x << (32 - pf_sh), also for pf_sh == 0 */ \
+    const uint32_t lo_ = (pf.x >> pf_sh) | ((pf.y << 1) << up_), hi_ = (pf.y >> pf_sh) | ((pf.z << 1) << up_); \
+    bb |= (((uint64_t)hi_ << 32) | lo_) << bc;                                                                          \
+    ip += (63u - bc) >> 3;                                                                     \
+    bc |= 56u;                                                                                 \
+    SCFQ_DPREFETCH();                                                                          \
   } while (0)
+#define SCFQ_DTAKE(n_) do { bb >>= (n_); bc -= (n_); } while (0)
+  SCFQ_DPREFETCH();
 
   uint32_t guard = 0;                                  // every pass of every loop below consumes input bits or ends
   while (!last && err == kOk) {
     SCFQ_DREFILL();
-    if (bc < 3) { err = kErrData; break; }
+    if (ip > ip_end + 16) { err = kErrData; break; }   // a malformed stream reading (clamped, harmless) bytes past its end
     last = bb & 1;
     const uint32_t type = (uint32_t)(bb >> 1) & 3u;
-    bb >>= 3; bc -= 3;
+    SCFQ_DTAKE(3);
     if (type == 0) {
       // stored: to the byte boundary, LEN / NLEN, then a plain copy (all lanes)
-      const uint32_t drop = bc & 7; bb >>= drop; bc -= drop;
-      SCFQ_DREFILL();
-      if (bc < 32) { err = kErrData; break; }
+      SCFQ_DTAKE(bc & 7);
       const uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
-      bb >>= 32; bc -= 32;
+      SCFQ_DTAKE(32);
       if ((len ^ nlen) != 0xFFFF) { err = kErrData; break; }
-      ip -= (uint32_t)bc >> 3;                                 // whole bytes go back to the byte stream
+      ip -= bc >> 3;                                   // whole bytes go back to the byte stream
       bb = 0; bc = 0;
-      if (ip_end - ip < len || pos + len > isize) { err = kErrData; break; }
+      if (ip > ip_end || ip_end - ip < len || pos + len > isize) { err = kErrData; break; }
       for (uint32_t k = lane; k < len; k += 64) o[pos + k] = in[ip + k];
       ip += len; pos += len;
+      SCFQ_DPREFETCH();
       continue;
     }
     if (type == 3) { err = kErrData; break; }
@@ -223,47 +258,40 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
         for (int k = 144; k < 256; ++k) lens[k] = 9;
         for (int k = 256; k < 280; ++k) lens[k] = 7;
         for (int k = 280; k < 288; ++k) lens[k] = 8;
-        bool ok = build_table(lens, 288, false, lit, kLitRoot, kLitEntries, sorted, count, offs);
+        bool ok = build_table(lens, 288, kKindLitLen, lit, kLitRoot, kLitEntries, sorted, count, offs, s_len, s_dist);
         for (int k = 0; k < 32; ++k) lens[k] = 5;
-        ok = ok && build_table(lens, 32, false, dist, kDistRoot, kDistEntries, sorted, count, offs);
+        ok = ok && build_table(lens, 32, kKindDist, dist, kDistRoot, kDistEntries, sorted, count, offs, s_len, s_dist);
         build_ok[wave] = ok ? 1u : 0u;
       }
     } else {
-      SCFQ_DREFILL();
-      if (bc < 14) { err = kErrData; break; }
       const uint32_t hlit = ((uint32_t)bb & 31) + 257, hdist = ((uint32_t)(bb >> 5) & 31) + 1, hclen = ((uint32_t)(bb >> 10) & 15) + 4;
-      bb >>= 14; bc -= 14;
+      SCFQ_DTAKE(14);
       if (hlit > 286 || hdist > 30) { err = kErrData; break; }
       // the 19 code-length code lengths, then the run-length coded literal/length + distance code lengths: all lanes
       // walk the bits together, lane 0 writes
       if (lane == 0) for (int k = 0; k < 19; ++k) lens[k] = 0;
       for (uint32_t k = 0; k < hclen; ++k) {
-        SCFQ_DREFILL();
-        if (bc < 3) { err = kErrData; break; }
+        if ((k & 7) == 0) SCFQ_DREFILL();              // 8 x 3 bits per refill
         if (lane == 0) lens[kClOrder[k]] = (uint8_t)(bb & 7);
-        bb >>= 3; bc -= 3;
+        SCFQ_DTAKE(3);
       }
-      if (err) break;
-      if (lane == 0) build_ok[wave] = build_table(lens, 19, true, cltab, 7, 128, sorted, count, offs) ? 1u : 0u;
+      if (lane == 0) build_ok[wave] = build_table(lens, 19, kKindCodeLen, cltab, 7, 128, sorted, count, offs, s_len, s_dist) ? 1u : 0u;
       __builtin_amdgcn_wave_barrier();
       if (!__builtin_amdgcn_readfirstlane((int)build_ok[wave])) { err = kErrData; break; }
       uint32_t k = 0, prev = 0;
       const uint32_t total = hlit + hdist;
       while (k < total) {
         if (++guard > (1u << 20)) { err = kErrData; break; }
-        SCFQ_DREFILL();
+        SCFQ_DREFILL();                                // a code-length symbol and its repeat count: at most 7 + 7 bits
         const uint32_t e = uni(cltab[bb & 127]);
-        const uint32_t len = e & 15;
-        if (e == kInvalid || (int32_t)len > bc) { err = kErrData; break; }
-        bb >>= len; bc -= (int32_t)len;
-        const uint32_t sym = e >> 4;
+        if (!(e & kVal)) { err = kErrData; break; }
+        SCFQ_DTAKE(e & 15);
+        const uint32_t sym = e >> 16;
         uint32_t rep = 1, val = sym;
-        if (sym == 16) { if (k == 0 || bc < 2) { err = kErrData; break; } val = prev; rep = 3 + ((uint32_t)bb & 3); bb >>= 2; bc -= 2; }
-        else if (sym == 17) { if (bc < 3) { err = kErrData; break; } val = 0; rep = 3 + ((uint32_t)bb & 7); bb >>= 3; bc -= 3; }
-        else if (sym == 18) { if (bc < 7) { err = kErrData; break; } val = 0; rep = 11 + ((uint32_t)bb & 127); bb >>= 7; bc -= 7; }
+        if (sym == 16) { if (k == 0) { err = kErrData; break; } val = prev; rep = 3 + ((uint32_t)bb & 3); SCFQ_DTAKE(2); }
+        else if (sym == 17) { val = 0; rep = 3 + ((uint32_t)bb & 7); SCFQ_DTAKE(3); }
+        else if (sym == 18) { val = 0; rep = 11 + ((uint32_t)bb & 127); SCFQ_DTAKE(7); }
         if (k + rep > total) { err = kErrData; break; }
-        // the lengths go to a second area (bytes 32..351 would collide with nothing: lens has 320 bytes, the code-length
-        // lengths above are dead once cltab is built)
         if (lane == 0) for (uint32_t r = 0; r < rep; ++r) lens[k + r] = (uint8_t)val;
         k += rep;
         prev = val;
@@ -272,8 +300,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       if (lane == 0) {
         bool ok = lens[256] != 0;
         // distance lengths follow the literal/length ones: build dist first from lens + hlit, then lit (build uses `sorted`)
-        ok = ok && build_table(lens + hlit, (int)hdist, false, dist, kDistRoot, kDistEntries, sorted, count, offs);
-        ok = ok && build_table(lens, (int)hlit, false, lit, kLitRoot, kLitEntries, sorted, count, offs);
+        ok = ok && build_table(lens + hlit, (int)hdist, kKindDist, dist, kDistRoot, kDistEntries, sorted, count, offs, s_len, s_dist);
+        ok = ok && build_table(lens, (int)hlit, kKindLitLen, lit, kLitRoot, kLitEntries, sorted, count, offs, s_len, s_dist);
         build_ok[wave] = ok ? 1u : 0u;
       }
     }
@@ -283,64 +311,55 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     // The loop holds no divergent branch: stores are predicated through the buffer descriptor (a lane that must not write
     // gets an out-of-range offset, which the hardware drops), so every branch below is a scalar branch on wave-uniform
     // state and the compiler emits the loop as written (with `if (lane == 0)` regions inside, the CFG structuriser wrapped
-    // every exit of the loop in a state machine: about 35 scalar instructions per literal on top of the decode).
+    // every exit of the loop in a state machine: about 35 scalar instructions per literal on top of the decode).  For the
+    // same reason it has ONE exit at the bottom and if/else instead of break/continue.
+    // One refill per pass is enough: a literal/length code, its extra bits, a distance code and its extra bits are at
+    // most 15 + 5 + 15 + 13 = 48 of the 56 bits a refill guarantees.
     // Checks are lazy where the hardware already bounds the access: writes beyond ISIZE are dropped by the descriptor
-    // and found by `pos != isize` afterwards; bits consumed beyond the member's end make `bc` negative, which the refill
-    // branch (taken on every pass once the input is exhausted) turns into an error.
-    // Written with ONE exit at the bottom (`done`) and if/else instead of break/continue: a loop with several exits is
-    // rewritten by the compiler's exit unification into the same kind of state machine.
+    // and end the loop (pos > isize); bits taken beyond the member's end are found by the position check after the loop.
+    // A match's store is DEFERRED: the load is issued, the wave goes on decoding, and the store follows when the next
+    // match is about to load (it must be in the memory pipeline before a load that may read those bytes) or when the
+    // block ends, so the load's latency overlaps the next symbols instead of stalling the wave.  pend_off is out of range
+    // in every lane while nothing is pending.
+    // The table addresses are formed on the vector ALU (lit_v / dist_v look per-lane to the compiler): the loop is bound
+    // by the CU's one scalar ALU, every instruction moved off it counts.
+    uint32_t* const lit_v = lit + lane_zero;
+    uint32_t* const dist_v = dist + lane_zero;
     uint32_t done = 0;
+    uint32_t pend_off = 0xFFFFFFFFu;
+    uint8_t pend_v = 0;
 #ifdef SCFQ_DSTATS
     ++n_blk;
 #endif
     do {
-      if (bc < 48) {
-        SCFQ_DREFILL();
-        if (bc < 0) { err = kErrData; done = 1; }
-        if (pos > isize) { err = kErrLength; done = 1; }
+      if (bc < 48) SCFQ_DREFILL();           // (the prefetched dwords stay valid: ip only moves in a refill)
+      uint32_t e = uni(lit_v[bb & ((1u << kLitRoot) - 1)]);
+      if (e & kSub) {
+        SCFQ_DTAKE(kLitRoot);
+        e = uni(lit_v[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 4) & 15)) - 1))]);
       }
-      uint32_t e = uni(lit[bb & ((1u << kLitRoot) - 1)]);
-      if (e & 0x8000u) {                     // second level, or an unassigned code (kInvalid carries the same flag)
-        if (e != kInvalid) {
-          e = uni(lit[((e >> 4) & 0x7FF) + ((uint32_t)(bb >> kLitRoot) & ((1u << (e & 15)) - 1))]);
-          bb >>= kLitRoot; bc -= kLitRoot;
-        }
-      }
-      const uint32_t len = e & 15;           // kInvalid: 15 bits and "symbol" 0xFFF, which the range check below rejects
-      bb >>= len; bc -= (int32_t)len;
-      const uint32_t sym = e >> 4;
-      if (sym < 256) {
-        if (!(SCFQ_DABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)sym, orsrc, pos | not_lane0, 0, 0);
+      SCFQ_DTAKE(e & 15);
+      if (e & kLit) {
+        if (!(SCFQ_DABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(e >> 16), orsrc, pos | not_lane0, 0, 0);
         ++pos;
 #ifdef SCFQ_DSTATS
         ++n_lit;
 #endif
-      } else if (sym == 256) {
-        if (bc < 0) err = kErrData;
-        done = 1;
-      } else if (sym > 285) {
-        err = kErrData; done = 1;
-      } else {
-        const uint32_t lb = uni(s_len[sym - 257]);               // base | extra bits << 16
-        const uint32_t lx = lb >> 16;
-        const uint32_t mlen = (lb & 0xFFFF) + ((uint32_t)bb & ((1u << lx) - 1));
-        bb >>= lx; bc -= (int32_t)lx;
-        if (bc < 28) SCFQ_DREFILL();         // distance code + extra bits: at most 15 + 13
-        uint32_t d = uni(dist[bb & ((1u << kDistRoot) - 1)]);
-        if (d & 0x8000u) {
-          if (d != kInvalid) {
-            d = uni(dist[((d >> 4) & 0x7FF) + ((uint32_t)(bb >> kDistRoot) & ((1u << (d & 15)) - 1))]);
-            bb >>= kDistRoot; bc -= kDistRoot;
-          }
+      } else if (e & kVal) {
+        const uint32_t lx = (e >> 4) & 15;
+        const uint32_t mlen = (e >> 16) + ((uint32_t)bb & ((1u << lx) - 1));
+        SCFQ_DTAKE(lx);
+        uint32_t d = uni(dist_v[bb & ((1u << kDistRoot) - 1)]);
+        if (d & kSub) {
+          SCFQ_DTAKE(kDistRoot);
+          d = uni(dist_v[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 4) & 15)) - 1))]);
         }
-        const uint32_t dl = d & 15;
-        bb >>= dl; bc -= (int32_t)dl;
-        const uint32_t dsym = d >> 4;
-        const uint32_t db = uni(s_dist[dsym & 31]);              // base | extra bits << 16 (entries 30, 31: zero)
-        const uint32_t dx = db >> 16;
-        const uint32_t off = (db & 0xFFFF) + ((uint32_t)bb & ((1u << dx) - 1));
-        bb >>= dx; bc -= (int32_t)dx;
-        if (dsym >= 30 || off > pos) {       // (a BGZF member starts with an empty window)
+        SCFQ_DTAKE(d & 15);
+        const uint32_t dx = (d >> 4) & 15;
+        const uint32_t off = (d >> 16) + ((uint32_t)bb & ((1u << dx) - 1));
+        SCFQ_DTAKE(dx);
+        if (off - 1u >= pos) {               // off > pos (a BGZF member starts with an empty window), or off == 0: the
+                                             // entry of an unassigned distance code has base 0 and no extra bits
           err = kErrData; done = 1;
         } else {
           // The bytes the match reads were stored by this same wave (lane 0's literals, other lanes' earlier copies).
@@ -353,17 +372,22 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #endif
           const uint32_t src0 = pos - off;
+          __builtin_amdgcn_raw_buffer_store_b8(pend_v, orsrc, pend_off, 0, 0);
+          pend_off = 0xFFFFFFFFu;
           if (SCFQ_DABLATE & 1) {
-          } else if (off >= mlen) {
-            for (uint32_t base = 0; base < mlen; base += 64) {
-              const uint32_t k = base + lane;
-              const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + k, 0, 1 /*sc0*/);
-              __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, k < mlen ? pos + k : 0xFFFFFFFFu, 0, 0);
+          } else if (mlen <= 64) {           // one pass of the wave (nested ifs: a combined condition costs the scalar ALU more)
+            if (off >= mlen) {
+              pend_v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + lane, 0, 1 /*sc0*/);
+              pend_off = lane < mlen ? pos + lane : 0xFFFFFFFFu;
+            } else {                         // the match overlaps its own output: period `off`
+              const uint32_t j = off == 1 ? 0u : lane % off;
+              const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + j, 0, 1 /*sc0*/);
+              __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, lane < mlen ? pos + lane : 0xFFFFFFFFu, 0, 0);
             }
-          } else {                           // the match overlaps its own output: period `off`
+          } else {
             for (uint32_t base = 0; base < mlen; base += 64) {
               const uint32_t k = base + lane;
-              const uint32_t j = off == 1 ? 0u : k % off;
+              const uint32_t j = off >= mlen ? k : (off == 1 ? 0u : k % off);
               const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + j, 0, 1 /*sc0*/);
               __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, k < mlen ? pos + k : 0xFFFFFFFFu, 0, 0);
             }
@@ -373,9 +397,17 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
           ++n_match; n_mbytes += mlen; n_overlap += off < mlen; n_long += mlen > 64;
 #endif
         }
+      } else {                               // end of block, or a code that is not assigned
+        if (!(e & kEob)) err = kErrData;
+        done = 1;
       }
+      done |= (isize - pos) >> 31;           // pos > isize (both below 2^17): the descriptor dropped the excess, the stream is malformed
     } while (!done);
+    if (pos > isize && err == kOk) err = kErrLength;
+    __builtin_amdgcn_raw_buffer_store_b8(pend_v, orsrc, pend_off, 0, 0);
   }
+  // bits taken beyond the end of the deflate data (they were trailer bytes, or the clamped load's): the stream is malformed
+  if (err == kOk && (uint64_t)ip * 8 - bc > (uint64_t)ip_end * 8) err = kErrData;
   if (err == kOk && pos != isize) err = kErrLength;
   // ---- CRC-32 of the member: every lane the standard CRC of a contiguous slice, then 63 combines ------------------------
   if (err == kOk && !(SCFQ_DABLATE & 2)) {
@@ -398,6 +430,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     if (total != blk.crc) err = kErrCrc;
   }
 #undef SCFQ_DREFILL
+#undef SCFQ_DPREFETCH
+#undef SCFQ_DTAKE
 #ifdef SCFQ_DSTATS
   if (lane == 0) { atomicAdd(status + 1, n_blk); atomicAdd(status + 2, n_lit); atomicAdd(status + 3, n_match); atomicAdd(status + 4, n_mbytes >> 4); atomicAdd(status + 5, n_overlap); atomicAdd(status + 6, n_long); }
 #endif
