@@ -75,5 +75,34 @@ for rep in range(10):
     assert scfq.dedup_host(two)[0] == first
 assert first == a.tobytes()
 print("10 repeated de-duplications identical")
+# device-side BGZF inflate: one 512 MB file counted 20 times, then by 4 threads at once (own sessions, shared device)
+import zlib, struct, os
+from concurrent.futures import ThreadPoolExecutor
+bplan = scfq.synth_plan(0, 17, 512 << 20)
+bdata, binfo = scfq.synth_host(0, 17, bplan.records)
+def bgzf_block(b):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15); p = co.compress(b) + co.flush(); bs = 18 + len(p) + 8
+    return b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bs - 1) + p + struct.pack("<II", zlib.crc32(b) & 0xFFFFFFFF, len(b))
+def span(x):
+    raw = x.tobytes(); return b"".join(bgzf_block(raw[i:i + 0xff00]) for i in range(0, len(raw), 0xff00))
+with ThreadPoolExecutor(16) as ex:
+    blobs = list(ex.map(span, [bdata[i:i + 0xff00 * 256] for i in range(0, bdata.size, 0xff00 * 256)]))
+bpath = "/tmp/scfq_soak.fq.gz"
+with open(bpath, "wb") as f:
+    for b in blobs: f.write(b)
+bwant = (bplan.records, binfo.gc_bases, binfo.n_bases, binfo.bases)
+def bcount():
+    c = scfq.count_file(bpath); return (c.reads, c.gc_bases, c.n_bases, c.bases)
+bbad = sum(bcount() != bwant for _ in range(20))
+print("20 repeated device-inflated BGZF counts, mismatches:", bbad)
+berrs = []
+def bworker(k):
+    for rep in range(5):
+        if bcount() != bwant: berrs.append((k, rep))
+ts = [threading.Thread(target=bworker, args=(k,)) for k in range(4)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("4 threads x 5 concurrent BGZF counts, mismatches:", len(berrs))
+os.remove(bpath)
+assert bbad == 0 and not berrs
 assert bad == 0 and not errs
 PY
