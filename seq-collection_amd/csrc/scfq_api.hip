@@ -456,6 +456,8 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
 // ---- BGZF with device-side inflate: the host only walks the member headers and moves COMPRESSED bytes ---------------
 constexpr uint32_t kMaxBlocksPerChunk = 1u << 18;
 constexpr int kFallbackToHost = 1;        // ingest_bgzf_device: could not set up, nothing queued
+constexpr int kNotPureBgzf = 2;           // ingest_bgzf_device: the file holds something other than BGZF members <= 64 KiB (found on the
+                                          // way: the header walk runs chunk by chunk under the device's work); queue drained, session to restart
 constexpr uint64_t kStagePad = 4096;      // inflated chunks start one tile into their buffer: byte [-1] carries the look-behind
 
 static int64_t bgzf_plan(const uint8_t* img, uint64_t n, uint64_t pos, uint64_t out_cap, uint64_t comp_cap, uint32_t max_blocks,
@@ -526,7 +528,7 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
 // 16448 members on 4096 wave slots the 64 members of a fifth round ran alone for a fifth of the kernel's time (measured:
 // 24.7 ms for 16448 members, 20.7 ms for 14192).  The member count of a full chunk is therefore a multiple of the slots
 // (CUs x resident waves of bgzf_inflate, asked of the runtime); the byte caps of the chunk still apply.
-static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk) {
+static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, bool first = false) {
   static const uint32_t slots = [] {
     int dev = 0, cus = 0, wgs = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -539,6 +541,7 @@ static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk) {
   }();
   const uint64_t fit = inflated_chunk >> 16;           // members of the maximum size (64 KiB) that fit the chunk
   if (!slots || fit < slots) return kMaxBlocksPerChunk;
+  if (first) return slots;                             // the first launch is one round: the device starts after 1/4 of the copy
   return (uint32_t)std::min<uint64_t>(kMaxBlocksPerChunk, fit / slots * slots);
 }
 
@@ -563,8 +566,12 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
     const auto tf = clk::now();
     uint32_t nb = 0;
     uint64_t ob = 0;
-    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, bgzf_members_per_launch(chunk), c->h_blk[b], &nb, &ob);
-    if (used < 0) return SCFQ_EGZ;
+    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, bgzf_members_per_launch(chunk, it == 0), c->h_blk[b], &nb, &ob);
+    if (used < 0) {                                    // not a BGZF member, or a truncated one: the host path decides what it is
+      HIPCHK(hipStreamSynchronize(c->copy));
+      HIPCHK(hipStreamSynchronize(c->compute));
+      return kNotPureBgzf;
+    }
     if (used == 0) break;
     const uint8_t* src = img + pos;
     parallel_pieces((uint64_t)used, [&](uint64_t o, uint64_t len) { std::memcpy(c->h_comp[b] + o, src + o, len); return 0; });
@@ -764,11 +771,12 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
           void* m = mmap(nullptr, (size_t)bsb.st_size, PROT_READ, MAP_PRIVATE, bfd, 0);
           if (m != MAP_FAILED) {
             (void)madvise(m, (size_t)bsb.st_size, MADV_SEQUENTIAL);
-            if (bgzf_is_pure(static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size)) {
-              rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing);
-              on_device = (rc != kFallbackToHost);
-              if (!on_device) rc = SCFQ_OK;
-            }
+            // (no purity walk up front: touching every member header of a mapped 1 GB file costs 15 ms of page faults;
+            // the chunk planner walks them anyway, under the device's work, and reports what it cannot take)
+            rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing);
+            on_device = (rc != kFallbackToHost && rc != kNotPureBgzf);
+            if (rc == kNotPureBgzf) rc = begin_session(c, true);      // drop what the device path accumulated
+            else if (!on_device) rc = SCFQ_OK;
             munmap(m, (size_t)bsb.st_size);
           }
         }

@@ -127,3 +127,29 @@ def test_dedup_of_a_bgzf_file_is_staged_by_the_device_inflate(gpu, scfq, oracle,
     with pytest.raises(scfq.ScfqError) as e:
         scfq.dedup_file(str(g), -1)
     assert e.value.rc == scfq.SCFQ_EGZ
+
+
+def test_file_that_stops_being_bgzf_restarts_on_the_host_path(gpu, scfq, oracle, tmp_path):
+    """The device path no longer walks every member header before it starts: a member it cannot take (plain gzip, a
+    member larger than 64 KiB, a truncated tail) is found on the way, after chunks were already counted on the device;
+    the count must restart on the host path and come out as if the device path had never run."""
+    d1, d2 = fastq_bytes(4_000_000, seed=31), fastq_bytes(700_000, seed=32)
+    big = zlib.compressobj(6, zlib.DEFLATED, 31)
+    big_member = big.compress(d2) + big.flush()                                   # one plain gzip member of 700 KB
+    cases = {
+        "gzip_member_in_the_middle.fq.gz": (bgzf_file(d1, eof_marker=False) + gzip.compress(d2) + bgzf_file(d1[:300_000]), d1 + d2 + d1[:300_000]),
+        "gzip_member_at_the_end.fq.gz": (bgzf_file(d1, eof_marker=False) + big_member, d1 + d2),
+    }
+    for name, (blob, data) in cases.items():
+        f = tmp_path / name
+        f.write_bytes(blob)
+        oc = oracle.count(np.frombuffer(data, dtype=np.uint8))
+        c = scfq.count_file(str(f), flags=scfq.SCFQ_QUAL_HIST)
+        for fld in ("reads", "gc_bases", "n_bases", "bases", "lines", "newlines", "input_bytes"):
+            assert getattr(c, fld) == getattr(oc, fld), (name, fld)
+        assert list(c.qual_hist) == list(oc.qual_hist), name
+    # a truncated last member: an error on either path, never a count
+    g = tmp_path / "cut.fq.gz"
+    g.write_bytes(bgzf_file(d1)[:-40])
+    with pytest.raises(scfq.ScfqError):
+        scfq.count_file(str(g))
