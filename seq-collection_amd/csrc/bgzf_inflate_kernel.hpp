@@ -26,7 +26,7 @@
 namespace scfq_dinflate {
 
 #ifndef SCFQ_DABLATE
-#define SCFQ_DABLATE 0      // measurement builds only (scripts/gpu_dinflate_ablate.sh): 1 no match copies, 2 no CRC, 4 no literal stores
+#define SCFQ_DABLATE 0      // measurement builds only (scripts/gpu_dinflate_ablate.sh): 1 no match copies, 2 no CRC, 4 no literal stores, 8 / 16 ten extra scalar / vector instructions per symbol
 #endif
 
 struct Block {              // offsets are relative to the chunk's compressed / inflated buffers
@@ -333,6 +333,18 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
 #endif
     do {
       if (bc < 48) SCFQ_DREFILL();           // (the prefetched dwords stay valid: ip only moves in a refill)
+      if (SCFQ_DABLATE & 8) {                // measurement only: ten more scalar instructions per symbol
+        uint32_t t_ = pos;
+#pragma unroll
+        for (int q_ = 0; q_ < 10; ++q_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(t_) : : "scc");
+        asm volatile("" : : "s"(t_));
+      }
+      if (SCFQ_DABLATE & 16) {               // measurement only: ten more vector instructions per symbol
+        uint32_t t_ = lane;
+#pragma unroll
+        for (int q_ = 0; q_ < 10; ++q_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_));
+        asm volatile("" : : "v"(t_));
+      }
       uint32_t e = uni(lit_v[bb & ((1u << kLitRoot) - 1)]);
       if (e & kSub) {
         SCFQ_DTAKE(kLitRoot);
