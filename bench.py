@@ -3,10 +3,12 @@
 
 One "step" = one pass of the hot path (scan kernel K1 + ordered fold K2 + the partial exchange across
 ranks) over one HBM-resident batch of synthetic FASTQ.  N=1 workload = BASELINE.json configs[1]:
-synthetic 10 GB uncompressed 150 bp Illumina FASTQ (seed 20260101).  For N>1 every rank
-holds its own 10 GB byte range of one N x 10 GB record stream, cut at ARBITRARY byte offsets (not record
-aligned), scans it, and the ranks exchange their 32-word partials with one RCCL all_gather (the combine is
-ordered / non-commutative, so a sum-allreduce of counters would be wrong) -> "scaling": "weak".
+synthetic 10 GB uncompressed 150 bp Illumina FASTQ (seed 20260101).  N>1 workload =
+BASELINE.json configs[2]: every rank holds its own 25 GB byte range (200 GB / 8) of one N x 25 GB record
+stream (seed 20260102), cut at ARBITRARY byte offsets (not record aligned), scans it, and the ranks
+exchange their 32-word partials with one RCCL all-gather issued by the C library itself (scfq_comm_*,
+librccl; the combine is ordered / non-commutative, so a sum-allreduce of counters would be wrong)
+-> "scaling": "weak".  torch.distributed only provides the contract's barrier and the max over ranks.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -73,13 +75,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bytes-per-gpu", type=float, default=10e9, help="bytes of FASTQ resident per GPU")
+    ap.add_argument("--bytes-per-gpu", type=float, default=0,
+                    help="bytes of FASTQ resident per GPU (default: 10e9 at N=1 = configs[1]; 25e9 at N>1 = configs[2], 200 GB / 8)")
     ap.add_argument("--workload", choices=["illumina", "nanopore"], default="illumina")
     ap.add_argument("--cpu-sample-bytes", type=float, default=10.1e9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra SCFQ_* flags (1 = qual hist, 2 = struct check)")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic (ablation builds): skip the counter checks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--exchange", choices=["lib", "torch"], default="lib",
+                    help="lib = the C library's own communicator (scfq_comm_*, librccl; default with the nccl backend); "
+                         "torch = the Python mirror over torch.distributed (always used with gloo)")
+    ap.add_argument("--exchange-timeout-s", type=float, default=120.0, help="deadline of one exchange: a stuck collective ends the run non-zero")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo backend); the number is not a scaling result")
     ap.add_argument("--exchange-at-1", action="store_true",
@@ -114,10 +121,12 @@ def main():
         kw = {"device_id": dev} if args.backend == "nccl" else {}
         dist.init_process_group(args.backend, rank=0, world_size=1, **kw)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
+    tmo_ms = int(args.exchange_timeout_s * 1e3)
 
     kind = 0 if args.workload == "illumina" else 1
-    seed = SEED if kind == 0 else 20260103
-    per = int(args.bytes_per_gpu)
+    # N=1: BASELINE configs[1] (10 GB, seed 20260101); N>1: configs[2] (25 GB per GPU = 200 GB / 8, seed 20260102)
+    seed = (SEED if world == 1 else 20260102) if kind == 0 else 20260103
+    per = int(args.bytes_per_gpu) if args.bytes_per_gpu > 0 else int(10e9 if world == 1 else 25e9)
     lo, hi = rank * per, (rank + 1) * per   # this rank's byte range of the N x per stream: arbitrary cut points
 
     # ---- build this rank's shard directly in HBM (not timed) ------------------------------------------
@@ -140,15 +149,42 @@ def main():
 
     flags = scfq.SCFQ_TIMING | args.flags
 
-    class Exchanger:
-        """the exchange + rank-ordered fold of a step's partial on ONE persistent helper thread: all_gather, device->host copy
-        and the host fold of step k run while the main thread is inside the (GIL-free) C call that scans step k+1"""
+    class LibExchange:
+        """the exchange inside the C library (scfq_comm_*: pinned staging, ncclAllGather of ncclUint64 on a private stream,
+        rank-ordered fold) — its worker thread runs the collective while this thread is inside the C call that scans the next
+        step, so submit() never blocks and wait() normally finds the result ready"""
+        def __init__(self):
+            # rank 0 creates the RCCL unique id, the ranks fetch it from torch.distributed's store (no collective involved)
+            if world > 1:
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    store.set("scfq_comm_uid", scfq.Comm.unique_id())
+                uid = bytes(store.get("scfq_comm_uid"))
+            else:
+                uid = scfq.Comm.unique_id()
+            self.comm = scfq.Comm.init_rank(uid, world, rank, local_rank, timeout_ms=tmo_ms)
+            self.what = "%s ncclAllGather of 32 x u64 partials inside libsc_fqcount_hip (scfq_comm_*) + rank-ordered fold" % self.comm.transport
+
+        def submit(self, partial):
+            self.comm.start(partial, timeout_ms=tmo_ms)
+
+        def wait(self):
+            return scfq.finalize(self.comm.finish(timeout_ms=tmo_ms))
+
+        def close(self):
+            self.comm.destroy()
+
+    class TorchExchange:
+        """the Python mirror (pyhost/scfq_dist.py over torch.distributed) on ONE persistent helper thread: all_gather,
+        device->host copy and the host fold of step k run while the main thread is inside the (GIL-free) C call that scans
+        step k+1.  Used with the gloo backend (rehearsals on one device) and with --exchange torch."""
         def __init__(self):
             import queue
             import threading
             self.q_in, self.q_out = queue.SimpleQueue(), queue.SimpleQueue()
             self.t = threading.Thread(target=self._run, daemon=True)
             self.t.start()
+            self.what = "%s all_gather of 32 x u64 partials via torch.distributed + rank-ordered fold" % ("RCCL" if args.backend == "nccl" else args.backend)
 
         def _run(self):
             torch.cuda.set_device(dev)          # the current device is thread-local
@@ -169,19 +205,46 @@ def main():
 
         def submit(self, partial):
             self.q_in.put(partial)
-            return self
 
         def wait(self):
-            r = self.q_out.get(timeout=300)     # a stuck collective fails the run instead of hanging it
+            r = self.q_out.get(timeout=args.exchange_timeout_s)     # a stuck collective fails the run instead of hanging it
             if isinstance(r, BaseException):
                 raise r
             return r
 
-    exchanger = Exchanger() if exchange else None
+        def close(self):
+            self.q_in.put(None)
+            self.t.join(timeout=10)
+
+    exchanger = None
+    exchange_note = None
+    if exchange:
+        use_lib = args.exchange == "lib" and args.backend == "nccl"
+        if use_lib:
+            # every rank must end up on the same path: a rank whose library communicator failed takes all ranks to the mirror
+            ok, err = 1, ""
+            try:
+                exchanger = LibExchange()
+            except Exception as e:      # noqa: BLE001
+                ok, err = 0, repr(e)
+            if world > 1:
+                t_ok = torch.tensor([ok], dtype=torch.int32, device=xdev)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                all_ok = int(t_ok.item())
+            else:
+                all_ok = ok
+            if not all_ok:
+                if exchanger is not None:
+                    exchanger.close()
+                exchanger = None
+                exchange_note = "library communicator unavailable on at least one rank (%s): exchange ran through torch.distributed" % (err or "another rank")
+                sys.stderr.write("bench.py rank %d: %s\n" % (rank, exchange_note))
+        if exchanger is None:
+            exchanger = TorchExchange()
 
     def step(pending):
-        """one pass over this rank's shard.  The exchange of a step's partial (an RCCL all_gather issued right after that
-        step, on the helper thread) overlaps the following scans: its kernel only gets CUs when the scan it overlaps drains
+        """one pass over this rank's shard.  The exchange of a step's partial (an RCCL all-gather issued right after that
+        step, off this thread) overlaps the following scans: its kernel only gets CUs when the scan it overlaps drains
         (the scan fills every CU), so it completes just AFTER that scan; results are therefore collected two steps late and
         nothing of the exchange is on the critical path except the last two, which are drained inside the timed region"""
         p = scfq.partial_device(shard_ptr, shard_n, prev_byte, flags=flags)
@@ -272,11 +335,14 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": ("synthetic %.0f GB uncompressed 150 bp Illumina FASTQ per GPU, HBM-resident (BASELINE configs[1])"
-                         % (per / 1e9)) if kind == 0 else
+            "workload": (("synthetic %.0f GB uncompressed 150 bp Illumina FASTQ per GPU, HBM-resident (BASELINE configs[1])" % (per / 1e9))
+                         if world == 1 else
+                         ("synthetic %.0f GB uncompressed 150 bp Illumina FASTQ byte-sharded across %d GPUs, %.0f GB per GPU, HBM-resident "
+                          "(BASELINE configs[2]: 200 GB across 8 x MI355X + RCCL exchange%s)"
+                          % (per * world / 1e9, world, per / 1e9, "" if (world == 8 and per == int(25e9)) else "; same shard size per GPU as its N=8 case"))) if kind == 0 else
                         ("synthetic %.0f GB Nanopore-style 500 bp-50 kb FASTQ per GPU, HBM-resident (BASELINE configs[4])" % (per / 1e9)),
             "bytes_per_gpu": shard_n, "seed": seed, "shards": "byte ranges at arbitrary (unaligned) cut points",
-            "exchange": "none" if world == 1 else "%s all_gather of 32 x u64 partials + rank-ordered fold" % ("RCCL" if args.backend == "nccl" else args.backend),
+            "exchange": "none" if not exchange else exchanger.what,
             "flags": args.flags,
         },
         "roofline": {
@@ -289,6 +355,8 @@ def main():
                      "bases": counts.bases, "tsv": scfq.format_tsv(counts), "matches_generator_tally": exact},
         "setup_s": round(gen_s, 2),
     }
+    if exchange_note:
+        out["config"]["exchange_note"] = exchange_note
     # the same device's read-stream ceiling: the scan kernel's load structure with no compute (diagnostic kernel)
     al = (-shard_ptr) % 4096
     if shard_n > al + (1 << 20):
@@ -306,6 +374,7 @@ def main():
                 j = json.load(f)
             if int(j.get("bytes_per_launch", -1)) == shard_n:
                 out["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (offline rocprofv3 --pmc passes over this same workload and kernel: %s; not measured in this run)" % j.get("source", "")
         except Exception:
             pass
 
@@ -346,10 +415,19 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if exchange:
-        exchanger.q_in.put(None)
-        exchanger.t.join()
+        exchanger.close()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:      # noqa: BLE001
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        # a failed or stuck collective must END the rank (non-zero), never leave it waiting in an atexit hook or a join
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)

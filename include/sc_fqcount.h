@@ -35,6 +35,8 @@ extern "C" {
 #define SCFQ_EARG    (-5)  /* bad argument (NULL pointer, struct_size mismatch, bad flag) */
 #define SCFQ_EIO     (-6)  /* read error after a successful open */
 #define SCFQ_ENOMEM  (-7)  /* host allocation failed */
+#define SCFQ_EPIPE   (-9)  /* the reader of an output descriptor went away (write -> EPIPE): `sc fq-dedup | head` ends quietly with
+                              status 0 as the reference does for `errno: 32 Broken pipe` (sc.nim:304); every other write error is SCFQ_EIO */
 #define SCFQ_ESPEC   (-8)  /* the speculative quality histogram of a shard backed a class that is not the quality line
                               (malformed input cut into shards): count that shard again with SCFQ_HIST_EXACT.
                               scfq_count_file / scfq_count_buffer do this by themselves and never return it. */
@@ -44,6 +46,7 @@ extern "C" {
 #define SCFQ_STRUCT_CHECK  0x2u  /* also count header lines not starting '@' / separator lines not starting '+' (K4) */
 #define SCFQ_TIMING        0x4u  /* bracket the scan kernel with HIP events; read back with scfq_last_timing() */
 #define SCFQ_PREV_IN_MEMORY 0x8u /* scfq_partial_buffer: the byte before `ptr` is addressable and is the look-behind halo */
+#define SCFQ_WAIT_STREAM   0x20u /* order this call after the work already enqueued on scfq_opts.wait_stream (see there) */
 #define SCFQ_HIST_EXACT    0x10u /* with SCFQ_QUAL_HIST: build all four class histograms exactly (slower kernel) instead of the
                                     verified-speculative form that only completes the quality class (scfq_partial.hist_class) */
 
@@ -70,7 +73,17 @@ typedef struct scfq_opts {
   uint32_t flags;           /* SCFQ_* option flags */
   uint32_t reserved;
   uint64_t chunk_bytes;     /* host->device staging chunk for file / host-buffer ingest; 0 = default (64 MiB) */
+  /* ---- fields below exist when struct_size >= 48 (SCFQ_OPTS_V1_SIZE = 40 is still accepted) ---- */
+  void*    wait_stream;     /* hipStream_t of the CALLER, read when SCFQ_WAIT_STREAM is set in flags (NULL then names the legacy
+                               default stream). Device-pointer arguments (inputs and outputs) are used on library-private
+                               non-blocking streams, which do not order against the stream that produced the input or last
+                               used the output buffer. With SCFQ_WAIT_STREAM the library records an event on this stream at
+                               entry and makes its own streams wait for it, so work already enqueued there completes first.
+                               Without it the caller has synchronised (hipStreamSynchronize / hipDeviceSynchronize) before
+                               the call. Every entry point synchronises its own streams before it returns, so results are
+                               visible to any stream afterwards. */
 } scfq_opts;
+#define SCFQ_OPTS_V1_SIZE 40u
 
 /*
  * The shard partial: what a contiguous byte range contributes when its line
@@ -93,7 +106,7 @@ typedef struct scfq_partial {
   uint64_t hist_class;    /* K3 side array: 0 = all four class histograms are complete; k+1 (k = 0..3) = only class k is
                              (the speculative form histograms just the lines it verified to be quality lines);
                              5 = none (shards that disagree were combined: finalize returns SCFQ_ESPEC) */
-  uint64_t reserved[4];
+  uint64_t reserved[4];   /* [0]: status word, OR-ed by the combine (scfq_count_file_sharded: a rank whose shard failed); rest 0 */
 } scfq_partial;
 
 #define SCFQ_HIST_WORDS (4 * 256)  /* optional K3 side array: uint64_t hist[4][256], class-major */
@@ -137,6 +150,51 @@ int  scfq_partial_combine(scfq_partial* acc, const scfq_partial* b, uint64_t* hi
 /* Interpret a partial folded from the start of the file: select the sequence class, derive
  * lines and reads (ceil(lines/4), src/fq_count.nim:39-41). */
 int  scfq_partial_finalize(const scfq_partial* p, const uint64_t* hist, scfq_counts* out);
+
+/* ---- C1: the cross-rank exchange of shard partials -----------------------------
+ * The reference is one process with no collective (one call per file, sc.nim:114-116); the exchange exists because the
+ * input is byte-range sharded across the GPUs of a node. Every rank contributes the partial of its shard; all ranks
+ * receive the same rank-ordered (+) fold (an all-gather of the 32-word partials over RCCL / xGMI and the ordered combine —
+ * NOT a sum-allreduce of counters: (+) is not commutative). librccl is dlopen()ed on first use.
+ * A communicator runs its RCCL / HIP calls on its own worker thread; every wait has a deadline (timeout_ms, <= 0 means
+ * 300 s) and a missing or stuck rank comes back as SCFQ_ERCCL, never as a hang. scfq_comm_error_detail() has the text.
+ * One communicator per (process, device); calls on one communicator come from one host thread at a time. */
+typedef struct scfq_comm scfq_comm;
+#define SCFQ_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+#define SCFQ_COMM_RCCL 0         /* ncclAllGather of ncclUint64 on a private stream of the rank's device */
+#define SCFQ_COMM_TCP  1         /* host sockets through rank 0: explicit opt-in for hosts without a common RCCL fabric and for
+                                    CPU-only tests of the multi-process path; needs no device; never chosen by the library itself */
+
+/* One process per GPU, the host distributes the id itself (rank 0 creates it, every rank passes the same bytes): */
+int scfq_comm_unique_id(void* id, uint64_t cap /* >= SCFQ_COMM_ID_BYTES */);
+int scfq_comm_init_rank(const void* id, int world, int rank, int device, int timeout_ms, scfq_comm** out);
+/* One process per GPU, the library distributes the id: rank 0 listens on host:port (IPv4 name or address, NULL = 127.0.0.1),
+ * the other ranks connect (retrying until the deadline). transport = SCFQ_COMM_RCCL | SCFQ_COMM_TCP. */
+int scfq_comm_init_rendezvous(const char* host, int port, int world, int rank, int device, int transport, int timeout_ms,
+                              scfq_comm** out);
+/* One process, n distinct devices (ncclCommInitAll): out[k] is the communicator of device_ids[k], rank k. */
+int scfq_comm_init_all(int n, const int32_t* device_ids, int timeout_ms, scfq_comm** out);
+int scfq_comm_world(const scfq_comm* c);
+int scfq_comm_rank(const scfq_comm* c);
+const char* scfq_comm_transport(const scfq_comm* c);   /* "RCCL 2.x.y" | "tcp"; thread-local static storage */
+/* folded = P_0 (+) P_1 (+) ... (+) P_{world-1}, identical on every rank. hist: NULL on every rank, or uint64_t[SCFQ_HIST_WORDS]
+ * on every rank (then hist_folded receives the folded class histograms). */
+int scfq_comm_exchange(scfq_comm* c, const scfq_partial* mine, const uint64_t* hist, scfq_partial* folded,
+                       uint64_t* hist_folded, int timeout_ms);
+/* The same in two halves, so that a host can scan shard k+1 while the exchange of shard k is in flight; finishes answer
+ * starts in order. */
+int scfq_comm_exchange_start(scfq_comm* c, const scfq_partial* mine, const uint64_t* hist, int timeout_ms);
+int scfq_comm_exchange_finish(scfq_comm* c, scfq_partial* folded, uint64_t* hist_folded, int timeout_ms);
+/* all[r * words + k] = word k of rank r (words <= 1056): barriers and max-over-ranks timings of a non-Python host. */
+int scfq_comm_allgather_u64(scfq_comm* c, const uint64_t* mine, uint32_t words, uint64_t* all, int timeout_ms);
+int scfq_comm_destroy(scfq_comm* c);
+const char* scfq_comm_error_detail(void);   /* static, thread-local */
+
+/* fq_count of ONE file by all ranks of a communicator: rank r scans bytes [size*r/world, size*(r+1)/world) of `path` — cut at
+ * arbitrary byte offsets, one byte of look-behind — on the current device (or opts->device_ids[0]), the partials are
+ * exchanged, every rank receives the counters of the whole file. Gzip input has no byte-range shards: rank 0 inflates and
+ * scans all of it, the other ranks contribute the identity. Collective: every rank must call it. */
+int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* comm, scfq_counts* out);
 
 /* ---- K5: line index (record-boundary detection) ---------------------------------------------
  * Lines as the reference's `lines(stream)` yields them (src/fq_count.nim:38, src/fq_dedup.nim:42): record i of a FASTQ
@@ -198,25 +256,16 @@ const char* scfq_strerror(int rc);   /* static storage */
 const char* scfq_last_error_detail(void); /* static, thread-local: e.g. the failing HIP call */
 int  scfq_last_timing(scfq_timing* t);
 int  scfq_device_count(void);        /* number of visible HIP devices, or negative on error */
-/* Diagnostic: ranges of this thread's last histogram session that the speculative K3 form served / that were (re)done
- * by the exact kernel (no guess, or a guess that did not verify). */
-int  scfq_debug_hist_stats(uint64_t* fast_ranges, uint64_t* redone_ranges);
+/* Default caller stream of THIS host thread for the entry points that take device pointers but no scfq_opts
+ * (scfq_index_lines, scfq_dedup_buffer) and for calls without SCFQ_WAIT_STREAM: same contract as scfq_opts.wait_stream.
+ * enable = 0 (the initial state): the caller synchronises before calling. hip_stream = NULL with enable != 0 names the
+ * legacy default stream. scfq_get_wait_stream returns the stream, *enabled (may be NULL) whether one is set. */
+int   scfq_set_wait_stream(void* hip_stream, int enable);
+void* scfq_get_wait_stream(int* enabled);
 int  scfq_shutdown(void);            /* frees streams, pinned and device scratch; safe to call twice */
 
-/* Diagnostic only (used by the parity tests as a second, independent device implementation):
- * byte-serial HIP kernel, one thread per 256 bytes. Never called by the counting entry points. */
-int  scfq_debug_partial_simple(const void* device_ptr, uint64_t n, int prev_byte, scfq_partial* out);
-/* Diagnostic only: the byte stream scfq_count_file() would scan for `path` (plain pread, BGZF block-parallel
- * inflate, or serial gzread), produced on the host without any device. Returns bytes written or a negative code. */
-int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk_bytes);
-/* Diagnostic only: inflate a whole BGZF image (host memory) with the device-side inflate kernel, result to host memory.
- * Returns the inflated size, SCFQ_EARG when the image is not pure BGZF or does not fit into cap, SCFQ_EGZ for a corrupt
- * member (deflate data, ISIZE or CRC-32). */
-int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64_t cap);
-/* Diagnostic only: milliseconds (best of `reps`) the scan kernel's LOAD STRUCTURE alone (same ranges, same non-temporal
- * LDS-DMA ring, no classification / accounting) needs for the whole tiles of a 4 KiB-aligned device buffer: the
- * practical read-stream ceiling on this device, reported next to the roofline by bench.py. Negative on error. */
-double scfq_debug_stream_ms(const void* device_ptr, uint64_t n, int reps);
+/* Diagnostic entry points (scfq_debug_*: a second device implementation for the parity tests, host-only readers, the
+ * stream-ceiling probe) are declared in sc_fqcount_debug.h; a reference-side binding needs none of them. */
 
 /* ---- synthetic workloads of SURVEY.md §8(d) / BASELINE.json configs ------------------------
  * Counter-based generator: record i of a workload is a pure function of (seed, i), so host and

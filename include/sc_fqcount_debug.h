@@ -1,0 +1,37 @@
+/*
+ * sc_fqcount_debug.h — diagnostic entry points of libsc_fqcount_hip.so. NOT part of the drop-in boundary
+ * (include/sc_fqcount.h): nothing here is needed by a reference-side binding of `sc fq-count`
+ * (src/fq_count.nim:14-53); the parity tests, bench.py's stream-ceiling probe and the measurement scripts use them.
+ * No counting entry point calls any of these.
+ */
+#ifndef SC_FQCOUNT_DEBUG_H
+#define SC_FQCOUNT_DEBUG_H
+
+#include "sc_fqcount.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostic: ranges of this thread's last histogram session that the speculative K3 form served / that were (re)done
+ * by the exact kernel (no guess, or a guess that did not verify). */
+int  scfq_debug_hist_stats(uint64_t* fast_ranges, uint64_t* redone_ranges);
+/* Diagnostic only (used by the parity tests as a second, independent device implementation):
+ * byte-serial HIP kernel, one thread per 256 bytes. Never called by the counting entry points. */
+int  scfq_debug_partial_simple(const void* device_ptr, uint64_t n, int prev_byte, scfq_partial* out);
+/* Diagnostic only: the byte stream scfq_count_file() would scan for `path` (plain pread, BGZF block-parallel
+ * inflate, or serial gzread), produced on the host without any device. Returns bytes written or a negative code. */
+int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk_bytes);
+/* Diagnostic only: inflate a whole BGZF image (host memory) with the device-side inflate kernel, result to host memory.
+ * Returns the inflated size, SCFQ_EARG when the image is not pure BGZF or does not fit into cap, SCFQ_EGZ for a corrupt
+ * member (deflate data, ISIZE or CRC-32). */
+int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64_t cap);
+/* Diagnostic only: milliseconds (best of `reps`) the scan kernel's LOAD STRUCTURE alone (same ranges, same non-temporal
+ * LDS-DMA ring, no classification / accounting) needs for the whole tiles of a 4 KiB-aligned device buffer: the
+ * practical read-stream ceiling on this device, reported next to the roofline by bench.py. Negative on error. */
+double scfq_debug_stream_ms(const void* device_ptr, uint64_t n, int reps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_FQCOUNT_DEBUG_H */

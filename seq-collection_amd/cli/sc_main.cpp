@@ -117,7 +117,11 @@ static void help_fq_count(FILE* f) {   // docs/fq-count.md:5-19
       "      --struct-check         Report header lines not starting '@' / separator lines not starting '+' on stderr\n"
       "      --qual-hist            Print the quality-byte histogram on stderr\n"
       "      --stats                Print bytes / device milliseconds / GB/s as JSON on stderr\n"
-      "      --jobs=N               Keep up to N files in flight (rows still come out in argument order)\n",
+      "      --jobs=N               Keep up to N files in flight (rows still come out in argument order)\n"
+      "      --shard-rank=R --shard-world=W --rendezvous=HOST:PORT [--transport=rccl|tcp]\n"
+      "                             One process per GPU: this process scans byte range R of W of every file on its device\n"
+      "                             (--devices=ID, default R), the partials are exchanged (RCCL all-gather), rank 0 prints\n"
+      "                             the rows. Defaults come from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.\n",
       f);
 }
 
@@ -145,13 +149,15 @@ struct FileResult {
 };
 
 // proc fq_count*(fastq: string, basename: bool, absolute: bool)      src/fq_count.nim:14  (compute part)
-static FileResult fq_count_compute(const std::string& fastq, bool basename, bool absolute, const scfq_opts& opts, bool stats) {
+static FileResult fq_count_compute(const std::string& fastq, bool basename, bool absolute, const scfq_opts& opts, bool stats,
+                                   scfq_comm* comm = nullptr) {
   FileResult r;
   if (fastq.size() < 3) { r.exit_code = 1; r.error = "index out of bounds"; return r; }   // fastq[^3 .. ^1] raises; sc.nim:299-305 -> exit 1
   scfq_counts c;
   std::memset(&c, 0, sizeof c);
   c.struct_size = sizeof c;
-  const int rc = scfq_count_file(fastq.c_str(), &opts, &c);
+  // one process per GPU: this rank's byte range, exchange, every rank gets the whole file's counters
+  const int rc = comm ? scfq_count_file_sharded(fastq.c_str(), &opts, comm, &c) : scfq_count_file(fastq.c_str(), &opts, &c);
   if (rc == SCFQ_EOPEN) {
     const bool gz = fastq.compare(fastq.size() - 3, 3, ".gz") == 0;
     // plain: stream == nil -> quit_error(..., 2) (fq_count.nim:35-36); .gz: the stream constructor raises -> exit 1 (sc.nim:299-305)
@@ -243,7 +249,7 @@ static int cmd_fq_dedup(const std::vector<std::string>& params) {
   std::fflush(stdout);
   const int rc = scfq_dedup_file(fastq.c_str(), nullptr, 1, &st);
   if (rc == SCFQ_EOPEN) quit_error("Unable to open file: " + fastq, 2);                         // fq_dedup.nim:37-38
-  if (rc == SCFQ_EIO) return 0;                                                                 // EPIPE: swallowed like sc.nim:304
+  if (rc == SCFQ_EPIPE) return 0;              // `errno: 32 Broken pipe` is swallowed (sc.nim:304); any other IOError exits 1 (sc.nim:299-305)
   if (rc != SCFQ_OK) quit_error(std::string(scfq_strerror(rc)) + ": " + scfq_dedup_error_detail() + scfq_last_error_detail(), 1);
   if (st.duplicates == 0) std::fputs("No Duplicates Found\nCopying fq to stdout\n", stderr);   // :51-53 (check.len == 0)
   std::fprintf(stderr, "total_reads: %llu\n", (unsigned long long)st.total_reads);            // :74
@@ -313,6 +319,8 @@ int main(int argc, char** argv) {
 
   bool header = false, basename = false, absolute = false, stats = false;
   int jobs = 1;
+  int shard_rank = -1, shard_world = 0, transport = SCFQ_COMM_RCCL;
+  std::string rendezvous;
   std::vector<std::string> files;
   std::vector<int32_t> devices;
   uint32_t flags = 0;
@@ -330,6 +338,11 @@ int main(int argc, char** argv) {
     else if (a == "--qual-hist") flags |= SCFQ_QUAL_HIST;
     else if (a == "--stats") { stats = true; flags |= SCFQ_TIMING; }
     else if (a.rfind("--jobs=", 0) == 0) jobs = std::max(1, std::atoi(a.substr(7).c_str()));
+    else if (a.rfind("--shard-rank=", 0) == 0) shard_rank = std::atoi(a.substr(13).c_str());
+    else if (a.rfind("--shard-world=", 0) == 0) shard_world = std::atoi(a.substr(14).c_str());
+    else if (a.rfind("--rendezvous=", 0) == 0) rendezvous = a.substr(13);
+    else if (a == "--transport=tcp") transport = SCFQ_COMM_TCP;
+    else if (a == "--transport=rccl") transport = SCFQ_COMM_RCCL;
     else if (a.rfind("--devices=", 0) == 0) {
       const std::string list = a.substr(10);
       size_t p = 0;
@@ -360,6 +373,34 @@ int main(int argc, char** argv) {
   opts.n_devices = (int32_t)devices.size();
   opts.device_ids = devices.empty() ? nullptr : devices.data();
   if (const char* e = std::getenv("SC_GPU_CHUNK")) opts.chunk_bytes = std::strtoull(e, nullptr, 10);
+
+  // ---- one process per GPU (addition): byte-range shard per rank, exchange inside the library, rank 0 prints ----------
+  if (shard_world > 0 || shard_rank >= 0) {
+    if (shard_world <= 0 && std::getenv("WORLD_SIZE")) shard_world = std::atoi(std::getenv("WORLD_SIZE"));
+    if (shard_rank < 0 && std::getenv("RANK")) shard_rank = std::atoi(std::getenv("RANK"));
+    if (rendezvous.empty() && std::getenv("MASTER_PORT"))
+      rendezvous = std::string(std::getenv("MASTER_ADDR") ? std::getenv("MASTER_ADDR") : "127.0.0.1") + ":" + std::getenv("MASTER_PORT");
+    const size_t colon = rendezvous.rfind(':');
+    if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world || colon == std::string::npos)
+      quit_error("--shard-rank / --shard-world / --rendezvous=HOST:PORT do not describe a rank", 1);
+    const std::string host = rendezvous.substr(0, colon);
+    const int port = std::atoi(rendezvous.substr(colon + 1).c_str());
+    if (devices.empty()) devices.push_back(shard_rank);
+    opts.n_devices = 1;
+    opts.device_ids = devices.data();
+    scfq_comm* comm = nullptr;
+    const int rc = scfq_comm_init_rendezvous(host.c_str(), port, shard_world, shard_rank, devices[0], transport, 0, &comm);
+    if (rc) quit_error(std::string(scfq_strerror(rc)) + ": " + scfq_comm_error_detail(), 1);
+    if (header && shard_rank == 0) std::printf("%s\n", output_header(kHeader, basename, absolute).c_str());
+    else if (!header && files.empty()) quit_error("No FASTQ specified", 3);
+    for (const auto& f : files) {
+      const FileResult r = fq_count_compute(f, basename, absolute, opts, stats, comm);
+      if (r.exit_code || shard_rank == 0) fq_count_emit(r);       // every rank quits with the reference's message on an error
+    }
+    scfq_comm_destroy(comm);
+    scfq_shutdown();
+    return 0;
+  }
 
   if (header) std::printf("%s\n", output_header(kHeader, basename, absolute).c_str());   // sc.nim:110-111
   else if (files.empty()) quit_error("No FASTQ specified", 3);                           // sc.nim:112-113

@@ -9,6 +9,7 @@
 // There is NO CPU fallback in this library: without a HIP device every counting entry point returns
 // SCFQ_EHIP.
 #include "../../include/sc_fqcount.h"
+#include "../../include/sc_fqcount_debug.h"
 #include "fq_scan_kernels.hpp"
 #include "scfq_bgzf.hpp"
 #include "scfq_gzfast.hpp"
@@ -94,6 +95,7 @@ struct Ctx {
   uint8_t* h_pin[2] = {nullptr, nullptr};
   uint64_t stage_cap = 0;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
+  hipEvent_t ev_caller = nullptr;      // orders the caller's stream (scfq_opts.wait_stream) before the private ones
   scfq_timing timing{};
   std::mutex mu;   // one counting session at a time per device context
 };
@@ -107,6 +109,9 @@ struct SessionLock {
 };
 
 int env_int(const char* name, int dflt);
+}  // namespace
+extern "C" void scfq_dedup_release_pools(void);      // scfq_dedup.hip
+namespace {
 
 std::mutex g_mu;
 std::map<int, std::vector<std::unique_ptr<Ctx>>> g_ctx;
@@ -401,12 +406,98 @@ uint64_t opt_chunk(const scfq_opts* o) {
   ch = (ch + scfq::kTile - 1) & ~(uint64_t)(scfq::kTile - 1);
   return std::max<uint64_t>(ch, scfq::kTile);
 }
+// the caller's opts as a current-size struct (v1 callers pass 40 bytes: everything after chunk_bytes reads as zero)
+scfq_opts opts_copy(const scfq_opts* o) {
+  scfq_opts c{};
+  if (o) std::memcpy(&c, o, std::min<uint64_t>(o->struct_size, sizeof c));
+  c.struct_size = sizeof c;
+  return c;
+}
+thread_local void* g_wait_stream = nullptr;       // scfq_set_wait_stream(): this host thread's default caller stream
+thread_local bool g_wait_enabled = false;
+bool opt_wait_stream(const scfq_opts* o, void** ws) {
+  if (o && o->struct_size >= sizeof(scfq_opts) && (o->flags & SCFQ_WAIT_STREAM)) { *ws = o->wait_stream; return true; }
+  *ws = g_wait_stream;
+  return g_wait_enabled;
+}
+// Device-pointer arguments are used on the context's private streams; opts->wait_stream (the caller's stream) is ordered
+// before them by an event (include/sc_fqcount.h: scfq_opts.wait_stream).
+int wait_for_caller(Ctx* c, const scfq_opts* o) {
+  void* ws = nullptr;
+  if (!opt_wait_stream(o, &ws)) return SCFQ_OK;
+  if (!c->ev_caller) HIPCHK(hipEventCreateWithFlags(&c->ev_caller, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(c->ev_caller, static_cast<hipStream_t>(ws)));
+  HIPCHK(hipStreamWaitEvent(c->compute, c->ev_caller, 0));
+  HIPCHK(hipStreamWaitEvent(c->copy, c->ev_caller, 0));
+  return SCFQ_OK;
+}
 int check_opts(const scfq_opts* o) {
-  if (o && o->struct_size != sizeof(scfq_opts)) return SCFQ_EARG;
-  if (o && (o->flags & ~(SCFQ_QUAL_HIST | SCFQ_STRUCT_CHECK | SCFQ_TIMING | SCFQ_PREV_IN_MEMORY | SCFQ_HIST_EXACT))) return SCFQ_EARG;
+  if (o && o->struct_size != sizeof(scfq_opts) && o->struct_size != SCFQ_OPTS_V1_SIZE) return SCFQ_EARG;
+  if (o && (o->flags & ~(SCFQ_QUAL_HIST | SCFQ_STRUCT_CHECK | SCFQ_TIMING | SCFQ_PREV_IN_MEMORY | SCFQ_HIST_EXACT | SCFQ_WAIT_STREAM))) return SCFQ_EARG;
   if (o && o->n_devices < 0) return SCFQ_EARG;
   if (o && o->n_devices > 0 && !o->device_ids) return SCFQ_EARG;
   return SCFQ_OK;
+}
+
+// ---- C1 inside one process: communicators of the multi-device path (scfq_opts.n_devices > 1) -------------------------
+// One RCCL communicator per listed device (ncclCommInitAll), kept until scfq_shutdown.  RCCL cannot form a communicator
+// that names a device twice, so a list with repeats (several ingest sessions sharing one GPU to overlap file reads) folds
+// its partials on the host, as does SCFQ_EXCHANGE=host (a host that does not want librccl mapped for 256 bytes per rank).
+std::mutex g_comm_mu;
+std::map<std::vector<int>, std::vector<scfq_comm*>> g_comms;
+
+void release_comms() {
+  std::lock_guard<std::mutex> lk(g_comm_mu);
+  for (auto& kv : g_comms) for (scfq_comm* c : kv.second) scfq_comm_destroy(c);
+  g_comms.clear();
+}
+
+bool exchange_on_host(const int32_t* ids, int nd) {
+  const char* e = std::getenv("SCFQ_EXCHANGE");
+  if (e && e[0] == 'h') return true;
+  for (int a = 0; a < nd; ++a) for (int b = a + 1; b < nd; ++b) if (ids[a] == ids[b]) return true;
+  return false;
+}
+
+// parts[d] (+ hists[d]) of the devices in list order -> their rank-ordered fold
+int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_partial>& parts, const std::vector<std::vector<uint64_t>>& hists,
+                         bool want_hist, scfq_partial* p, uint64_t* hist) {
+  if (exchange_on_host(o.device_ids, nd)) {
+    scfq_partial_identity(p, want_hist ? hist : nullptr);
+    for (int d = 0; d < nd; ++d) scfq_partial_combine(p, &parts[d], want_hist ? hist : nullptr, want_hist ? hists[d].data() : nullptr);
+    return SCFQ_OK;
+  }
+  std::vector<scfq_comm*> comms;
+  {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    std::vector<int> key(o.device_ids, o.device_ids + nd);
+    auto it = g_comms.find(key);
+    if (it == g_comms.end()) {
+      std::vector<scfq_comm*> cs(nd, nullptr);
+      const int rc = scfq_comm_init_all(nd, o.device_ids, 0, cs.data());
+      if (rc) { std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return rc; }
+      it = g_comms.emplace(key, cs).first;
+    }
+    comms = it->second;
+  }
+  static std::mutex one_at_a_time;      // exchanges of concurrent sessions on the same communicators must not interleave
+  std::lock_guard<std::mutex> lk(one_at_a_time);
+  for (int d = 0; d < nd; ++d) {
+    const int rc = scfq_comm_exchange_start(comms[d], &parts[d], want_hist ? hists[d].data() : nullptr, 0);
+    if (rc) return rc;
+  }
+  int rc = SCFQ_OK;
+  std::vector<uint64_t> h2(want_hist ? SCFQ_HIST_WORDS : 0);
+  for (int d = 0; d < nd; ++d) {
+    scfq_partial q;
+    const int r = scfq_comm_exchange_finish(comms[d], d == 0 ? p : &q, want_hist ? (d == 0 ? hist : h2.data()) : nullptr, 0);
+    if (r && !rc) { rc = r; std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); }
+    if (!r && d > 0 && (std::memcmp(&q, p, sizeof q) != 0 || (want_hist && std::memcmp(h2.data(), hist, SCFQ_HIST_WORDS * sizeof(uint64_t)) != 0))) {
+      std::snprintf(g_err, sizeof g_err, "exchange: rank %d folded a different result than rank 0", d);
+      rc = SCFQ_ERCCL;
+    }
+  }
+  return rc;
 }
 
 #include "scfq_sources.hpp"   // Source, MemSource, FdSource, GzSource, FastGzSource, BgzfSource, open_gz_source
@@ -485,7 +576,8 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
   // One wave inflates one member and a member is slow on its own (a serial bit stream): the kernel needs thousands of
   // members per launch to fill 256 CUs, so the device path works in large inflated chunks (up to 1 GiB, i.e. ~16 K
   // members) whatever the staging chunk of the host path is; compressed chunks are a third to a quarter of that.
-  static const uint64_t max_inf = (uint64_t)std::max(64, env_int("SCFQ_BGZF_DEVICE_CHUNK_MB", 1024)) << 20;
+  // (scfq_dinflate::Block keeps 32-bit offsets into the chunk: the knob is clamped so that a chunk stays below 4 GiB)
+  static const uint64_t max_inf = (uint64_t)std::min(2048, std::max(64, env_int("SCFQ_BGZF_DEVICE_CHUNK_MB", 1024))) << 20;
   const uint64_t want_inf = std::min<uint64_t>(max_inf, std::max<uint64_t>(64ull << 20, (fsize * 5 + 4095) & ~4095ull));
   const uint64_t want_comp = std::min<uint64_t>(want_inf / 2, std::max<uint64_t>(32ull << 20, (fsize + 4095) & ~4095ull));
   if (c->comp_cap < want_comp || c->inf_cap < want_inf) {
@@ -622,6 +714,7 @@ int partial_on_current_device(const void* ptr, uint64_t n, int is_device, int pr
   const bool timing = flags & SCFQ_TIMING;
   rc = begin_session(c, prev_byte == -1 && !(flags & SCFQ_PREV_IN_MEMORY));   // -1: the range starts the input
   if (rc) return rc;
+  if (is_device && (rc = wait_for_caller(c, opts))) return rc;
   if (is_device) {
     const int prev = (flags & SCFQ_PREV_IN_MEMORY) ? -2 : prev_byte;
     rc = scan_async(c, static_cast<const uint8_t*>(ptr), n, prev, flags, timing);
@@ -651,6 +744,9 @@ int scfq_device_count(void) {
   return n;
 }
 
+int scfq_set_wait_stream(void* hip_stream, int enable) { g_wait_stream = enable ? hip_stream : nullptr; g_wait_enabled = enable != 0; return SCFQ_OK; }
+void* scfq_get_wait_stream(int* enabled) { if (enabled) *enabled = g_wait_enabled ? 1 : 0; return g_wait_stream; }
+
 int scfq_debug_hist_stats(uint64_t* fast_ranges, uint64_t* redone_ranges) {
   if (fast_ranges) *fast_ranges = g_hist_stats[0];
   if (redone_ranges) *redone_ranges = g_hist_stats[1];
@@ -677,11 +773,12 @@ int scfq_partial_buffer(const void* ptr, uint64_t n, int is_device, int prev_byt
 // into shards: SCFQ_ESPEC from combine / finalize) is counted again with the exact histogram kernel.
 static int count_buffer_once(const void* ptr, uint64_t n, int is_device, const scfq_opts* opts, scfq_counts* out);
 static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts* out);
+static int count_file_partial(const char* path, const scfq_opts* opts, scfq_partial* p_out, uint64_t* hist_out);
 
 int scfq_count_buffer(const void* ptr, uint64_t n, int is_device, const scfq_opts* opts, scfq_counts* out) {
   int rc = count_buffer_once(ptr, n, is_device, opts, out);
   if (rc == SCFQ_ESPEC) {
-    scfq_opts o = *opts;     // ESPEC implies opts with SCFQ_QUAL_HIST
+    scfq_opts o = opts_copy(opts);     // ESPEC implies opts with SCFQ_QUAL_HIST
     o.flags |= SCFQ_HIST_EXACT;
     rc = count_buffer_once(ptr, n, is_device, &o, out);
   }
@@ -691,7 +788,7 @@ int scfq_count_buffer(const void* ptr, uint64_t n, int is_device, const scfq_opt
 int scfq_count_file(const char* path, const scfq_opts* opts, scfq_counts* out) {
   int rc = count_file_once(path, opts, out);
   if (rc == SCFQ_ESPEC) {
-    scfq_opts o = *opts;
+    scfq_opts o = opts_copy(opts);
     o.flags |= SCFQ_HIST_EXACT;
     rc = count_file_once(path, &o, out);
   }
@@ -702,9 +799,7 @@ static int count_buffer_once(const void* ptr, uint64_t n, int is_device, const s
   if (!out || out->struct_size != sizeof(scfq_counts) || (!ptr && n)) return SCFQ_EARG;
   int rc = check_opts(opts);
   if (rc) return rc;
-  scfq_opts o{};
-  if (opts) o = *opts;
-  o.struct_size = sizeof(o);
+  scfq_opts o = opts_copy(opts);
   o.flags &= ~SCFQ_PREV_IN_MEMORY;
   const bool want_hist = o.flags & SCFQ_QUAL_HIST;
   std::vector<uint64_t> hist(want_hist ? SCFQ_HIST_WORDS : 0);
@@ -729,9 +824,8 @@ static int count_buffer_once(const void* ptr, uint64_t n, int is_device, const s
     }
     for (auto& t : th) t.join();
     for (int d = 0; d < nd; ++d) if (rcs[d]) return rcs[d];
-    scfq_partial_identity(&p, want_hist ? hist.data() : nullptr);
-    for (int d = 0; d < nd; ++d)
-      scfq_partial_combine(&p, &parts[d], want_hist ? hist.data() : nullptr, want_hist ? hists[d].data() : nullptr);
+    rc = fold_device_partials(o, nd, parts, hists, want_hist, &p, want_hist ? hist.data() : nullptr);
+    if (rc) return rc;
   } else {
     if (!is_device && o.n_devices >= 1) HIPCHK(hipSetDevice(o.device_ids[0]));
     rc = partial_on_current_device(ptr, n, is_device, -1, &o, &p, want_hist ? hist.data() : nullptr);
@@ -744,14 +838,29 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
   if (!path || !out || out->struct_size != sizeof(scfq_counts)) return SCFQ_EARG;
   int rc = check_opts(opts);
   if (rc) return rc;
-  scfq_opts o{};
-  if (opts) o = *opts;
-  o.struct_size = sizeof(o);
+  const bool want_hist = opt_flags(opts) & SCFQ_QUAL_HIST;
+  std::vector<uint64_t> hist(want_hist ? SCFQ_HIST_WORDS : 0);
+  scfq_partial p;
+  rc = count_file_partial(path, opts, &p, want_hist ? hist.data() : nullptr);
+  if (rc) return rc;
+  return SCFQ_OK;
+}
+
+// The partial of a whole file folded from its first byte (source selection: plain pread / BGZF on the device or the host /
+// the library's gzip readers), before finalisation.  hist_out: uint64_t[SCFQ_HIST_WORDS] when SCFQ_QUAL_HIST is set.
+static int count_file_partial(const char* path, const scfq_opts* opts, scfq_partial* p_out, uint64_t* hist_out) {
+  int rc = SCFQ_OK;
+  scfq_opts o = opts_copy(opts);
   o.flags &= ~SCFQ_PREV_IN_MEMORY;
   const bool want_hist = o.flags & SCFQ_QUAL_HIST;
   const bool timing = o.flags & SCFQ_TIMING;
   std::vector<uint64_t> hist(want_hist ? SCFQ_HIST_WORDS : 0);
   scfq_partial p;
+  struct Hand {      // hands the folded partial to the caller on every successful return
+    scfq_partial* p; std::vector<uint64_t>* h; scfq_partial* po; uint64_t* ho;
+    ~Hand() { *po = *p; if (ho && !h->empty()) std::memcpy(ho, h->data(), SCFQ_HIST_WORDS * sizeof(uint64_t)); }
+  } hand{&p, &hist, p_out, hist_out};
+  scfq_partial_identity(&p, nullptr);
   const size_t plen = std::strlen(path);
   // fastq[^3 .. ^1] == ".gz"      src/fq_count.nim:31 (case-sensitive, last three bytes)
   const bool is_gz = plen >= 3 && std::memcmp(path + plen - 3, ".gz", 3) == 0;
@@ -788,7 +897,7 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
         if (rc) return rc;
         rc = end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
         if (rc) return rc;
-        return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+        return SCFQ_OK;
       }
       if (bfd >= 0) close(bfd);
     }
@@ -805,7 +914,7 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
     if (rc) return rc;
     rc = end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
     if (rc) return rc;
-    return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+    return SCFQ_OK;
   }
   int fd = open(path, O_RDONLY);
   if (fd < 0) return SCFQ_EOPEN;
@@ -813,8 +922,10 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
   if (fstat(fd, &sb) != 0 || S_ISDIR(sb.st_mode)) { close(fd); return SCFQ_EOPEN; }
   const bool regular = S_ISREG(sb.st_mode);
   const uint64_t size = regular ? (uint64_t)sb.st_size : 0;
+  // SCFQ_EXCHANGE_AT_1=1 (rehearsal on a one-GPU box): a one-device list takes the sharded path too, exchange included
+  static const bool at1 = env_int("SCFQ_EXCHANGE_AT_1", 0) != 0;
   const int nd = (regular && o.n_devices > 1 && size >= (uint64_t)o.n_devices * (1u << 20)) ? o.n_devices : 1;
-  if (nd > 1) {
+  if (nd > 1 || (at1 && regular && o.n_devices == 1)) {
     std::vector<scfq_partial> parts(nd);
     std::vector<std::vector<uint64_t>> hists(nd, std::vector<uint64_t>(want_hist ? SCFQ_HIST_WORDS : 0));
     std::vector<int> rcs(nd, 0);
@@ -837,10 +948,9 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
     for (auto& t : th) t.join();
     close(fd);
     for (int d = 0; d < nd; ++d) if (rcs[d]) return rcs[d];
-    scfq_partial_identity(&p, want_hist ? hist.data() : nullptr);
-    for (int d = 0; d < nd; ++d)
-      scfq_partial_combine(&p, &parts[d], want_hist ? hist.data() : nullptr, want_hist ? hists[d].data() : nullptr);
-    return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+    rc = fold_device_partials(o, nd, parts, hists, want_hist, &p, want_hist ? hist.data() : nullptr);
+    if (rc) return rc;
+    return SCFQ_OK;
   }
   if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { close(fd); return SCFQ_EHIP; }
   Ctx* c = nullptr;
@@ -874,7 +984,66 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
   if (rc) return rc;
   rc = end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
   if (rc) return rc;
-  return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
+  return SCFQ_OK;
+}
+
+// fq_count of one file by all ranks of a communicator (include/sc_fqcount.h): byte-range shard -> K1/K2 -> exchange -> fold
+int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* comm, scfq_counts* out) {
+  if (!path || !comm || !out || out->struct_size != sizeof(scfq_counts)) return SCFQ_EARG;
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  scfq_opts o = opts_copy(opts);
+  o.flags &= ~SCFQ_PREV_IN_MEMORY;
+  const bool want_hist = o.flags & SCFQ_QUAL_HIST;
+  const bool timing = o.flags & SCFQ_TIMING;
+  const int world = scfq_comm_world(comm), rank = scfq_comm_rank(comm);
+  std::vector<uint64_t> hist(want_hist ? SCFQ_HIST_WORDS : 0), hist_all(want_hist ? SCFQ_HIST_WORDS : 0);
+  scfq_partial mine, all;
+  scfq_partial_identity(&mine, want_hist ? hist.data() : nullptr);
+  const size_t plen = std::strlen(path);
+  const bool is_gz = plen >= 3 && std::memcmp(path + plen - 3, ".gz", 3) == 0;      // src/fq_count.nim:31
+  int local = SCFQ_OK;          // a rank that fails still takes part in the exchange (with the identity) so nobody hangs
+  if (is_gz) {
+    if (rank == 0) {
+      // a deflate stream has no byte-range shards: rank 0 inflates and scans all of it
+      scfq_opts o1 = o;
+      o1.n_devices = std::min(o.n_devices, 1);
+      local = count_file_partial(path, &o1, &mine, want_hist ? hist.data() : nullptr);
+    }
+  } else {
+    const int fd = open(path, O_RDONLY);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+      if (fd >= 0) close(fd);
+      local = SCFQ_EOPEN;
+    } else {
+      const uint64_t size = (uint64_t)sb.st_size;
+      const uint64_t lo = size / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>(size % (uint64_t)world, (uint64_t)rank);
+      const uint64_t hi = size / (uint64_t)world * (uint64_t)(rank + 1) + std::min<uint64_t>(size % (uint64_t)world, (uint64_t)rank + 1);
+      int prev = -1;
+      if (lo) { uint8_t pb; if (pread(fd, &pb, 1, (off_t)(lo - 1)) != 1) local = SCFQ_EIO; else prev = pb; }
+      if (!local && o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) local = SCFQ_EHIP;
+      if (!local) {
+        Ctx* c = nullptr;
+        SessionLock sl;
+        local = get_ctx(&c, sl);
+        if (!local) local = begin_session(c, lo == 0);
+        if (!local && hi > lo) {
+          FdSource src(fd, lo, hi);
+          local = ingest(c, src, prev, o.flags, std::min<uint64_t>(opt_chunk(&o), std::max<uint64_t>((hi - lo + 4095) & ~4095ull, 4096)), timing);
+        }
+        if (!local) local = end_session(c, want_hist, &mine, want_hist ? hist.data() : nullptr);
+      }
+      close(fd);
+    }
+  }
+  if (local) scfq_partial_identity(&mine, want_hist ? hist.data() : nullptr);
+  mine.reserved[0] = (uint64_t)(int64_t)local;       // every rank learns whether any rank failed
+  rc = scfq_comm_exchange(comm, &mine, want_hist ? hist.data() : nullptr, &all, want_hist ? hist_all.data() : nullptr, 0);
+  if (rc) { std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return local ? local : rc; }
+  if (local) return local;
+  if (all.reserved[0]) { std::snprintf(g_err, sizeof g_err, "another rank failed to count its shard"); return SCFQ_EIO; }
+  return scfq_partial_finalize(&all, want_hist ? hist_all.data() : nullptr, out);
 }
 
 int scfq_shutdown(void) {
@@ -911,14 +1080,12 @@ int scfq_shutdown(void) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->cp_pool) (void)hipEventDestroy(e);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->ev_caller) (void)hipEventDestroy(c->ev_caller);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
   }
-  // fq-dedup keeps its scratch in the devices' stream-ordered pools (release threshold raised): give it back
-  for (auto& kv : g_ctx) {
-    hipMemPool_t pool;
-    if (hipSetDevice(kv.first) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, kv.first) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
-  }
+  scfq_dedup_release_pools();     // fq-dedup keeps its scratch in library-owned stream-ordered pools: give them back
+  release_comms();                // communicators of the single-process multi-device path
   g_ctx.clear();
   return SCFQ_OK;
 }
@@ -1168,6 +1335,7 @@ int scfq_index_lines(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_
   if (rc) return rc;
   rc = begin_session(c, true);
   if (rc) return rc;
+  if ((rc = wait_for_caller(c, nullptr))) return rc;      // input and line_off are the caller's device buffers
   const uint8_t* base = static_cast<const uint8_t*>(dptr);
   rc = scan_async(c, base, n, -1, 0, false);
   if (rc) return rc;

@@ -24,10 +24,13 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -44,19 +47,31 @@ thread_local char g_derr[512] = "";
     }                                                                                                       \
   } while (0)
 
-// Scratch comes from the device's stream-ordered memory pool, which is told to keep what it has (release threshold =
-// everything): after the first call a de-duplication allocates nothing from the driver (hipMalloc / hipFree of multi-GB
-// buffers cost more than all kernels of the pipeline together).
-int pool_keep_memory() {
-  static thread_local int done_dev = -1;
+// Scratch comes from a stream-ordered memory pool OWNED BY THIS LIBRARY (one per device, release threshold = keep
+// everything, destroyed by scfq_shutdown): after the first call a de-duplication allocates nothing from the driver
+// (hipMalloc / hipFree of multi-GB buffers cost more than all kernels of the pipeline together), and the device's default
+// pool — which belongs to the host application — is left as it was.
+std::mutex g_pool_mu;
+std::map<int, hipMemPool_t> g_pools;
+
+int scratch_pool(hipMemPool_t* out) {
   int dev = 0;
   DCHK(hipGetDevice(&dev));
-  if (done_dev == dev) return SCFQ_OK;
-  hipMemPool_t pool;
-  DCHK(hipDeviceGetDefaultMemPool(&pool, dev));
-  uint64_t keep = UINT64_MAX;
-  DCHK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-  done_dev = dev;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pools.find(dev);
+  if (it == g_pools.end()) {
+    hipMemPoolProps props{};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    DCHK(hipMemPoolCreate(&pool, &props));
+    uint64_t keep = UINT64_MAX;
+    DCHK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    it = g_pools.emplace(dev, pool).first;
+  }
+  *out = it->second;
   return SCFQ_OK;
 }
 
@@ -65,9 +80,30 @@ struct DevBuf {   // returns its memory to the pool on scope exit (stream-ordere
   hipStream_t s = nullptr;
   ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
   template <typename T> T* as() { return static_cast<T*>(p); }
-  int alloc(size_t bytes, hipStream_t stream) { s = stream; DCHK(hipMallocAsync(&p, std::max<size_t>(bytes, 16), stream)); return SCFQ_OK; }
+  int alloc(size_t bytes, hipStream_t stream) {
+    s = stream;
+    hipMemPool_t pool;
+    int rc = scratch_pool(&pool);
+    if (rc) return rc;
+    DCHK(hipMallocFromPoolAsync(&p, std::max<size_t>(bytes, 16), pool, stream));
+    return SCFQ_OK;
+  }
   void* release() { void* q = p; p = nullptr; return q; }
 };
+
+// the caller's stream (scfq_set_wait_stream) is ordered before this call's private stream
+int wait_for_caller(hipStream_t stream) {
+  int on = 0;
+  void* ws = scfq_get_wait_stream(&on);
+  if (!on) return SCFQ_OK;
+  hipEvent_t ev;
+  DCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, static_cast<hipStream_t>(ws));
+  if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev, 0);
+  (void)hipEventDestroy(ev);
+  DCHK(e);
+  return SCFQ_OK;
+}
 
 // text of line j: [line_off[j], end) where end excludes the '\n' and a '\r' directly before a REAL '\n'
 // (Nim 1.0.6 readLine; a final line without '\n' keeps a trailing '\r')
@@ -249,9 +285,7 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
     std::fprintf(stderr, "scfq dedup: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  int rc = pool_keep_memory();
-  if (rc) return rc;
-  rc = scfq_index_lines(d_in, n, nullptr, 0, &lines);
+  int rc = scfq_index_lines(d_in, n, nullptr, 0, &lines);
   if (rc) return rc;
   mark("count lines (K1 + K2)");
   st->total_reads = lines / 4;                       // n_reads = i div 4      src/fq_dedup.nim:49
@@ -329,7 +363,12 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
 int write_all(int fd, const uint8_t* p, uint64_t n) {
   while (n) {
     ssize_t w = write(fd, p, (size_t)std::min<uint64_t>(n, 1u << 30));
-    if (w < 0) return SCFQ_EIO;
+    if (w < 0 && errno == EINTR) continue;
+    if (w < 0) {       // only a vanished reader is the quiet case (sc.nim:304); a full disk or an I/O error is an error
+      const int e = errno;
+      std::snprintf(g_derr, sizeof g_derr, "write: %s", std::strerror(e));
+      return e == EPIPE ? SCFQ_EPIPE : SCFQ_EIO;
+    }
     p += w;
     n -= (uint64_t)w;
   }
@@ -337,6 +376,13 @@ int write_all(int fd, const uint8_t* p, uint64_t n) {
 }
 
 }  // namespace
+
+// called by scfq_shutdown(): the pools go back to the driver
+extern "C" void scfq_dedup_release_pools(void) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto& kv : g_pools) { if (hipSetDevice(kv.first) == hipSuccess) (void)hipMemPoolDestroy(kv.second); }
+  g_pools.clear();
+}
 
 extern "C" {
 
@@ -354,9 +400,9 @@ int scfq_dedup_buffer(const void* ptr, uint64_t n, int is_device, void* out, uin
   struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
   DevBuf staged;
   const uint8_t* d_in = static_cast<const uint8_t*>(ptr);
+  if (is_device || (out && out_is_device)) { int rc = wait_for_caller(stream); if (rc) return rc; }
   if (!is_device && n) {
-    int rc = pool_keep_memory();
-    if (!rc) rc = staged.alloc(n, stream);
+    int rc = staged.alloc(n, stream);
     if (rc) return rc;
     DCHK(hipMemcpyAsync(staged.p, ptr, n, hipMemcpyHostToDevice, stream));
     DCHK(hipStreamSynchronize(stream));
@@ -413,7 +459,7 @@ int scfq_dedup_file(const char* path, const scfq_opts* opts, int out_fd, scfq_de
     DCHK(hipEventSynchronize(ev[k & 1]));
     if (k + 1 < n_chunks) DCHK(issue(k + 1));
     const uint64_t lo = k * chunk, len = std::min(chunk, nb - lo);
-    if (write_all(out_fd, pin[k & 1], len)) return SCFQ_EIO;
+    if ((rc = write_all(out_fd, pin[k & 1], len))) return rc;
   }
   return SCFQ_OK;
 }

@@ -45,6 +45,7 @@ int scfq_partial_combine(scfq_partial* acc, const scfq_partial* b, uint64_t* his
       for (unsigned v = 0; v < 256; ++v) dst[v] += src[v];
     }
   }
+  acc->reserved[0] |= b->reserved[0];   // status word of a sharded count: non-zero when a contributing shard failed
   acc->nl += b->nl;
   if (b->bytes) acc->last_byte = b->last_byte;
   acc->bytes += b->bytes;
@@ -116,7 +117,8 @@ const char* scfq_strerror(int rc) {
     case SCFQ_EHIP: return "HIP runtime error (is a gfx950 GPU visible?)";
     case SCFQ_ERCCL: return "collective exchange error";
     case SCFQ_EARG: return "invalid argument";
-    case SCFQ_EIO: return "read error";
+    case SCFQ_EIO: return "read / write error";
+    case SCFQ_EPIPE: return "broken pipe on the output descriptor";
     case SCFQ_ENOMEM: return "out of host memory";
     case SCFQ_ESPEC: return "speculative quality histogram did not verify across shards (retry with SCFQ_HIST_EXACT)";
     default: return "unknown error";

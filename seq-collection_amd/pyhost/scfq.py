@@ -21,7 +21,10 @@ SCFQ_STRUCT_CHECK = 0x2
 SCFQ_TIMING = 0x4
 SCFQ_PREV_IN_MEMORY = 0x8
 SCFQ_HIST_EXACT = 0x10
-SCFQ_EOPEN, SCFQ_EGZ, SCFQ_EHIP, SCFQ_ERCCL, SCFQ_EARG, SCFQ_EIO, SCFQ_ENOMEM, SCFQ_ESPEC = -1, -2, -3, -4, -5, -6, -7, -8
+SCFQ_WAIT_STREAM = 0x20
+SCFQ_EOPEN, SCFQ_EGZ, SCFQ_EHIP, SCFQ_ERCCL, SCFQ_EARG, SCFQ_EIO, SCFQ_ENOMEM, SCFQ_ESPEC, SCFQ_EPIPE = -1, -2, -3, -4, -5, -6, -7, -8, -9
+SCFQ_COMM_RCCL, SCFQ_COMM_TCP = 0, 1
+COMM_ID_BYTES = 128
 PARTIAL_WORDS = 32
 HIST_WORDS = 4 * 256
 
@@ -33,6 +36,10 @@ EXPORTS = [
     "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
     "scfq_index_lines", "scfq_dedup_buffer", "scfq_dedup_file", "scfq_dedup_error_detail", "scfq_stage_file",
     "scfq_device_free", "scfq_meta_header", "scfq_meta_file_tsv", "scfq_debug_bgzf_inflate",
+    "scfq_set_wait_stream", "scfq_get_wait_stream", "scfq_count_file_sharded",
+    "scfq_comm_unique_id", "scfq_comm_init_rank", "scfq_comm_init_rendezvous", "scfq_comm_init_all", "scfq_comm_world",
+    "scfq_comm_rank", "scfq_comm_transport", "scfq_comm_exchange", "scfq_comm_exchange_start", "scfq_comm_exchange_finish",
+    "scfq_comm_allgather_u64", "scfq_comm_destroy", "scfq_comm_error_detail",
 ]
 
 
@@ -45,7 +52,7 @@ class Counts(ctypes.Structure):
 class Opts(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint64), ("n_devices", ctypes.c_int32),
                 ("device_ids", ctypes.POINTER(ctypes.c_int32)), ("flags", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32), ("chunk_bytes", ctypes.c_uint64)]
+                ("reserved", ctypes.c_uint32), ("chunk_bytes", ctypes.c_uint64), ("wait_stream", ctypes.c_void_p)]
 
 
 class Partial(ctypes.Structure):
@@ -139,6 +146,26 @@ def lib():
         L.scfq_debug_stream_ms.restype = ctypes.c_double
         L.scfq_synth_locate.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        L.scfq_set_wait_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.scfq_get_wait_stream.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        L.scfq_get_wait_stream.restype = ctypes.c_void_p
+        vp, pvp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)
+        L.scfq_comm_unique_id.argtypes = [vp, ctypes.c_uint64]
+        L.scfq_comm_init_rank.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, pvp]
+        L.scfq_comm_init_rendezvous.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, pvp]
+        L.scfq_comm_init_all.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, pvp]
+        L.scfq_comm_world.argtypes = [vp]
+        L.scfq_comm_rank.argtypes = [vp]
+        L.scfq_comm_transport.argtypes = [vp]
+        L.scfq_comm_transport.restype = ctypes.c_char_p
+        L.scfq_comm_exchange.argtypes = [vp, ctypes.POINTER(Partial), vp, ctypes.POINTER(Partial), vp, ctypes.c_int]
+        L.scfq_comm_exchange_start.argtypes = [vp, ctypes.POINTER(Partial), vp, ctypes.c_int]
+        L.scfq_comm_exchange_finish.argtypes = [vp, ctypes.POINTER(Partial), vp, ctypes.c_int]
+        L.scfq_comm_allgather_u64.argtypes = [vp, vp, ctypes.c_uint32, vp, ctypes.c_int]
+        L.scfq_comm_destroy.argtypes = [vp]
+        L.scfq_comm_error_detail.restype = ctypes.c_char_p
+        L.scfq_count_file_sharded.argtypes = [ctypes.c_char_p, ctypes.POINTER(Opts), vp, ctypes.POINTER(Counts)]
         _lib = L
     return _lib
 
@@ -152,11 +179,14 @@ def _check(rc, what):
         raise ScfqError(rc, what, lib().scfq_last_error_detail().decode())
 
 
-def make_opts(flags=0, devices=None, chunk_bytes=0):
+def make_opts(flags=0, devices=None, chunk_bytes=0, wait_stream=None):
     o = Opts()
     o.struct_size = ctypes.sizeof(Opts)
     o.flags = flags
     o.chunk_bytes = chunk_bytes
+    if wait_stream is not None:          # 0 names the legacy default stream (what torch uses unless told otherwise)
+        o.flags |= SCFQ_WAIT_STREAM
+        o.wait_stream = wait_stream or None
     if devices:
         arr = (ctypes.c_int32 * len(devices))(*devices)
         o._keep = arr
@@ -196,17 +226,19 @@ def count_host(data, flags=0, devices=None, chunk_bytes=0):
     return c
 
 
-def count_device(dev_ptr, n, flags=0):
+def count_device(dev_ptr, n, flags=0, wait_stream=None):
+    """wait_stream: hipStream_t (int) of the producer of the buffer, e.g. torch.cuda.current_stream().cuda_stream; None = the
+    caller has synchronised (include/sc_fqcount.h: scfq_opts.wait_stream)"""
     c = _new_counts()
-    o = make_opts(flags)
+    o = make_opts(flags, wait_stream=wait_stream)
     _check(lib().scfq_count_buffer(ctypes.c_void_p(dev_ptr), n, 1, ctypes.byref(o), ctypes.byref(c)),
            "scfq_count_buffer")
     return c
 
 
-def partial_device(dev_ptr, n, prev_byte=-1, flags=0, want_hist=False):
+def partial_device(dev_ptr, n, prev_byte=-1, flags=0, want_hist=False, wait_stream=None):
     p = Partial()
-    o = make_opts(flags)
+    o = make_opts(flags, wait_stream=wait_stream)
     hist = (ctypes.c_uint64 * HIST_WORDS)() if want_hist else None
     _check(lib().scfq_partial_buffer(ctypes.c_void_p(dev_ptr), n, 1, prev_byte, ctypes.byref(o), ctypes.byref(p),
                                      ctypes.byref(hist) if want_hist else None), "scfq_partial_buffer")
@@ -221,6 +253,93 @@ def partial_host(data, prev_byte=-1, flags=0, want_hist=False, chunk_bytes=0):
     _check(lib().scfq_partial_buffer(addr, n, 0, prev_byte, ctypes.byref(o), ctypes.byref(p),
                                      ctypes.byref(hist) if want_hist else None), "scfq_partial_buffer")
     return (p, hist) if want_hist else p
+
+
+def set_wait_stream(stream):
+    """this thread's default caller stream for device-pointer calls (scfq_set_wait_stream): an int hipStream_t handle
+    (0 = the legacy default stream, e.g. torch.cuda.current_stream().cuda_stream); None clears it"""
+    lib().scfq_set_wait_stream(ctypes.c_void_p(stream or 0), 0 if stream is None else 1)
+
+
+class Comm:
+    """scfq_comm: the cross-rank exchange of shard partials inside the C library (RCCL all-gather + rank-ordered fold)"""
+
+    def __init__(self, handle):
+        self.h = ctypes.c_void_p(handle)
+
+    @staticmethod
+    def _err(rc, what):
+        if rc != 0:
+            raise ScfqError(rc, what, lib().scfq_comm_error_detail().decode())
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        Comm._err(lib().scfq_comm_unique_id(buf, COMM_ID_BYTES), "scfq_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, uid, world, rank, device, timeout_ms=0):
+        h = ctypes.c_void_p()
+        cls._err(lib().scfq_comm_init_rank(uid, world, rank, device, timeout_ms, ctypes.byref(h)), "scfq_comm_init_rank")
+        return cls(h.value)
+
+    @classmethod
+    def init_rendezvous(cls, host, port, world, rank, device=0, transport=SCFQ_COMM_RCCL, timeout_ms=0):
+        h = ctypes.c_void_p()
+        cls._err(lib().scfq_comm_init_rendezvous(host.encode() if host else None, port, world, rank, device, transport,
+                                                 timeout_ms, ctypes.byref(h)), "scfq_comm_init_rendezvous")
+        return cls(h.value)
+
+    @classmethod
+    def init_all(cls, devices, timeout_ms=0):
+        n = len(devices)
+        arr = (ctypes.c_int32 * n)(*devices)
+        hs = (ctypes.c_void_p * n)()
+        cls._err(lib().scfq_comm_init_all(n, arr, timeout_ms, hs), "scfq_comm_init_all")
+        return [cls(h) for h in hs]
+
+    world = property(lambda self: lib().scfq_comm_world(self.h))
+    rank = property(lambda self: lib().scfq_comm_rank(self.h))
+    transport = property(lambda self: lib().scfq_comm_transport(self.h).decode())
+
+    def exchange(self, partial, hist=None, timeout_ms=0):
+        out = Partial()
+        out_h = (ctypes.c_uint64 * HIST_WORDS)() if hist is not None else None
+        self._err(lib().scfq_comm_exchange(self.h, ctypes.byref(partial), ctypes.byref(hist) if hist is not None else None,
+                                           ctypes.byref(out), ctypes.byref(out_h) if hist is not None else None, timeout_ms),
+                  "scfq_comm_exchange")
+        return (out, out_h) if hist is not None else out
+
+    def start(self, partial, hist=None, timeout_ms=0):
+        self._err(lib().scfq_comm_exchange_start(self.h, ctypes.byref(partial), ctypes.byref(hist) if hist is not None else None,
+                                                 timeout_ms), "scfq_comm_exchange_start")
+
+    def finish(self, want_hist=False, timeout_ms=0):
+        out = Partial()
+        out_h = (ctypes.c_uint64 * HIST_WORDS)() if want_hist else None
+        self._err(lib().scfq_comm_exchange_finish(self.h, ctypes.byref(out), ctypes.byref(out_h) if want_hist else None, timeout_ms),
+                  "scfq_comm_exchange_finish")
+        return (out, out_h) if want_hist else out
+
+    def allgather_u64(self, words, timeout_ms=0):
+        n = len(words)
+        mine = (ctypes.c_uint64 * n)(*[int(w) & 0xFFFFFFFFFFFFFFFF for w in words])
+        out = (ctypes.c_uint64 * (n * self.world))()
+        self._err(lib().scfq_comm_allgather_u64(self.h, mine, n, out, timeout_ms), "scfq_comm_allgather_u64")
+        return [list(out[r * n:(r + 1) * n]) for r in range(self.world)]
+
+    def count_file(self, path, flags=0, devices=None, chunk_bytes=0):
+        """scfq_count_file_sharded: this rank's byte range of `path`, exchange, the whole file's counters on every rank"""
+        c = _new_counts()
+        o = make_opts(flags, devices, chunk_bytes)
+        _check(lib().scfq_count_file_sharded(os.fsencode(path), ctypes.byref(o), self.h, ctypes.byref(c)), "scfq_count_file_sharded")
+        return c
+
+    def destroy(self):
+        if self.h:
+            lib().scfq_comm_destroy(self.h)
+            self.h = ctypes.c_void_p()
 
 
 def index_lines_device(dev_ptr, n, line_off_ptr=None, cap=0):

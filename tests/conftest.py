@@ -16,7 +16,8 @@ def _ensure_built():
     """hipcc cross-compiles gfx950 without a GPU: (re)build the product library + CLI when missing or stale."""
     lib = os.path.join(PKG, "libsc_fqcount_hip.so")
     srcs = [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc"))] + \
-           [os.path.join(PKG, "cli", "sc_main.cpp"), os.path.join(ROOT, "include", "sc_fqcount.h")]
+           [os.path.join(PKG, "cli", "sc_main.cpp"), os.path.join(PKG, "Makefile"), os.path.join(ROOT, "include", "sc_fqcount.h"),
+            os.path.join(ROOT, "include", "sc_fqcount_debug.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     for target in (lib, os.path.join(PKG, "sc")):
         if not os.path.exists(target) or os.path.getmtime(target) < newest:
@@ -135,4 +136,7 @@ def gpu(scfq):
     assert torch.cuda.is_available(), "no GPU visible to torch"
     scfq.lib()
     assert scfq.lib().scfq_device_count() >= 1
+    # the tests fill device buffers with torch kernels and hand them straight to the library: order every device-pointer
+    # call of this thread after torch's stream (include/sc_fqcount.h: scfq_set_wait_stream) instead of synchronising by hand
+    scfq.set_wait_stream(torch.cuda.current_stream().cuda_stream)
     return torch

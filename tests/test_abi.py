@@ -11,7 +11,7 @@ from conftest import ROOT, golden_rows
 
 
 def declared_functions():
-    txt = open(os.path.join(ROOT, "include", "sc_fqcount.h")).read()
+    txt = open(os.path.join(ROOT, "include", "sc_fqcount.h")).read() + open(os.path.join(ROOT, "include", "sc_fqcount_debug.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(scfq_[a-z_0-9]+)\s*\(", txt)))
 
@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(scfq):
 def test_struct_layouts(scfq):
     assert ctypes.sizeof(scfq.Counts) == 8 * (11 + 256)
     assert ctypes.sizeof(scfq.Partial) == 8 * 32
-    assert ctypes.sizeof(scfq.Opts) == 40
+    assert ctypes.sizeof(scfq.Opts) == 48 and scfq.Opts.wait_stream.offset == 40    # v1 callers pass 40 (SCFQ_OPTS_V1_SIZE)
     assert scfq.Partial.gc.offset == 8 and scfq.Partial.len.offset == 72 and scfq.Partial.bytes.offset == 200
 
 
@@ -121,10 +121,19 @@ def test_header_is_plain_c_and_example_builds(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", "count_shards.c"), "-L", os.path.join(ROOT, "seq-collection_amd"),
                            "-lsc_fqcount_hip", "-Wl,-rpath," + os.path.join(ROOT, "seq-collection_amd"), "-o", str(exe)])
-    import torch
-    if torch.cuda.is_available():
-        r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "sra.fq"), "5"], capture_output=True, text=True)
-        assert r.returncode == 0 and r.stdout == "2\t0.4305555555555556\t62\t0\t144\n"
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_on_the_gpu(gpu, tmp_path):
+    """examples/count_shards.c (C99, gcc, no C++ runtime of its own) over the C ABI: shards at arbitrary cuts, (+) fold, row"""
+    import subprocess
+    exe = tmp_path / "count_shards"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "count_shards.c"), "-L", os.path.join(ROOT, "seq-collection_amd"),
+                           "-lsc_fqcount_hip", "-Wl,-rpath," + os.path.join(ROOT, "seq-collection_amd"), "-o", str(exe)])
+    for shards in ("1", "5", "17"):
+        r = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "sra.fq"), shards], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == "2\t0.4305555555555556\t62\t0\t144\n", (shards, r.stderr)
 
 
 def test_hist_class_algebra(scfq):
