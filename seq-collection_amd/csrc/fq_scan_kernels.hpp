@@ -222,6 +222,19 @@ __device__ __forceinline__ uint32_t plane_ne(const uint32_t* w) {
   return __builtin_amdgcn_bitop3_b32(g1, g2, g3, 0x7F);   // ~(g1 & g2 & g3)
 }
 
+// x[8]: the bit planes of the group, left to the caller (the K3 plane-matching form counts quality bytes from them)
+template <bool STRUCT>
+__device__ __forceinline__ void masks32_planes_x(const uint32_t* d, const PlaneConsts& pc, uint32_t* x, uint32_t& wnl, uint32_t& wgc,
+                                                 uint32_t& wnn, uint32_t& wat, uint32_t& wpl) {
+  transpose4x4(d[0], d[2], d[4], d[6], &x[0]);
+  transpose4x4(d[1], d[3], d[5], d[7], &x[4]);
+  to_bit_planes(x, pc);
+  wnl = plane_ne<0x0A>(x);
+  wgc = plane_ne<0x43, true>(x);
+  wnn = plane_ne<0x4E>(x);
+  if (STRUCT) { wat = plane_ne<0x40>(x); wpl = plane_ne<0x2B>(x); }
+}
+
 template <bool STRUCT>
 __device__ __forceinline__ void masks32_planes(const uint32_t* d, const PlaneConsts& pc, uint32_t& wnl, uint32_t& wgc,
                                                uint32_t& wnn, uint32_t& wat, uint32_t& wpl) {
@@ -278,7 +291,17 @@ struct WaveState {
   uint32_t piv4;       // wave-uniform, HIST == 2: the range's pivot quality byte, replicated into all four bytes
   uint32_t piv_set;    // wave-uniform: piv4 is valid
   uint32_t piv_cnt;    // per lane: quality dwords equal to piv4 (counted here instead of four LDS atomics each)
+  // HIST == 2, plane-matching form (hist_tile_planes): the byte values met so far on quality lines ("hot" values, at most
+  // kHot) are counted from the bit planes into per-lane registers; anything else goes to the LDS histogram
+  uint32_t hotp[2];    // wave-uniform: the hot byte values in order of discovery, four per word
+  uint32_t p_hot[2];   // per lane: 8-bit fields, quality bytes equal to hot value k of up to 3 tiles (k = 4 * word + field)
+  Acc16 hot_lo, hot_hi;// per lane: the same widened to 16-bit fields (values 0..3 / 4..7), like the class counters
+  uint32_t n_hot;      // wave-uniform
+  uint32_t qmode;      // wave-uniform: 0 = plane matching, 1 = the alphabet of this range is too large for it: hist_tile_q
+  uint32_t qover;      // wave-uniform: tiles that held quality bytes outside a full hot set
 };
+constexpr int kHot = 8;
+constexpr uint32_t kHotOverflowTiles = 2;   // after this many tiles with bytes outside a full hot set the range goes to hist_tile_q
 
 // widen the pending 8-bit fields into the 16-bit per-lane accumulators (at most every 3rd tile: 3 x 64 < 256)
 __device__ __forceinline__ void flush_pending(WaveState& st) {
@@ -289,7 +312,10 @@ __device__ __forceinline__ void flush_pending(WaveState& st) {
   st.starts.add_tile8(st.p_st);
   st.fat.add_tile8(st.p_fat);
   st.fplus.add_tile8(st.p_fpl);
+  st.hot_lo.add_tile8(st.p_hot[0]);
+  st.hot_hi.add_tile8(st.p_hot[1]);
   st.p_gc = st.p_nn = st.p_len = st.p_crlf = st.p_st = st.p_fat = st.p_fpl = 0;
+  st.p_hot[0] = st.p_hot[1] = 0;
   st.pending = 0;
 }
 
@@ -516,6 +542,96 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
   }
 }
 
+// ---- K3 fast form, plane matching ------------------------------------------------------------------------------
+// The bit planes of the classifier are already there: the bytes of a 32-byte group that equal a value v are ONE 8-input
+// AND of planes / complements (3 + 1 v_bitop3, the quality-segment mask M riding along as the ninth input), so a quality
+// line over a small alphabet is counted with ~12 vector instructions per value and tile instead of one LDS atomic per
+// byte: binned Illumina qualities (4 - 8 distinct values) never touch the LDS histogram at all.  The truth table of
+// v_bitop3 is an immediate, the values are only known at run time: each 3-plane group is matched under a wave-uniform
+// switch on the corresponding bits of v (scalar branches; the vector unit sees one instruction per case).
+// Exact for any input: bytes outside the hot set are found (M minus the union of the matches), new values join the set
+// while it has room, the rest goes to the LDS histogram byte by byte, and a range whose alphabet keeps overflowing the
+// set switches to hist_tile_q (the dword loop) for its remaining tiles.
+#include "hot_dispatch.inc"     // SCFQ_HOT_STANZAS: 256 stanzas of SCFQ_HOT_STANZA_BYTES, generated by scripts/gen_hot_dispatch.py
+
+// bytes equal to v (wave-uniform, 0..255) inside the masks (Ma: positions 0..31 of the lane, Mb: 32..63).
+// One computed jump into the stanza of v (six v_bitop3 with v's truth tables as immediates), one jump back: a compare
+// chain over the bits of v (what a C++ switch becomes here) cost ~30 scalar instructions and ~8 branches per 3-plane
+// group and saturated the CU's scalar unit.  s[90:91] hold the target address.
+__device__ __forceinline__ void hot_match(const uint32_t* xa, const uint32_t* xb, uint32_t Ma, uint32_t Mb, uint32_t v,
+                                          uint32_t& ma, uint32_t& mb) {
+  uint32_t t0, t1, t2, t3, st;
+  asm volatile(
+      "s_mul_i32 %[st], %[v], %[stanza]\n\t"
+      "s_getpc_b64 s[90:91]\n"
+      ".Lhm_pc%=:\n\t"
+      "s_add_u32 s90, s90, %[st]\n\t"
+      "s_addc_u32 s91, s91, 0\n\t"
+      "s_add_u32 s90, s90, .Lhm_tab%=-.Lhm_pc%=\n\t"
+      "s_addc_u32 s91, s91, 0\n\t"
+      "s_setpc_b64 s[90:91]\n"
+      ".Lhm_tab%=:\n\t"
+      SCFQ_HOT_STANZAS
+      "\n.Lhm_end%=:\n\t"
+      "v_bitop3_b32 %[ma], %[ma], %[t0], %[t2] bitop3:0x80\n\t"
+      "v_bitop3_b32 %[mb], %[mb], %[t1], %[t3] bitop3:0x80"
+      : [ma] "=&v"(ma), [mb] "=&v"(mb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [st] "=&s"(st)
+      : [v] "s"(v), [stanza] "n"(SCFQ_HOT_STANZA_BYTES), [a0] "v"(xa[0]), [a1] "v"(xa[1]), [a2] "v"(xa[2]), [a3] "v"(xa[3]),
+        [a4] "v"(xa[4]), [a5] "v"(xa[5]), [a6] "v"(xa[6]), [a7] "v"(xa[7]), [b0] "v"(xb[0]), [b1] "v"(xb[1]), [b2] "v"(xb[2]),
+        [b3] "v"(xb[3]), [b4] "v"(xb[4]), [b5] "v"(xb[5]), [b6] "v"(xb[6]), [b7] "v"(xb[7]), [Ma] "v"(Ma), [Mb] "v"(Mb)
+      : "s90", "s91", "scc");
+}
+
+// One interior tile whose lanes hold at most two newlines each (checked by the caller; every 100+ bp FASTQ shape).
+// xa / xb: the bit planes of the lane's two 32-byte groups; cls0: class of the lane's first byte.
+__device__ __forceinline__ void hist_tile_planes(const uint32_t* xa, const uint32_t* xb, uint32_t* hq, const uint8_t* slot, int lane,
+                                                 uint32_t cls0, uint64_t NL, WaveState& st) {
+  // the lane's quality segment: segment i0 = (qcls - cls0) & 3 of the lane (segments are separated by its newlines)
+  const uint32_t i0 = (st.qcls - cls0) & 3u;
+  const uint64_t xm1 = NL - 1, x1 = NL & xm1, x1m1 = x1 - 1;
+  const uint64_t seg0 = ~NL & xm1;                       // below the first newline (everything when there is none)
+  const uint64_t seg1 = (~x1 & x1m1) & ~(NL ^ xm1);      // above the first newline, below the second; none without a first
+  const uint64_t seg2 = ~(x1 ^ x1m1);                    // above the second newline; none without a second
+  const uint64_t M = (i0 == 0) ? seg0 : (i0 == 1) ? seg1 : (i0 == 2) ? seg2 : 0ull;
+  uint32_t ra = (uint32_t)M, rb = (uint32_t)(M >> 32);   // quality bytes not yet accounted for
+  uint64_t have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
+  if (have == 0) return;                                 // long reads: most tiles hold no quality byte at all
+  uint32_t k = 0;
+  for (;;) {
+    const uint32_t n_hot = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
+    for (; k < n_hot; ++k) {                             // wave-uniform loop: one dispatch per hot value
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)((k < 4u) ? st.hotp[0] : st.hotp[1]));
+      const uint32_t sh = (k & 3u) * 8u;
+      uint32_t ma, mb;
+      hot_match(xa, xb, ra, rb, (word >> sh) & 0xFFu, ma, mb);    // hot values are distinct: matching inside the rest is exact
+      const uint32_t c = ((uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb)) << sh;
+      if (k < 4u) st.p_hot[0] += c; else st.p_hot[1] += c;
+      ra &= ~ma;
+      rb &= ~mb;
+    }
+    have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
+    if (have == 0 || n_hot >= (uint32_t)kHot) break;
+    // a byte outside the hot set while the set has room: its value joins (the loop above then counts it)
+    const int L = __builtin_ctzll(have);
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)ra, L), lb = (uint32_t)__builtin_amdgcn_readlane((int)rb, L);
+    const uint32_t kbit = la ? (uint32_t)__builtin_ctz(la) : 32u + (uint32_t)__builtin_ctz(lb);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)slot[L * 64 + kbit]);
+    if (n_hot < 4u) st.hotp[0] |= v << (n_hot * 8u); else st.hotp[1] |= v << ((n_hot - 4u) * 8u);
+    st.n_hot = n_hot + 1u;
+  }
+  if (have == 0) return;
+  // the hot set is full: the rest is counted in the workgroup's LDS histogram byte by byte; a range that keeps coming
+  // here has a large alphabet (unbinned qualities) and is better served by the dword loop of hist_tile_q
+  uint64_t r = (uint64_t)ra | ((uint64_t)rb << 32);
+  const uint8_t* lane_bytes = slot + lane * 64;
+  while (r) {
+    const int kb = __builtin_ctzll(r);
+    r &= r - 1;
+    atomicAdd(&hq[(uint32_t)lane_bytes[kb] * kQRep + (lane & (kQRep - 1))], 1u);
+  }
+  if (++st.qover > kHotOverflowTiles) st.qmode = 1u;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Interior tile of the default variant (no EDGE / STRUCT / HIST): the same arithmetic as
 // process_tile with the segment loop restructured so that the common FASTQ shapes (0, 1 or 2
@@ -530,14 +646,15 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   uint32_t d[16] = {q0v.x, q0v.y, q0v.z, q0v.w, q1v.x, q1v.y, q1v.z, q1v.w,
                     q2v.x, q2v.y, q2v.z, q2v.w, q3v.x, q3v.y, q3v.z, q3v.w};
   uint64_t WNL, WGC, WNN, WAT = 0, WPL = 0;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N' / '@' / '+'
+  uint32_t xa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xb[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bit planes of the two 32-byte groups (live past the classifier for HIST == 2 only)
   if (SCFQ_ABLATE == 1 || SCFQ_ABLATE == 3) {   // timing-only: masks are a cheap function of the data
     WNL = ~((uint64_t)(d[0] & d[5] & 0x01010101u) | ((uint64_t)(d[9] & d[13] & 0x00010100u) << 32));
     WGC = ((uint64_t)d[1] << 32) | d[2];
     WNN = ((uint64_t)d[3] << 32) | d[4] | d[6] | d[7] | d[8] | d[10] | d[11] | d[12] | d[14] | d[15];
   } else {
     uint32_t a0, a1, a2, a3 = 0, a4 = 0, b0, b1, b2, b3 = 0, b4 = 0;
-    masks32_planes<STRUCT>(d, pc, a0, a1, a2, a3, a4);
-    masks32_planes<STRUCT>(d + 8, pc, b0, b1, b2, b3, b4);
+    masks32_planes_x<STRUCT>(d, pc, xa, a0, a1, a2, a3, a4);
+    masks32_planes_x<STRUCT>(d + 8, pc, xb, b0, b1, b2, b3, b4);
     WNL = (uint64_t)a0 | ((uint64_t)b0 << 32);
     WGC = (uint64_t)a1 | ((uint64_t)b1 << 32);
     WNN = (uint64_t)a2 | ((uint64_t)b2 << 32);
@@ -551,7 +668,12 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint32_t sh0 = ((st.phase + incl - cnt) & 3u) * 8u;
   if (HIST == 1) hist_tile_full(d, hist_lds, lane, sh0 >> 3, NL);
   if (HIST == 2) {
-    if (st.qcls < 4u) hist_tile_q(d, hist_lds, slot, lane, sh0 >> 3, NL, cnt, st);   // wave-uniform branch
+    if (st.qcls < 4u) {   // wave-uniform branches
+      // plane matching needs the quality segment of a lane to be one of its first three segments: at most two newlines
+      // per lane (any read of 30+ bases); other tiles, and ranges with a large quality alphabet, take the dword loop
+      if (st.qmode == 0u && __builtin_amdgcn_ballot_w64(cnt > 2u) == 0) hist_tile_planes(xa, xb, hist_lds, slot, lane, sh0 >> 3, NL, st);
+      else hist_tile_q(d, hist_lds, slot, lane, sh0 >> 3, NL, cnt, st);
+    }
   }
 
   // K4: line-start bytes = the byte after a '\n' (bit 0: previous lane's / previous tile's last byte)
@@ -864,6 +986,15 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWa
     if (lane == 0 && crq) atomicSub(&hist_lds[13 * kQRep], crq);
     const uint32_t pivots = wave_sum(st.piv_cnt);      // dwords of four pivot bytes that were counted in registers
     if (lane == 0 && pivots) atomicAdd(&hist_lds[(st.piv4 & 0xFFu) * kQRep], 4u * pivots);
+    {   // the plane-matching form's register counts (flush_pending has widened them)
+      const uint4 lo4 = sum4(st.hot_lo), hi4 = sum4(st.hot_hi);
+      const uint32_t tot[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+      for (int k = 0; k < kHot; ++k) {
+        const uint32_t v = ((k < 4 ? st.hotp[0] : st.hotp[1]) >> ((k & 3) * 8)) & 0xFFu;
+        if (lane == 0 && (uint32_t)k < st.n_hot && tot[k]) atomicAdd(&hist_lds[v * kQRep], tot[k]);
+      }
+    }
   }
   if (HIST == 1) {
     // per-range histogram partial [class][byte] (u32): sum the lane-keyed copies, then take back the bytes that

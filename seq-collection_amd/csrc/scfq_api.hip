@@ -843,7 +843,7 @@ static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts*
   scfq_partial p;
   rc = count_file_partial(path, opts, &p, want_hist ? hist.data() : nullptr);
   if (rc) return rc;
-  return SCFQ_OK;
+  return scfq_partial_finalize(&p, want_hist ? hist.data() : nullptr, out);
 }
 
 // The partial of a whole file folded from its first byte (source selection: plain pread / BGZF on the device or the host /

@@ -227,6 +227,23 @@ struct Star {
 
 constexpr uint32_t kMaxWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;   // 1056: partial | hist[4][256]
 
+// RCCL 2.27 prints a version banner on STDOUT when the first communicator of a process comes up; this library never
+// writes to stdout (a host's stdout is its TSV, src/fq_count.nim:53).  While a communicator is being created, and until its
+// first collective has run, descriptor 1 points at descriptor 2.
+struct StdoutToStderr {
+  static std::mutex& mu() { static std::mutex m; return m; }
+  std::unique_lock<std::mutex> lk{mu()};
+  int saved = -1;
+  StdoutToStderr() {
+    std::fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0) dup2(2, 1);
+  }
+  ~StdoutToStderr() {
+    if (saved >= 0) { std::fflush(stdout); dup2(saved, 1); close(saved); }
+  }
+};
+
 struct Job {
   enum Kind { kInitRank, kAdopt, kGather, kStop } kind = kGather;
   std::vector<uint64_t> row;
@@ -327,13 +344,24 @@ struct scfq_comm {
       Done d;
       d.words = (uint32_t)j.row.size();
       d.with_hist = j.with_hist;
-      if (j.kind == Job::kInitRank) {
-        if (device_setup(&d) == SCFQ_OK) {
+      if (j.kind == Job::kInitRank || (j.kind == Job::kAdopt && transport == SCFQ_COMM_RCCL)) {
+        if (device_setup(&d) == SCFQ_OK && j.kind == Job::kInitRank) {
           ncclResult_t r = rccl->CommInitRank(&nc, world, j.id, rank);
           if (r != ncclSuccess) nccl_fail("ncclCommInitRank", r, &d);
         }
+        if (d.rc == SCFQ_OK) {
+          // one collective before the communicator is handed out: connections are set up (and anything RCCL wants to
+          // print is printed) here, under the creator's deadline, not inside a host's first timed exchange
+          Job w;
+          w.row.assign(1, (uint64_t)rank);
+          w.timeout_ms = j.timeout_ms;
+          Done dw;
+          gather_rccl(w, &dw);
+          if (dw.rc) { d.rc = dw.rc; d.err = dw.err; }
+          else for (int r = 0; r < world; ++r) if (dw.all[(size_t)r] != (uint64_t)r) { d.rc = SCFQ_ERCCL; d.err = "warm-up all-gather returned the wrong ranks"; }
+        }
       } else if (j.kind == Job::kAdopt) {
-        if (transport == SCFQ_COMM_RCCL) device_setup(&d);     // the communicator itself came from ncclCommInitAll
+        // TCP transport: nothing to set up on a device
       } else if (broken) {
         d.rc = SCFQ_ERCCL;
         d.err = "communicator is broken (an earlier exchange failed or timed out)";
@@ -428,7 +456,7 @@ int start_and_wait(scfq_comm* c, Job&& j, int timeout_ms) {
   c->worker = std::thread([c] { c->run(); });
   c->post(std::move(j));
   Done d;
-  return c->take(&d, timeout_ms);
+  return c->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);     // the worker's own deadline fires first and says why
 }
 
 }  // namespace
@@ -461,7 +489,9 @@ int scfq_comm_init_rank(const void* id, int world, int rank, int device, int tim
   c->rccl = r;
   Job j;
   j.kind = Job::kInitRank;
+  j.timeout_ms = timeout_ms;
   std::memcpy(&j.id, id, sizeof j.id);
+  StdoutToStderr quiet;
   const int rc = start_and_wait(c, std::move(j), timeout_ms);
   if (rc) { c->broken = true; destroy_impl(c); return rc; }
   *out = c;
@@ -510,10 +540,11 @@ int scfq_comm_init_all(int n, const int32_t* device_ids, int timeout_ms, scfq_co
   std::vector<int> devs(device_ids, device_ids + n);
   int prev = 0;
   (void)hipGetDevice(&prev);
+  StdoutToStderr quiet;
   const ncclResult_t e = r->CommInitAll(ncs.data(), n, devs.data());
   (void)hipSetDevice(prev);
   if (e != ncclSuccess) { set_err("ncclCommInitAll(%d devices) -> %s", n, r->GetErrorString(e)); return SCFQ_ERCCL; }
-  int rc = SCFQ_OK;
+  // every worker first runs one collective (see run()): all of them are started before any is waited for
   for (int k = 0; k < n; ++k) {
     auto* c = new scfq_comm;
     c->world = n;
@@ -522,10 +553,17 @@ int scfq_comm_init_all(int n, const int32_t* device_ids, int timeout_ms, scfq_co
     c->rccl = r;
     c->nc = ncs[k];
     out[k] = c;
+    c->worker = std::thread([c] { c->run(); });
     Job j;
     j.kind = Job::kAdopt;
-    const int rk = start_and_wait(c, std::move(j), timeout_ms);
-    if (rk && !rc) rc = rk;
+    j.timeout_ms = timeout_ms;
+    c->post(std::move(j));
+  }
+  int rc = SCFQ_OK;
+  for (int k = 0; k < n; ++k) {
+    Done d;
+    const int rk = out[k]->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);
+    if (rk) { out[k]->broken = true; if (!rc) rc = rk; }
   }
   if (rc) {
     for (int k = 0; k < n; ++k) { destroy_impl(out[k]); out[k] = nullptr; }
@@ -552,7 +590,7 @@ int scfq_comm_allgather_u64(scfq_comm* c, const uint64_t* mine, uint32_t words, 
   j.timeout_ms = timeout_ms;
   c->post(std::move(j));
   Done d;
-  const int rc = c->take(&d, timeout_ms > 0 ? timeout_ms + 2000 : 0);
+  const int rc = c->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);
   if (rc) return rc;
   std::memcpy(all, d.all.data(), d.all.size() * sizeof(uint64_t));
   return SCFQ_OK;
@@ -575,7 +613,7 @@ int scfq_comm_exchange_start(scfq_comm* c, const scfq_partial* mine, const uint6
 int scfq_comm_exchange_finish(scfq_comm* c, scfq_partial* folded, uint64_t* hist_folded, int timeout_ms) {
   if (!c || !folded) return SCFQ_EARG;
   Done d;
-  const int rc = c->take(&d, timeout_ms > 0 ? timeout_ms + 2000 : 0);
+  const int rc = c->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);
   if (rc) return rc;
   return fold_rows(d, c->world, folded, hist_folded);
 }

@@ -34,14 +34,18 @@ def _member(piece, level=6):
 def _check(scfq, oracle, path, data, info, flags=0):
     c = scfq.count_file(str(path), flags=flags | scfq.SCFQ_TIMING)
     t = scfq.last_timing()
-    oc = oracle.count(data, "lines")
+    oc = oracle.count(data, "lines")          # the reference-shaped line loop (src/fq_count.nim:38-45)
+    if flags & (scfq.SCFQ_QUAL_HIST | scfq.SCFQ_STRUCT_CHECK):
+        oc = oracle.count(data, "bytes")      # the byte-serial restatement also carries the K3 / K4 additions
     for f in REF_FIELDS:
         assert getattr(c, f) == getattr(oc, f), (f, getattr(c, f), getattr(oc, f))
     assert (c.reads, c.gc_bases, c.n_bases, c.bases) == (info.records, info.gc_bases, info.n_bases, info.bases)
     assert c.input_bytes == data.size
     assert scfq.format_tsv(c) == oracle.tsv(oc)
     if flags & scfq.SCFQ_QUAL_HIST:
-        assert list(c.qual_hist) == list(oc.qual_hist)
+        assert list(c.qual_hist) == list(oc.qual_hist) and sum(c.qual_hist) == c.bases
+    if flags & scfq.SCFQ_STRUCT_CHECK:
+        assert (c.bad_at, c.bad_plus) == (oc.bad_at, oc.bad_plus) == (0, 0)
     return c, t
 
 
