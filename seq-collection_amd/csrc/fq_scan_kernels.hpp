@@ -54,7 +54,11 @@ constexpr int kHistWaves = 2;   // waves per block in the histogram variant (LDS
 // HIST == 1 kernel, so results never depend on it).  With the class known only quality bytes are histogrammed, into ONE
 // workgroup-shared histogram of 256 bins x kQRep lane-keyed copies (16 KiB for 4 waves instead of 16 KiB per wave):
 // u32 bin[byte * kQRep + copy].
-constexpr int kQRep = 16;
+#ifndef SCFQ_QREP
+#define SCFQ_QREP 16
+#endif
+constexpr int kQRep = SCFQ_QREP;     // 4 | 8 | 16
+constexpr int kQShift = 2 + (kQRep == 16 ? 4 : kQRep == 8 ? 3 : 2);   // byte offset of a bin copy: byte << kQShift | copy << 2
 constexpr int kQWords = 256 * kQRep;
 #ifndef SCFQ_QWAVES
 #define SCFQ_QWAVES 8
@@ -467,8 +471,8 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
   const uint32_t qcls = st.qcls;
   const uint8_t* lane_bytes = slot + lane * 64;
   uint8_t* base = reinterpret_cast<uint8_t*>(hq) + ((lane & (kQRep - 1)) << 2);
-  constexpr uint32_t kMask = 0xFFu << 6;   // byte offset of a bin copy: byte << 6 | copy << 2
-  static_assert(kQRep == 16, "bin offset arithmetic assumes 16 copies");
+  constexpr uint32_t kMask = 0xFFu << kQShift;   // byte offset of a bin copy: byte << kQShift | copy << 2
+  static_assert(kQRep == 16 || kQRep == 8 || kQRep == 4, "bin offset arithmetic");
 #ifndef SCFQ_QABLATE
 #define SCFQ_QABLATE 0   // timing-only diagnostic builds: 1 = addresses computed but no LDS atomics, 2 = no histogram work at all
 #endif
@@ -518,10 +522,10 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
     const bool is_piv = (w == piv4);
     pc += (in && is_piv) ? 1u : 0u;
     if (in && !is_piv) {
-      bump_byte(w << 6);
-      bump_byte(w >> 2);
-      bump_byte(w >> 10);
-      bump_byte(w >> 18);
+      bump_byte(w << kQShift);
+      bump_byte(w >> (8 - kQShift));
+      bump_byte(w >> (16 - kQShift));
+      bump_byte(w >> (24 - kQShift));
     }
   }
   st.piv_cnt = pc;
@@ -530,14 +534,14 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
 #pragma unroll
   for (uint32_t i = 0; i < 3; ++i) {
     const uint32_t hp = a + i, tp = ts + i;
-    if (hp < he) bump((uint32_t)lane_bytes[hp] << 6);
-    if (tp < b) bump((uint32_t)lane_bytes[tp] << 6);
+    if (hp < he) bump((uint32_t)lane_bytes[hp] << kQShift);
+    if (tp < b) bump((uint32_t)lane_bytes[tp] << kQShift);
   }
   if (cnt >= i0 + 4u) {   // rare: another quality segment starts in this lane
     for (uint32_t k = b + 1; k < 64; ++k) {
       const uint64_t bit = 1ull << k;
       const uint32_t cls = (cls0 + popc64(NL & (bit - 1))) & 3u;
-      if (cls == qcls && !(NL & bit)) bump((uint32_t)lane_bytes[k] << 6);
+      if (cls == qcls && !(NL & bit)) bump((uint32_t)lane_bytes[k] << kQShift);
     }
   }
 }
@@ -599,16 +603,29 @@ __device__ __forceinline__ void hist_tile_planes(const uint32_t* xa, const uint3
   uint32_t k = 0;
   for (;;) {
     const uint32_t n_hot = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
-    for (; k < n_hot; ++k) {                             // wave-uniform loop: one dispatch per hot value
-      const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)((k < 4u) ? st.hotp[0] : st.hotp[1]));
-      const uint32_t sh = (k & 3u) * 8u;
+    // wave-uniform loop, one dispatch per hot value; the values sit in a 64-bit scalar shift register, the counts go to
+    // 8-bit fields of two registers (values 0..3 / 4..7) with one shift-add each
+    uint64_t hv = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0])) >> (8u * k);
+    uint32_t p0 = st.p_hot[0], p1 = st.p_hot[1];
+    for (; k < n_hot && k < 4u; ++k, hv >>= 8) {
       uint32_t ma, mb;
-      hot_match(xa, xb, ra, rb, (word >> sh) & 0xFFu, ma, mb);    // hot values are distinct: matching inside the rest is exact
-      const uint32_t c = ((uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb)) << sh;
-      if (k < 4u) st.p_hot[0] += c; else st.p_hot[1] += c;
+      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);    // hot values are distinct: matching inside the rest is exact
+      const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
+      p0 = (c << (8u * k)) + p0;
       ra &= ~ma;
       rb &= ~mb;
     }
+    for (; k < n_hot; ++k, hv >>= 8) {
+      uint32_t ma, mb;
+      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);
+      const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
+      p1 = (c << (8u * (k - 4u))) + p1;
+      ra &= ~ma;
+      rb &= ~mb;
+    }
+    st.p_hot[0] = p0;
+    st.p_hot[1] = p1;
     have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
     if (have == 0 || n_hot >= (uint32_t)kHot) break;
     // a byte outside the hot set while the set has room: its value joins (the loop above then counts it)
