@@ -1,0 +1,572 @@
+// gz_inflate_kernels.hpp — device-side inflate of ORDINARY gzip members (gfx950): BASELINE configs[3], the reference's
+// ".gz" path (src/fq_count.nim:30-34 -> newGZFileStream -> zlib gzread, gzip_stream.nim:16-17).
+//
+// A deflate stream is serial twice over: a block's bit position is only known once the block before it has been decoded,
+// and a back-reference may reach into the 32 KiB before the block.  As pugz / rapidgzip (and csrc/scfq_pgz.hpp on the
+// host) do it, in four kernels over the COMPRESSED bytes resident in HBM:
+//   G1 gz_sync_search     one workgroup per segment scans the bit positions after the segment's nominal start for
+//                         something that parses as a dynamic-Huffman block header (BTYPE, HLIT / HDIST ranges, a complete
+//                         code-length code: one lane per position; the few survivors then decode the code lengths and ask
+//                         for complete literal/length and distance codes and an end-of-block code).  A wrong sync never
+//                         survives the host's chain check: the segment before must arrive at exactly that bit.
+//   G2 gz_segment_decode  one wave per segment (the symbol loop of bgzf_inflate: bit reader on the scalar unit, tables in
+//                         LDS), output = 16-bit symbols behind 32768 marker symbols 0x8000 | k ("byte k of the window I do
+//                         not have yet"); back-references copy symbols whether known or not.  Ends at the first block
+//                         boundary at or after the next segment's start, or with the member's final block.
+//   G3 gz_window_chain    the 32 KiB window in front of every segment, sequentially along the chain (one workgroup, two
+//                         windows in LDS): W[k+1] = last 32 KiB of (W[k] ++ symbols of k), markers resolved through W[k].
+//   G4 gz_resolve         every symbol becomes a byte (markers through the segment's window), written at the segment's
+//                         offset of the inflated stream; a marker that points before the member's start is corrupt data.
+//   G5 gz_crc32_tiles     raw CRC-32 (zero init) of 1 MiB tiles of the inflated bytes; the host folds the tiles and checks
+//                         every member's CRC-32 / ISIZE trailer.
+// The host (scfq_api.hip: ingest_gz_device) validates the chain, re-decodes gaps (a false sync, the first block of a
+// further member), and falls back to the host readers on anything it cannot prove consistent: results are gzread's
+// byte stream or SCFQ_EGZ, never something in between.
+#pragma once
+#include "bgzf_inflate_kernel.hpp"
+
+namespace scfq_dinflate {
+
+constexpr uint32_t kGzWindow = 32768;
+
+// ---- bit access for the search kernel: 64 bits starting at an arbitrary bit position (the buffer is padded) ----------
+__device__ __forceinline__ uint64_t bits64_at(const uint64_t* words, uint64_t bit) {
+  const uint64_t w = bit >> 6;
+  const uint32_t sh = (uint32_t)bit & 63u;
+  const uint64_t lo = words[w], hi = words[w + 1];
+  return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+}
+
+constexpr uint32_t kSyncThreads = 256;
+constexpr uint32_t kSyncChunkBits = 32768;      // positions examined between two looks at the survivor list
+constexpr uint32_t kSyncListCap = 1024;
+
+// header of a dynamic block at `bit`: cheap tests first (one lane per position), result = survives / not
+__device__ __forceinline__ bool sync_quick(const uint64_t* words, uint64_t bit) {
+  const uint64_t w = bits64_at(words, bit);
+  if (((w >> 1) & 3u) != 2u) return false;                 // BTYPE 10
+  if (((w >> 3) & 31u) > 29u) return false;                // HLIT <= 286 - 257
+  if (((w >> 8) & 31u) > 29u) return false;                // HDIST <= 30 - 1
+  const uint32_t hclen = (uint32_t)((w >> 13) & 15u) + 4u;
+  const uint64_t w2 = bits64_at(words, bit + 17);          // the 3-bit code-length code lengths
+  uint32_t kraft = 0;
+  for (uint32_t k = 0; k < hclen; ++k) {
+    const uint32_t l = (uint32_t)(w2 >> (3u * k)) & 7u;
+    kraft += l ? (128u >> l) : 0u;
+  }
+  return kraft == 128u;                                    // complete (zlib rejects anything else for this code)
+}
+
+// the rest of the header: decode the HLIT + HDIST code lengths with the code-length code, ask for a complete literal/length
+// code with an end-of-block code and a distance code zlib accepts.  Everything lives in registers (counts and the symbols
+// sorted by code length are packed into 64-bit words), and a candidate is dropped the moment one of its codes is
+// over-subscribed: random bits get there within a few dozen lengths, so the survivors of sync_quick cost little.
+__device__ inline bool sync_deep(const uint64_t* words, uint64_t bit, uint64_t end_bit) {
+  const uint64_t w = bits64_at(words, bit);
+  const uint32_t hlit = (uint32_t)((w >> 3) & 31u) + 257u, hdist = (uint32_t)((w >> 8) & 31u) + 1u, hclen = (uint32_t)((w >> 13) & 15u) + 4u;
+  const uint64_t w2 = bits64_at(words, bit + 17);
+  uint64_t pl = 0;                                         // code length of code-length symbol s in bits [3s, 3s+3)
+  for (uint32_t k = 0; k < hclen; ++k) pl |= ((w2 >> (3u * k)) & 7ull) << (3u * kClOrder[k]);
+  uint64_t cnt8 = 0;                                       // number of symbols with code length l in bits [8l, 8l+8)
+  for (uint32_t s = 0; s < 19; ++s) cnt8 += 1ull << (8u * (uint32_t)((pl >> (3u * s)) & 7u));
+  // symbols sorted by (code length, symbol): 19 x 5 bits in two words (12 per word)
+  uint64_t srt0 = 0, srt1 = 0;
+  {
+    uint32_t at = 0;
+    for (uint32_t len = 1; len <= 7; ++len)
+      for (uint32_t s = 0; s < 19; ++s)
+        if (((pl >> (3u * s)) & 7u) == len) { if (at < 12) srt0 |= (uint64_t)s << (5u * at); else srt1 |= (uint64_t)s << (5u * (at - 12)); ++at; }
+  }
+  uint64_t pos = bit + 17 + 3u * hclen;
+  const uint32_t total = hlit + hdist;
+  uint32_t k = 0, prev = 0, kraft_l = 0, kraft_d = 0, n_d = 0, max_d = 0, len256 = 0;
+  while (k < total) {
+    if (pos + 64 > end_bit) return false;
+    uint64_t b = bits64_at(words, pos);
+    // canonical decode, one bit at a time (codes are at most 7 bits)
+    uint32_t code = 0, first = 0, index = 0, sym = 0xFFu, used = 0;
+    for (uint32_t len = 1; len <= 7; ++len) {
+      code |= (uint32_t)(b & 1u);
+      b >>= 1;
+      ++used;
+      const uint32_t cnt = (uint32_t)(cnt8 >> (8u * len)) & 0xFFu;
+      if (code - first < cnt) {
+        const uint32_t at = index + (code - first);
+        sym = at < 12 ? (uint32_t)(srt0 >> (5u * at)) & 31u : (uint32_t)(srt1 >> (5u * (at - 12))) & 31u;
+        break;
+      }
+      index += cnt;
+      first = (first + cnt) << 1;
+      code <<= 1;
+    }
+    if (sym == 0xFFu) return false;
+    uint32_t rep = 1, val = sym;
+    if (sym == 16) { if (k == 0) return false; val = prev; rep = 3 + ((uint32_t)b & 3u); used += 2; }
+    else if (sym == 17) { val = 0; rep = 3 + ((uint32_t)b & 7u); used += 3; }
+    else if (sym == 18) { val = 0; rep = 11 + ((uint32_t)b & 127u); used += 7; }
+    pos += used;
+    if (k + rep > total) return false;
+    if (val) {
+      // the run [k, k + rep) may straddle the literal/length | distance border
+      const uint32_t in_l = k >= hlit ? 0u : (k + rep <= hlit ? rep : hlit - k), in_d = rep - in_l;
+      kraft_l += in_l * (32768u >> val);
+      kraft_d += in_d * (32768u >> val);
+      if (kraft_l > 32768u || kraft_d > 32768u) return false;          // over-subscribed: no need to read on
+      if (k <= 256u && 256u < k + rep) len256 = val;
+      if (in_d) { n_d += in_d; max_d = val > max_d ? val : max_d; }
+    }
+    k += rep;
+    prev = val;
+  }
+  if (len256 == 0 || kraft_l != 32768u) return false;      // (zlib also takes an incomplete literal/length code of one 1-bit code: never a real block)
+  return kraft_d == 32768u || n_d == 0 || (n_d == 1 && max_d == 1);
+}
+
+// found[s] = first bit position >= from[s] (and < from[s] + max_bits, < end_bit) that passes; ~0 when none does
+__global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* __restrict__ words, uint64_t end_bit, const uint64_t* __restrict__ from,
+                                                              uint32_t n_seg, uint64_t max_bits, uint64_t* __restrict__ found) {
+  __shared__ uint32_t list[kSyncListCap];
+  __shared__ uint32_t n_list, best;
+  const uint32_t s = blockIdx.x;
+  if (s >= n_seg) return;
+  const uint64_t base = from[s];
+  const uint64_t limit = (base + max_bits < end_bit) ? base + max_bits : end_bit;
+  uint64_t result = ~0ull;
+  for (uint64_t c0 = base; c0 < limit; c0 += kSyncChunkBits) {
+    if (threadIdx.x == 0) { n_list = 0; best = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kSyncChunkBits; i += kSyncThreads) {
+      const uint64_t p = c0 + i;
+      if (p + 128 <= limit && sync_quick(words, p)) {
+        const uint32_t at = atomicAdd(&n_list, 1u);
+        if (at < kSyncListCap) list[at] = i;
+      }
+    }
+    __syncthreads();
+    const uint32_t n = n_list < kSyncListCap ? n_list : kSyncListCap;
+    // (a list that overflowed lost some LATER candidates of this chunk at worst out of order: every kept one is still
+    // tested, the minimum over them is taken, and a missed earlier true block only makes this segment a gap for the host)
+    for (uint32_t t = threadIdx.x; t < n; t += kSyncThreads)
+      if (sync_deep(words, c0 + list[t], end_bit)) atomicMin(&best, list[t]);
+    __syncthreads();
+    if (best != 0xFFFFFFFFu) { result = c0 + best; break; }       // block-uniform
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) found[s] = result;
+}
+
+// ---- G2 ----------------------------------------------------------------------------------------------------------------
+struct GzSeg {
+  uint64_t start_bit;       // first bit of a block header (relative to the compressed buffer)
+  uint64_t stop_bit;        // decode until the first block boundary at or after this bit (or the member's final block)
+  uint64_t sym_off;         // index, in the symbol pool, of the segment's first MARKER symbol (output follows the 32768 markers)
+  uint32_t cap;             // output symbols the segment may produce
+  uint32_t reserved;
+};
+struct GzSegOut {
+  uint64_t end_bit;         // bit after the last block decoded
+  uint32_t n_sym;           // symbols produced
+  uint32_t status;          // kGzOk: at a block boundary; kGzMemberEnd: the final block was decoded; else an error
+};
+enum : uint32_t { kGzOk = 0, kGzMemberEnd = 1, kGzErrData = 2, kGzErrOverflow = 3 };
+
+__global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint8_t* __restrict__ comp, uint64_t comp_bytes, const GzSeg* __restrict__ segs,
+                                                                     uint32_t n_seg, uint16_t* syms, GzSegOut* __restrict__ outs) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t b = blockIdx.x * kWavesPerWg + wave;
+  uint32_t* lit = lds + wave * (kWaveLdsBytes / 4);
+  uint32_t* dist = lit + kLitEntries;
+  uint32_t* cltab = dist + kDistEntries;
+  uint8_t* lens = reinterpret_cast<uint8_t*>(cltab + 128);
+  uint16_t* sorted = reinterpret_cast<uint16_t*>(lens + 320);
+  uint16_t* count = sorted + 320;
+  uint16_t* offs = count + 16;
+  __shared__ uint32_t build_ok[kWavesPerWg];
+  __shared__ uint32_t s_len[32], s_dist[32];
+  if (threadIdx.x < 29) s_len[threadIdx.x] = ((uint32_t)kLenBase[threadIdx.x] << 16) | ((uint32_t)kLenExtra[threadIdx.x] << 4) | kVal;
+  if (threadIdx.x < 30) s_dist[threadIdx.x] = ((uint32_t)kDistBase[threadIdx.x] << 16) | ((uint32_t)kDistExtra[threadIdx.x] << 4) | kVal;
+  __syncthreads();
+  if (b >= n_seg) return;
+
+  const GzSeg sg = segs[b];
+  const uint64_t seg_byte = sg.start_bit >> 3;                       // the read position `ip` counts bytes from here
+  const uint64_t left = comp_bytes - seg_byte;
+  const uint32_t ip_end = left < 0xF0000000ull ? (uint32_t)left : 0xF0000000u;
+  const uint64_t stop64 = sg.stop_bit > seg_byte * 8 ? sg.stop_bit - seg_byte * 8 : 0;
+  const uint32_t stop_rel = stop64 < 0xF0000000ull ? (uint32_t)stop64 : 0xF0000000u;     // bit position relative to seg_byte
+  uint32_t ip = 0;
+  uint16_t* const o = syms + sg.sym_off;
+  const uint32_t cap_total = kGzWindow + sg.cap;                      // symbols, markers included
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)(cap_total * 2u), 0x00020000);
+  const uint32_t not_lane0 = lane == 0 ? 0u : 0xFFFFFFFFu;
+  uint32_t lane_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  // the window this segment does not have: 32768 markers in front of its output
+  for (uint32_t k = lane; k < kGzWindow / 2; k += 64)
+    reinterpret_cast<uint32_t*>(o)[k] = (0x8000u | (2u * k)) | ((0x8000u | (2u * k + 1u)) << 16);
+  uint64_t bb = 0;
+  uint32_t bc = 0;
+  uint32_t pos = kGzWindow, err = kGzOk;
+  bool last = false;
+
+  typedef uint32_t dword4 __attribute__((ext_vector_type(4)));
+  typedef const dword4 __attribute__((address_space(4), aligned(4))) const_dword4;
+  typedef const uint8_t __attribute__((address_space(4))) const_byte;
+  const_byte* const in4 = (const_byte*)(uintptr_t)(comp + (seg_byte & ~3ull));
+  const uint8_t* const in = comp + seg_byte;
+  const uint32_t in_off = (uint32_t)(seg_byte & 3ull);
+  dword4 pf;
+  uint32_t pf_sh;
+#define SCFQ_GPREFETCH()                                                                       \
+  do {                                                                                         \
+    const uint32_t a_ = in_off + (ip < ip_end ? ip : ip_end);                                  \
+    pf_sh = (a_ & 3u) << 3;                                                                    \
+    pf = *(const_dword4*)(in4 + (a_ & ~3u));                                                   \
+  } while (0)
+#define SCFQ_GREFILL()                                                                         \
+  do {                                                                                         \
+    const uint32_t up_ = 31u - pf_sh;                                                          \
+    const uint32_t lo_ = (pf.x >> pf_sh) | ((pf.y << 1) << up_), hi_ = (pf.y >> pf_sh) | ((pf.z << 1) << up_); \
+    bb |= (((uint64_t)hi_ << 32) | lo_) << bc;                                                 \
+    ip += (63u - bc) >> 3;                                                                     \
+    bc |= 56u;                                                                                 \
+    SCFQ_GPREFETCH();                                                                          \
+  } while (0)
+#define SCFQ_GTAKE(n_) do { bb >>= (n_); bc -= (n_); } while (0)
+  SCFQ_GPREFETCH();
+  SCFQ_GREFILL();
+  SCFQ_GTAKE((uint32_t)(sg.start_bit & 7ull));
+
+  uint32_t guard = 0;
+  while (!last && err == kGzOk) {
+    if (ip * 8u - bc >= stop_rel) break;              // at a block boundary at or after the next segment's start
+    SCFQ_GREFILL();
+    if (ip > ip_end + 16) { err = kGzErrData; break; }
+    last = bb & 1;
+    const uint32_t type = (uint32_t)(bb >> 1) & 3u;
+    SCFQ_GTAKE(3);
+    if (type == 0) {
+      SCFQ_GTAKE(bc & 7);
+      const uint32_t len = (uint32_t)bb & 0xFFFF, nlen = (uint32_t)(bb >> 16) & 0xFFFF;
+      SCFQ_GTAKE(32);
+      if ((len ^ nlen) != 0xFFFF) { err = kGzErrData; break; }
+      ip -= bc >> 3;
+      bb = 0; bc = 0;
+      if (ip > ip_end || ip_end - ip < len) { err = kGzErrData; break; }
+      if (pos + len > cap_total) { err = kGzErrOverflow; break; }
+      for (uint32_t k = lane; k < len; k += 64) o[pos + k] = (uint16_t)in[ip + k];
+      ip += len; pos += len;
+      SCFQ_GPREFETCH();
+      continue;
+    }
+    if (type == 3) { err = kGzErrData; break; }
+    if (type == 1) {
+      if (lane == 0) {
+        for (int k = 0; k < 144; ++k) lens[k] = 8;
+        for (int k = 144; k < 256; ++k) lens[k] = 9;
+        for (int k = 256; k < 280; ++k) lens[k] = 7;
+        for (int k = 280; k < 288; ++k) lens[k] = 8;
+        bool ok = build_table(lens, 288, kKindLitLen, lit, kLitRoot, kLitEntries, sorted, count, offs, s_len, s_dist);
+        for (int k = 0; k < 32; ++k) lens[k] = 5;
+        ok = ok && build_table(lens, 32, kKindDist, dist, kDistRoot, kDistEntries, sorted, count, offs, s_len, s_dist);
+        build_ok[wave] = ok ? 1u : 0u;
+      }
+    } else {
+      const uint32_t hlit = ((uint32_t)bb & 31) + 257, hdist = ((uint32_t)(bb >> 5) & 31) + 1, hclen = ((uint32_t)(bb >> 10) & 15) + 4;
+      SCFQ_GTAKE(14);
+      if (hlit > 286 || hdist > 30) { err = kGzErrData; break; }
+      if (lane == 0) for (int k = 0; k < 19; ++k) lens[k] = 0;
+      for (uint32_t k = 0; k < hclen; ++k) {
+        if ((k & 7) == 0) SCFQ_GREFILL();
+        if (lane == 0) lens[kClOrder[k]] = (uint8_t)(bb & 7);
+        SCFQ_GTAKE(3);
+      }
+      if (lane == 0) build_ok[wave] = build_table(lens, 19, kKindCodeLen, cltab, 7, 128, sorted, count, offs, s_len, s_dist) ? 1u : 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (!__builtin_amdgcn_readfirstlane((int)build_ok[wave])) { err = kGzErrData; break; }
+      uint32_t k = 0, prev = 0;
+      const uint32_t total = hlit + hdist;
+      while (k < total) {
+        if (++guard > (1u << 28)) { err = kGzErrData; break; }
+        SCFQ_GREFILL();
+        const uint32_t e = uni(cltab[bb & 127]);
+        if (!(e & kVal)) { err = kGzErrData; break; }
+        SCFQ_GTAKE(e & 15);
+        const uint32_t sym = e >> 16;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) { if (k == 0) { err = kGzErrData; break; } val = prev; rep = 3 + ((uint32_t)bb & 3); SCFQ_GTAKE(2); }
+        else if (sym == 17) { val = 0; rep = 3 + ((uint32_t)bb & 7); SCFQ_GTAKE(3); }
+        else if (sym == 18) { val = 0; rep = 11 + ((uint32_t)bb & 127); SCFQ_GTAKE(7); }
+        if (k + rep > total) { err = kGzErrData; break; }
+        if (lane == 0) for (uint32_t r = 0; r < rep; ++r) lens[k + r] = (uint8_t)val;
+        k += rep;
+        prev = val;
+      }
+      if (err) break;
+      if (lane == 0) {
+        bool ok = lens[256] != 0;
+        ok = ok && build_table(lens + hlit, (int)hdist, kKindDist, dist, kDistRoot, kDistEntries, sorted, count, offs, s_len, s_dist);
+        ok = ok && build_table(lens, (int)hlit, kKindLitLen, lit, kLitRoot, kLitEntries, sorted, count, offs, s_len, s_dist);
+        build_ok[wave] = ok ? 1u : 0u;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!__builtin_amdgcn_readfirstlane((int)build_ok[wave])) { err = kGzErrData; break; }
+    // ---- symbols: the loop of bgzf_inflate, 16 bits per output symbol (see there for why it is shaped this way) --------
+    uint32_t* const lit_v = lit + lane_zero;
+    uint32_t* const dist_v = dist + lane_zero;
+    uint32_t done = 0;
+    uint32_t pend_off = 0xFFFFFFFFu;
+    uint16_t pend_v = 0;
+    do {
+      if (bc < 48) SCFQ_GREFILL();
+      uint32_t e = uni(lit_v[bb & ((1u << kLitRoot) - 1)]);
+      if (e & kSub) {
+        SCFQ_GTAKE(kLitRoot);
+        e = uni(lit_v[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 4) & 15)) - 1))]);
+      }
+      SCFQ_GTAKE(e & 15);
+      if (e & kLit) {
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(e >> 16), orsrc, (pos * 2u) | not_lane0, 0, 0);
+        ++pos;
+      } else if (e & kVal) {
+        const uint32_t lx = (e >> 4) & 15;
+        const uint32_t mlen = (e >> 16) + ((uint32_t)bb & ((1u << lx) - 1));
+        SCFQ_GTAKE(lx);
+        uint32_t d = uni(dist_v[bb & ((1u << kDistRoot) - 1)]);
+        if (d & kSub) {
+          SCFQ_GTAKE(kDistRoot);
+          d = uni(dist_v[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 4) & 15)) - 1))]);
+        }
+        SCFQ_GTAKE(d & 15);
+        const uint32_t dx = (d >> 4) & 15;
+        const uint32_t off = (d >> 16) + ((uint32_t)bb & ((1u << dx) - 1));
+        SCFQ_GTAKE(dx);
+        if (off == 0u) {                     // the entry of an unassigned distance code (a distance never exceeds 32768 <= pos)
+          err = kGzErrData; done = 1;
+        } else {
+          const uint32_t src0 = pos - off;
+          __builtin_amdgcn_raw_buffer_store_b16(pend_v, orsrc, pend_off, 0, 0);
+          pend_off = 0xFFFFFFFFu;
+          if (mlen <= 64) {
+            if (off >= mlen) {
+              pend_v = __builtin_amdgcn_raw_buffer_load_b16(orsrc, (src0 + lane) * 2u, 0, 1 /*sc0*/);
+              pend_off = lane < mlen ? (pos + lane) * 2u : 0xFFFFFFFFu;
+            } else {
+              const uint32_t j = off == 1 ? 0u : lane % off;
+              const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(orsrc, (src0 + j) * 2u, 0, 1 /*sc0*/);
+              __builtin_amdgcn_raw_buffer_store_b16(v, orsrc, lane < mlen ? (pos + lane) * 2u : 0xFFFFFFFFu, 0, 0);
+            }
+          } else {
+            for (uint32_t base = 0; base < mlen; base += 64) {
+              const uint32_t k = base + lane;
+              const uint32_t j = off >= mlen ? k : (off == 1 ? 0u : k % off);
+              const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(orsrc, (src0 + j) * 2u, 0, 1 /*sc0*/);
+              __builtin_amdgcn_raw_buffer_store_b16(v, orsrc, k < mlen ? (pos + k) * 2u : 0xFFFFFFFFu, 0, 0);
+            }
+          }
+          pos += mlen;
+        }
+      } else {
+        if (!(e & kEob)) err = kGzErrData;
+        done = 1;
+      }
+      done |= (cap_total - pos) >> 31;       // pos > cap_total: the descriptor dropped the excess
+      done |= (ip_end + 16u - ip) >> 31;     // a malformed stream reading (clamped) bytes far past the end of the data
+    } while (!done);
+    if (pos > cap_total && err == kGzOk) err = kGzErrOverflow;
+    if (ip > ip_end + 16 && err == kGzOk) err = kGzErrData;
+    __builtin_amdgcn_raw_buffer_store_b16(pend_v, orsrc, pend_off, 0, 0);
+  }
+  if (err == kGzOk && (uint64_t)ip * 8 - bc > (uint64_t)ip_end * 8) err = kGzErrData;     // bits taken beyond the data
+#undef SCFQ_GREFILL
+#undef SCFQ_GPREFETCH
+#undef SCFQ_GTAKE
+  if (lane == 0) {
+    GzSegOut r;
+    r.end_bit = seg_byte * 8 + ((uint64_t)ip * 8 - bc);
+    r.n_sym = pos - kGzWindow;
+    r.status = err ? err : (last ? kGzMemberEnd : kGzOk);
+    outs[b] = r;
+  }
+}
+
+// ---- G3 ----------------------------------------------------------------------------------------------------------------
+struct GzChain {           // one entry per segment of the validated chain, in stream order
+  uint64_t sym_off;        // as in GzSeg
+  uint64_t out_off;        // offset of the segment's first byte in the inflated stream
+  uint32_t n_sym;
+  uint32_t valid_before;   // bytes of real history in front of the segment (0 at a member's start, 32768 once a member is that long)
+  uint32_t chain_id;       // segments of one member form one chain (a member starts with an empty window)
+  uint32_t reserved;
+};
+
+// windows[k] = the 32 KiB in front of segment k (only its last valid_before bytes mean anything).  One workgroup per
+// member (blockIdx.x = chain id, the entries of a chain are contiguous: [first[c], first[c + 1])).
+__global__ __launch_bounds__(1024) void gz_window_chain(const GzChain* __restrict__ chain, const uint32_t* __restrict__ first, const uint16_t* __restrict__ syms,
+                                                       uint8_t* __restrict__ windows) {
+  __shared__ __attribute__((aligned(16))) uint8_t W[2][kGzWindow];
+  // the chain entries of the next 1024 segments, so that the loop never waits for a dependent global load: [k & 1023]
+  __shared__ uint64_t m_off[1024];
+  __shared__ uint32_t m_n[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k0 = first[blockIdx.x], k1 = first[blockIdx.x + 1];
+  for (uint32_t i = tid; i < kGzWindow / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;
+  auto load_meta = [&](uint32_t base) {      // entries [base, base + 1024) into slots [0, 1024)
+    const uint32_t k = base + tid;
+    if (k < k1) { m_off[tid] = chain[k].sym_off; m_n[tid] = chain[k].n_sym; }
+  };
+  load_meta(k0);
+  __syncthreads();
+  // The usual case — a segment of at least 32768 symbols: the new window is its last 32768 symbols, thread t owns 32
+  // consecutive ones (sixteen 4-byte loads in flight at once: the run starts at any symbol).  The loads of segment k + 1 are
+  // issued before segment k is resolved, so the chain pays LDS time per segment, not a memory round trip.
+  uint32_t w[16], wn[16];
+  auto fetch = [&](uint32_t k, uint32_t* dst) {
+    const uint32_t n_k = m_n[(k - k0) & 1023u];
+    if (n_k < kGzWindow) return;
+    const uint16_t* src = syms + m_off[(k - k0) & 1023u] + kGzWindow + (n_k - kGzWindow) + tid * 32u;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) __builtin_memcpy(&dst[q], src + 2 * q, 4);
+  };
+  if (k0 < k1) fetch(k0, w);
+  uint32_t cur = 0;
+  for (uint32_t k = k0; k < k1; ++k) {
+    const uint32_t n = m_n[(k - k0) & 1023u];
+    const uint64_t sym_off = m_off[(k - k0) & 1023u];
+    uint8_t* wout = windows + (uint64_t)k * kGzWindow;
+    for (uint32_t i = tid; i < kGzWindow / 16; i += 1024)
+      reinterpret_cast<uint4*>(wout)[i] = reinterpret_cast<const uint4*>(W[cur])[i];
+    if (k + 1 == k1) break;                                  // nobody needs the window after the chain's last segment
+    if (((k + 1 - k0) & 1023u) == 0) {                       // the next 1024 entries (everyone has read entry k by now)
+      __syncthreads();
+      load_meta(k + 1);
+      __syncthreads();
+    }
+    if (k + 2 < k1) fetch(k + 1, wn);                        // (only resolved when it is not the chain's last segment)
+    if (n >= kGzWindow) {
+      uint32_t o8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const uint32_t sy = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+        const uint32_t v = (sy & 0x8000u) ? (uint32_t)W[cur][sy & 0x7FFFu] : (sy & 0xFFu);
+        o8[j >> 2] |= v << ((j & 3) * 8);
+      }
+      uint32_t* dst = reinterpret_cast<uint32_t*>(W[cur ^ 1]) + tid * 8u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dst[q] = o8[q];
+    } else {
+      const uint16_t* s = syms + sym_off + kGzWindow;        // the segment's output symbols
+      for (uint32_t i = tid; i < kGzWindow; i += 1024) {
+        uint8_t v;
+        if (i >= kGzWindow - n) {
+          const uint16_t sy = s[n - kGzWindow + i];          // (n + i - 32768 >= 0 here)
+          v = (sy & 0x8000u) ? W[cur][sy & 0x7FFFu] : (uint8_t)sy;
+        } else {
+          v = W[cur][i + n];                                 // a short segment: the window slides by n
+        }
+        W[cur ^ 1][i] = v;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q] = wn[q];
+  }
+}
+
+// ---- G4 ----------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kResolveTile = 1u << 17;                  // symbols per workgroup: the 32 KiB window load is a quarter of the tile's traffic
+// work item w: chain entry entry[w], symbols [tile[w] * kResolveTile, ...) of it
+__global__ __launch_bounds__(256) void gz_resolve(const GzChain* __restrict__ chain, const uint32_t* __restrict__ entry, const uint32_t* __restrict__ tile,
+                                                  const uint16_t* __restrict__ syms, const uint8_t* __restrict__ windows, uint8_t* __restrict__ out,
+                                                  uint32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) uint8_t W[kGzWindow];
+  const uint32_t k = entry[blockIdx.x];
+  const GzChain c = chain[k];
+  const uint8_t* win = windows + (uint64_t)k * kGzWindow;
+  for (uint32_t i = threadIdx.x; i < kGzWindow / 16; i += 256) reinterpret_cast<uint4*>(W)[i] = reinterpret_cast<const uint4*>(win)[i];
+  __syncthreads();
+  const uint32_t lo = tile[blockIdx.x] * kResolveTile;
+  const uint32_t hi = (lo + kResolveTile < c.n_sym) ? lo + kResolveTile : c.n_sym;
+  const uint16_t* s = syms + c.sym_off + kGzWindow;
+  uint8_t* o = out + c.out_off;
+  const uint32_t missing = kGzWindow - c.valid_before;       // window slots [0, missing) do not exist
+  uint32_t bad = 0;
+  // 8 symbols (16 bytes in, 8 bytes out) per lane and step; the ends of the tile symbol by symbol (out_off has any alignment)
+  uint32_t i = lo + threadIdx.x * 8u;
+  for (; i + 8u <= hi; i += 256u * 8u) {
+    uint4 q;
+    __builtin_memcpy(&q, s + i, 16);                         // sym_off is a multiple of 8 symbols
+    const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+    uint32_t b8[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t sy = (w4[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+      uint32_t v = sy & 0xFFu;
+      if (sy & 0x8000u) { const uint32_t idx = sy & 0x7FFFu; bad |= (idx < missing) ? 1u : 0u; v = W[idx]; }
+      b8[j >> 2] |= v << ((j & 3) * 8);
+    }
+    __builtin_memcpy(o + i, b8, 8);
+  }
+  // the tile's ragged end (fewer than 8 symbols per lane left): one symbol per lane and step
+  const uint32_t full_end = lo + ((hi - lo) / 8u) * 8u;
+  for (uint32_t j = full_end + threadIdx.x; j < hi; j += 256u) {
+    const uint32_t sy = s[j];
+    uint32_t v = sy & 0xFFu;
+    if (sy & 0x8000u) { const uint32_t idx = sy & 0x7FFFu; bad |= (idx < missing) ? 1u : 0u; v = W[idx]; }
+    o[j] = (uint8_t)v;
+  }
+  if (bad) atomicOr(status, 1u << kGzErrData);
+}
+
+// ---- G5 ----------------------------------------------------------------------------------------------------------------
+// Raw CRC-32 (zero initial value, no final inversion: R(M) = M(x) x^32 mod P, reflected) of the kCrcTile-byte tiles of a
+// virtual message "pad zero bytes, then data[0 .. n)" whose length is a multiple of kCrcTile.  Leading zeros do not change R,
+// R(A || B) = R(A) x^(8|B|) + R(B), and crc32(M) = R(M) ^ (0xFFFFFFFF x^(8|M|)) ^ 0xFFFFFFFF: the host folds the tiles
+// (Horner with x^(8 kCrcTile)) and conditions the result.  Inside a tile thread t owns the 64-byte pieces t, t + 256, ...:
+// its pieces are folded with x^(8 * 16384) per step, the 256 threads are then shifted to the end of the tile and xor-ed.
+constexpr uint32_t kCrcTile = 1u << 20, kCrcStep = 256u * 64u;
+__global__ __launch_bounds__(256) void gz_crc32_tiles(const uint8_t* __restrict__ data, uint64_t n, uint64_t pad, uint32_t* __restrict__ tile_crc) {
+  __shared__ uint32_t red[256];
+  const uint32_t t = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * kCrcTile;    // virtual offset
+  const uint32_t x_step = x_pow_8n(kCrcStep);
+  uint32_t acc = 0;
+  for (uint32_t st = 0; st < kCrcTile / kCrcStep; ++st) {
+    const uint64_t v = tile0 + (uint64_t)st * kCrcStep + (uint64_t)t * 64u;     // virtual offset of this thread's piece
+    uint32_t c = 0;
+    if (v + 64 <= pad) {
+      // all zeros: contributes nothing
+    } else if (v >= pad && v + 64 <= pad + n) {
+      uint4 q[4];
+      __builtin_memcpy(q, data + (v - pad), 64);             // any alignment
+      const uint32_t w[16] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        c ^= w[j];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+      }
+    } else {
+      for (uint32_t j = 0; j < 64; ++j) {
+        const uint64_t p = v + j;
+        const uint32_t byte = (p >= pad && p < pad + n) ? data[p - pad] : 0u;
+        c = crc_byte(c, byte);
+      }
+    }
+    acc = gf2_mulmod(x_step, acc) ^ c;
+  }
+  // thread t's pieces end 64 * (255 - t) bytes before the end of every step
+  red[t] = gf2_mulmod(x_pow_8n(64u * (255u - t)), acc);
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] ^= red[t + s];
+    __syncthreads();
+  }
+  if (t == 0) tile_crc[blockIdx.x] = red[0];
+}
+
+}  // namespace scfq_dinflate

@@ -15,6 +15,7 @@
 #include "scfq_gzfast.hpp"
 #include "scfq_pgz.hpp"
 #include "bgzf_inflate_kernel.hpp"
+#include "gz_inflate_kernels.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -51,6 +52,15 @@ thread_local char g_err[512] = "";
 constexpr uint64_t kDefaultChunk = 64ull << 20;
 constexpr int kStateWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS + scfq::kExtWords;   // partial | hist[4][256] | ext (K3 speculation)
 constexpr int kExtAt = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;
+
+struct GzDevBuffers {      // grow-only, kept in the context between calls (a driver allocation of tens of GB costs more than the inflate)
+  uint8_t* d_comp = nullptr;  uint64_t comp_cap = 0;
+  uint16_t* d_sym = nullptr;  uint64_t sym_cap = 0;      // symbols
+  uint8_t* d_out = nullptr;   uint64_t out_cap = 0;
+  uint8_t* d_win = nullptr;   uint64_t win_cap = 0;
+  uint8_t* d_meta = nullptr;  uint64_t meta_cap = 0;     // segment tables, results, chain, work lists, tile CRCs
+  uint8_t* h_meta = nullptr;  uint64_t hmeta_cap = 0;    // pinned mirror
+};
 
 struct Ctx {
   int dev = -1;
@@ -97,6 +107,7 @@ struct Ctx {
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
   hipEvent_t ev_caller = nullptr;      // orders the caller's stream (scfq_opts.wait_stream) before the private ones
   scfq_timing timing{};
+  GzDevBuffers gz;                     // device-side inflate of ordinary gzip members (scfq_gzdev.hpp)
   std::mutex mu;   // one counting session at a time per device context
 };
 
@@ -704,6 +715,8 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
   return SCFQ_OK;
 }
 
+#include "scfq_gzdev.hpp"      // ingest_gz_device: ordinary gzip members inflated on the device
+
 int partial_on_current_device(const void* ptr, uint64_t n, int is_device, int prev_byte, const scfq_opts* opts,
                               scfq_partial* out, uint64_t* hist) {
   Ctx* c = nullptr;
@@ -901,6 +914,35 @@ static int count_file_partial(const char* path, const scfq_opts* opts, scfq_part
       }
       if (bfd >= 0) close(bfd);
     }
+    // ordinary gzip members: inflate on the device (compressed bytes over PCIe); anything the device path cannot prove
+    // consistent — and small files, FIFOs — goes to the host readers below, which are gzread byte for byte
+    if (gz_device_enabled()) {
+      const int gfd = open(path, O_RDONLY);
+      struct stat gsb;
+      static const uint64_t min_bytes = (uint64_t)std::max(0, env_int("SCFQ_GZ_DEVICE_MIN_MB", 4)) << 20;
+      if (gfd >= 0 && fstat(gfd, &gsb) == 0 && S_ISREG(gsb.st_mode) && (uint64_t)gsb.st_size >= std::max<uint64_t>(min_bytes, 64)) {
+        void* m = mmap(nullptr, (size_t)gsb.st_size, PROT_READ, MAP_PRIVATE, gfd, 0);
+        if (m != MAP_FAILED) {
+          (void)madvise(m, (size_t)gsb.st_size, MADV_SEQUENTIAL);
+          struct Unmap { void* m; size_t n; int fd; ~Unmap() { munmap(m, n); close(fd); } } um{m, (size_t)gsb.st_size, gfd};
+          if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) return SCFQ_EHIP;
+          Ctx* c = nullptr;
+          SessionLock sl;
+          rc = get_ctx(&c, sl);
+          if (!rc) rc = begin_session(c, true);
+          if (!rc) rc = ingest_gz_device(c, static_cast<const uint8_t*>(m), (uint64_t)gsb.st_size, o.flags, timing);
+          if (rc == SCFQ_OK) return end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
+          if (rc != kFallbackToHost) return rc;
+          (void)hipStreamSynchronize(c->compute);
+          (void)hipStreamSynchronize(c->copy);
+          rc = SCFQ_OK;
+        } else {
+          close(gfd);
+        }
+      } else if (gfd >= 0) {
+        close(gfd);
+      }
+    }
     gzFile f = nullptr;
     std::unique_ptr<Source> gsrc = open_gz_source(path, opt_chunk(&o), &f);
     if (!gsrc) return SCFQ_EOPEN;
@@ -1075,6 +1117,7 @@ int scfq_shutdown(void) {
       if (c->h_comp[b]) (void)hipHostFree(c->h_comp[b]);
     }
     if (c->d_dstatus) (void)hipFree(c->d_dstatus);
+    gz_free(&c->gz);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
