@@ -201,7 +201,8 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
  * is lines 4i .. 4i+3. For a device-resident input writes line_off[j] = offset of the first byte of line j for
  * j = 0 .. lines-1 and the sentinel line_off[lines] = offset one past the (real or implied) final '\n', so that line j
  * is bytes [line_off[j], line_off[j+1] - 1) before "\r\n" stripping. line_off_device: device memory of `cap` entries,
- * or NULL to only count. *lines_out is always set; nothing is written when cap < lines + 1. */
+ * or NULL to only count. *lines_out is always set. One pass over the input: entries are written as they are found, so
+ * when cap < lines + 1 the first cap entries are valid and the index is incomplete (size from *lines_out, call again). */
 int scfq_index_lines(const void* device_ptr, uint64_t n, uint64_t* line_off_device, uint64_t cap, uint64_t* lines_out);
 
 /* ---- `sc fq-dedup` (next row of SURVEY.md §8f): src/fq_dedup.nim:14-84 ------------------------

@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(256) void fq_fold_hist_wg(const uint32_t* hist_wg, 
 // exclusive prefix sum of the per-range newline counts (one block; n_ranges is a few 10^4): first_ord[r] = line_base + 1 +
 // number of '\n' in ranges < r  (the first '\n' of range r starts line first_ord[r]); first_ord[n_ranges] = total + line_base + 1
 __global__ __launch_bounds__(1024) void fq_nl_prefix(const uint64_t* partials, uint64_t n_ranges, uint64_t line_base,
-                                                     uint64_t* first_ord) {
+                                                     uint64_t* first_ord, uint32_t stride = kPartialWords) {
   __shared__ uint64_t wave_tot[16];
   __shared__ uint64_t carry;
   const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(1024) void fq_nl_prefix(const uint64_t* partials, u
   __syncthreads();
   for (uint64_t r0 = 0; r0 < n_ranges; r0 += 1024) {
     const uint64_t r = r0 + tid;
-    const uint32_t nl = (r < n_ranges) ? (uint32_t)partials[r * kPartialWords + W_NL] : 0u;   // <= 4096 * kMaxTilesPerRange
+    const uint32_t nl = (r < n_ranges) ? (uint32_t)partials[r * stride + W_NL] : 0u;   // <= 4096 * kMaxTilesPerRange (stride 1: a plain array of counts)
     const uint32_t incl = wave_inclusive_scan(nl);
     if (lane == 63) wave_tot[w] = incl;
     __syncthreads();
@@ -1377,6 +1377,146 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_lines(IndexArgs 
     }
     ord += total;
     slot ^= 1u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5, one pass over the INPUT (the default): fq_index_masks streams the input once through the LDS-DMA ring (the ranges of
+// K1: one wave, ~100 consecutive tiles) and keeps what the index needs of it — the newline mask of every lane's 64 bytes
+// (one bit per input byte, 512 B per tile, coalesced) and the range's newline count; fq_nl_prefix turns the counts into
+// first ordinals; fq_index_expand walks the MASKS (an eighth of the input) and scatters `position of '\n' + 1`.
+// Algorithmic bytes: input x (1 + 1/8 + 1/8) + 8 B per line = 1.34 x input for 150 bp reads, against 2.1 x for the form
+// that reads the input twice.  (A single kernel with a decoupled look-back over the ranges' counts was built and measured
+// first: with 4096 ranges in flight a range's look-back walks 64 dependent steps of 64 predecessors and the kernel ran at
+// 0.33 TB/s; ranges long enough to hide that do not fit their masks into registers.)
+// ------------------------------------------------------------------------------------------------
+struct IndexMaskArgs {
+  const uint8_t* base;        // first byte of the input (any alignment)
+  uint64_t n;                 // bytes
+  uint32_t tiles_per_range;
+  uint64_t n_ranges;
+  uint64_t* masks;            // [n_tiles][64]: newline mask of lane L's 64 bytes of tile t at masks[t * 64 + L]
+  uint64_t* counts;           // [n_ranges]
+  uint32_t* flags_out;        // optional: bit 0 is set when the input may hold a '\r' directly before a '\n' (conservative: a '\r' in
+                              // the last byte of a lane's 64 counts); fq-dedup skips its "\r\n" look-behind reads when it stays clear
+};
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_masks(IndexMaskArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* ring = smem + wave * (2 * kTile);
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
+  const uint64_t range = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (range >= a.n_ranges) return;
+  const uint64_t B = (uint64_t)(uintptr_t)a.base, E = B + a.n;
+  const uint64_t A0 = B & ~(uint64_t)(kTile - 1);
+  const uint32_t n_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((E - A0 + kTile - 1) / kTile));
+  const uint32_t t_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(range * a.tiles_per_range));
+  uint32_t t_end = t_begin + a.tiles_per_range;
+  if (t_end > n_tiles) t_end = n_tiles;
+  t_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_end);
+  const uint32_t full_lo = (uint32_t)__builtin_amdgcn_readfirstlane((A0 < B) ? 1 : 0);
+  const uint32_t full_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A0 + (uint64_t)n_tiles * kTile > E) ? n_tiles - 1 : n_tiles));
+  const bool want_cr = (bool)__builtin_amdgcn_readfirstlane(a.flags_out != nullptr ? 1 : 0);
+  PlaneConsts pc;
+  pc.init();
+
+  auto issue = [&](uint32_t t, uint32_t slot) {
+    const uint64_t ts = A0 + (uint64_t)t * kTile;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + slot * kTile));
+    if (t >= full_lo && t < full_hi) {
+      glds_tile<true>(reinterpret_cast<const uint8_t*>(ts + (uint64_t)lane * 16), dst);
+    } else {
+      const uint64_t safe = (B & ~15ull);
+      uint64_t s[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint64_t ps = ts + (uint64_t)k * 1024 + (uint64_t)lane * 16;
+        const bool ok = (ps + 16 > B) && (ps < E);
+        s[k] = (ok ? ps : safe) - (uint64_t)k * 1024;
+      }
+      glds_tile_edge(reinterpret_cast<const uint8_t*>(s[0]), reinterpret_cast<const uint8_t*>(s[1]),
+                     reinterpret_cast<const uint8_t*>(s[2]), reinterpret_cast<const uint8_t*>(s[3]), dst);
+    }
+  };
+
+  uint64_t cr_seen = 0;
+  uint32_t cnt = 0;                                 // per lane; 64 per tile at most, kMaxTilesPerRange tiles
+  if (t_begin < t_end) issue(t_begin, 0);
+  uint32_t slot = 0;
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) { issue(t + 1, slot ^ 1u); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+    const uint4* p = reinterpret_cast<const uint4*>(ring + slot * kTile + lane * 64);
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    uint32_t a0, a1, a2, a3, a4, b0, b1, b2, b3, b4, xa[8], xb[8];
+    masks32_planes_x<false>(d, pc, xa, a0, a1, a2, a3, a4);
+    masks32_planes_x<false>(d + 8, pc, xb, b0, b1, b2, b3, b4);
+    uint64_t NL = ~((uint64_t)a0 | ((uint64_t)b0 << 32));
+    if (want_cr) {
+      const uint64_t CR = ~((uint64_t)plane_ne<0x0D>(xa) | ((uint64_t)plane_ne<0x0D>(xb) << 32));
+      cr_seen |= ((CR << 1) & NL) | (CR >> 63);
+    }
+    if (!(t >= full_lo && t < full_hi)) {     // first / last tile of the input: only bytes inside [B, E) exist
+      const uint64_t ts = A0 + (uint64_t)t * kTile;
+      const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);
+      int64_t lo = (int64_t)B - ls, hi = (int64_t)E - ls;
+      lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
+      hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
+      const uint64_t mhi = (hi >= 64) ? ~0ull : ((1ull << hi) - 1);
+      const uint64_t mlo = (lo >= 64) ? ~0ull : ((1ull << lo) - 1);
+      NL &= mhi & ~mlo;
+    }
+    __builtin_nontemporal_store(NL, &a.masks[(uint64_t)t * 64 + lane]);
+    cnt += popc64(NL);
+    slot ^= 1u;
+  }
+  const uint32_t total = wave_sum(cnt);
+  if (lane == 0) a.counts[range] = total;
+  if (want_cr && __builtin_amdgcn_ballot_w64(cr_seen != 0) != 0 && lane == 0) atomicOr(a.flags_out, 1u);
+}
+
+struct IndexExpandArgs {
+  const uint64_t* masks;      // fq_index_masks
+  uint64_t lead;              // bytes between the first tile's start and the input's first byte (B - A0)
+  uint32_t n_tiles;
+  uint32_t tiles_per_range;
+  uint64_t n_ranges;
+  const uint64_t* first_ord;  // fq_nl_prefix over the ranges' counts
+  uint64_t* line_off;         // [cap]
+  uint64_t cap;
+  uint64_t off_base;          // offset of the input's first byte in the whole input (streaming chunks)
+};
+
+// one wave per range again, tile by tile over the masks: wave prefix sum of the per-lane counts + a running ordinal
+__global__ __launch_bounds__(256) void fq_index_expand(IndexExpandArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t range = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (range >= a.n_ranges) return;
+  const uint32_t t_begin = (uint32_t)(range * a.tiles_per_range);
+  uint32_t t_end = t_begin + a.tiles_per_range;
+  if (t_end > a.n_tiles) t_end = a.n_tiles;
+  uint64_t ord = a.first_ord[range];
+  // the masks of the next tile are requested before this tile's offsets are written
+  uint64_t x = t_begin < t_end ? __builtin_nontemporal_load(&a.masks[(uint64_t)t_begin * 64 + lane]) : 0;
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    const uint64_t nx = t + 1 < t_end ? __builtin_nontemporal_load(&a.masks[(uint64_t)(t + 1) * 64 + lane]) : 0;
+    const uint32_t cnt = popc64(x);
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total) {      // wave-uniform
+      uint64_t o = ord + (incl - cnt);
+      const uint64_t lane_off = a.off_base + ((uint64_t)t * kTile + (uint64_t)lane * 64 - a.lead) + 1;   // offset of the byte AFTER bit 0 of this lane
+      while (x) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(x);
+        x &= x - 1;
+        if (o < a.cap) a.line_off[o] = lane_off + k;
+        ++o;
+      }
+    }
+    ord += total;
+    x = nx;
   }
 }
 

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint
         done = 1;
       }
       done |= (cap_total - pos) >> 31;       // pos > cap_total: the descriptor dropped the excess
-      done |= (ip_end + 16u - ip) >> 31;     // a malformed stream reading (clamped) bytes far past the end of the data
+      done |= ip > ip_end + 16u ? 1u : 0u;   // a malformed stream reading (clamped) bytes far past the end of the data
     } while (!done);
     if (pos > cap_total && err == kGzOk) err = kGzErrOverflow;
     if (ip > ip_end + 16 && err == kGzOk) err = kGzErrData;

@@ -1370,8 +1370,20 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
 }
 
 // ---- K5: line index of a device-resident input ------------------------------------------------------------------
+// One pass over the input (fq_index_masks keeps one bit per byte, fq_index_expand turns the bits into offsets);
+// SCFQ_INDEX_TWO_PASS=1 keeps the first form (K1 + K2 count, prefix kernel, second pass over the input) for comparison.
+static int index_lines_two_pass(Ctx* c, const uint8_t* base, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out);
+
+// internal (fq-dedup): the index plus flags — bit 0: the input may hold "\r\n" line ends
+int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out);
+
 int scfq_index_lines(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out) {
+  return scfq_index_lines_ex(dptr, n, d_line_off, cap, lines_out, nullptr);
+}
+
+int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out) {
   if ((!dptr && n) || !lines_out) return SCFQ_EARG;
+  if (flags_out) *flags_out = 1u;            // unknown until the one-pass kernel says otherwise
   Ctx* c = nullptr;
   SessionLock sl;
   int rc = get_ctx(&c, sl);
@@ -1380,7 +1392,86 @@ int scfq_index_lines(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_
   if (rc) return rc;
   if ((rc = wait_for_caller(c, nullptr))) return rc;      // input and line_off are the caller's device buffers
   const uint8_t* base = static_cast<const uint8_t*>(dptr);
-  rc = scan_async(c, base, n, -1, 0, false);
+  static const bool two_pass = env_int("SCFQ_INDEX_TWO_PASS", 0) != 0;
+  if (two_pass) return index_lines_two_pass(c, base, n, d_line_off, cap, lines_out);
+  *lines_out = 0;
+  if (n == 0) {
+    if (flags_out) *flags_out = 0;
+    if (d_line_off && cap >= 1) { HIPCHK(hipMemsetAsync(d_line_off, 0, sizeof(uint64_t), c->compute)); HIPCHK(hipStreamSynchronize(c->compute)); }
+    return SCFQ_OK;
+  }
+  const uint64_t B = (uint64_t)(uintptr_t)base, A0 = B & ~(uint64_t)(scfq::kTile - 1);
+  const uint64_t n_tiles = (B + n - A0 + scfq::kTile - 1) / scfq::kTile;
+  if (n_tiles >= (1ull << 32)) { std::snprintf(g_err, sizeof g_err, "a single index launch covers at most 16 TiB"); return SCFQ_EARG; }
+  const uint32_t tpr = pick_tiles_per_range(c, n_tiles);
+  const uint64_t n_ranges = (n_tiles + tpr - 1) / tpr;
+  // scratch: [n_tiles * 64] masks | [n_ranges] counts | [n_ranges + 1] first ordinals | flags
+  const uint64_t words = n_tiles * 64 + 2 * n_ranges + 8;
+  if (words > c->cap_first_ord) {
+    HIPCHK(hipStreamSynchronize(c->compute));
+    if (c->d_first_ord) HIPCHK(hipFree(c->d_first_ord));
+    c->d_first_ord = nullptr;
+    c->cap_first_ord = 0;
+    const uint64_t want = words + words / 8;
+    HIPCHK(hipMalloc(&c->d_first_ord, want * sizeof(uint64_t)));
+    c->cap_first_ord = want;
+  }
+  uint64_t* d_masks = c->d_first_ord;
+  uint64_t* d_counts = d_masks + n_tiles * 64;
+  uint64_t* d_ord = d_counts + n_ranges;
+  uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_ord + n_ranges + 1);
+  const bool write = d_line_off && cap >= 1;
+  if (flags_out) HIPCHK(hipMemsetAsync(d_flags, 0, 8, c->compute));
+  if (write) HIPCHK(hipMemsetAsync(d_line_off, 0, sizeof(uint64_t), c->compute));          // line 0 starts at offset 0
+  scfq::IndexMaskArgs ma;
+  ma.base = base;
+  ma.n = n;
+  ma.tiles_per_range = tpr;
+  ma.n_ranges = n_ranges;
+  ma.masks = d_masks;
+  ma.counts = d_counts;
+  ma.flags_out = flags_out ? d_flags : nullptr;
+  const unsigned grid = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
+  hipLaunchKernelGGL(scfq::fq_index_masks, dim3(grid), dim3(64 * scfq::kWavesPerBlock), scfq::kWavesPerBlock * 2 * scfq::kTile, c->compute, ma);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(scfq::fq_nl_prefix, dim3(1), dim3(1024), 0, c->compute, d_counts, n_ranges, (uint64_t)0, d_ord, 1u);
+  HIPCHK(hipGetLastError());
+  if (write) {
+    scfq::IndexExpandArgs ea;
+    ea.masks = d_masks;
+    ea.lead = B - A0;
+    ea.n_tiles = (uint32_t)n_tiles;
+    ea.tiles_per_range = tpr;
+    ea.n_ranges = n_ranges;
+    ea.first_ord = d_ord;
+    ea.line_off = d_line_off;
+    ea.cap = cap;
+    ea.off_base = 0;
+    hipLaunchKernelGGL(scfq::fq_index_expand, dim3((unsigned)((n_ranges + 3) / 4)), dim3(256), 0, c->compute, ea);
+    HIPCHK(hipGetLastError());
+  }
+  // first_ord[n_ranges] = 1 + number of '\n'
+  HIPCHK(hipMemcpyAsync(c->h_state, d_ord + n_ranges, sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
+  HIPCHK(hipMemcpyAsync(c->h_state + 1, base + n - 1, 1, hipMemcpyDeviceToHost, c->compute));
+  if (flags_out) HIPCHK(hipMemcpyAsync(c->h_state + 2, d_flags, 4, hipMemcpyDeviceToHost, c->compute));
+  HIPCHK(hipStreamSynchronize(c->compute));
+  if (flags_out) *flags_out = (uint32_t)(c->h_state[2] & 0xFFFFFFFFu);
+  c->h_state[0] -= 1;
+  const uint64_t nl = c->h_state[0];
+  const bool open_end = (uint8_t)(c->h_state[1] & 0xFF) != (uint8_t)'\n';
+  const uint64_t lines = nl + (open_end ? 1u : 0u);
+  *lines_out = lines;
+  if (write && cap >= lines + 1 && open_end) {
+    // the final line has no '\n': the sentinel pretends there is one right after the input
+    c->h_state[0] = n + 1;
+    HIPCHK(hipMemcpyAsync(d_line_off + lines, c->h_state, sizeof(uint64_t), hipMemcpyHostToDevice, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+  }
+  return SCFQ_OK;
+}
+
+static int index_lines_two_pass(Ctx* c, const uint8_t* base, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out) {
+  int rc = scan_async(c, base, n, -1, 0, false);
   if (rc) return rc;
   scfq_partial p;
   rc = end_session(c, false, &p, nullptr);      // synchronises: the newline count sizes the index

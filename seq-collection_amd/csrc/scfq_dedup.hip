@@ -6,20 +6,24 @@
 // pre-filter (a false positive is still echoed on its first occurrence), so stdout is exactly "drop each record whose
 // header line equals an earlier header line".  Here the whole (inflated) input sits in HBM (288 GB per GPU) and that
 // definition is computed directly, with no probabilistic structure:
-//   K5  line index            (fq_scan_kernels.hpp: K1 + K2 + fq_nl_prefix + fq_index_lines)
+//   K5  line index            (fq_scan_kernels.hpp: fq_index_masks + fq_index_expand, one pass over the input; it also says whether the input
+//                             holds "\r\n" line ends at all: without them no kernel below looks behind a newline)
 //   D1  dd_hash_headers       64-bit hash of every header line (line 4i, EOL stripped as Nim readLine does)
-//   D2  radix sort            (hash, record) pairs, rocPRIM via hipCUB; stable, so equal hashes stay in file order
+//   D2  radix sort            (hash, record) pairs, rocprim::radix_sort_pairs; stable, so equal hashes stay in file order
 //   D3  dd_mark_duplicates    a record is a duplicate iff an EARLIER record of its equal-hash run has the same bytes:
 //                             exact string compare, so hash collisions cost time, never correctness
 //   D4  dd_record_lengths     bytes each kept record echoes: for each of its lines, text + '\n' ("\r\n" comes out as "\n",
 //                             a final line without '\n' gains one: `echo record`, fq_dedup.nim:59,67,71)
-//   D5  exclusive scan        output offset of every kept record (hipCUB)
+//   D5  exclusive scan        output offset of every kept record (rocprim::exclusive_scan)
 //   D6  dd_gather             one wave per 32 records: one contiguous 16 B/lane copy when the group is kept verbatim
 // Everything is integer / byte work bound by HBM traffic; there is no CPU fallback.
 #include "../../include/sc_fqcount.h"
 
+#include <cstring>        // (rocprim's texture iterator calls memset from host code)
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
+
+extern "C" int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out);   // scfq_api.hip
 
 #include <unistd.h>
 
@@ -108,11 +112,11 @@ int wait_for_caller(hipStream_t stream) {
 // text of line j: [line_off[j], end) where end excludes the '\n' and a '\r' directly before a REAL '\n'
 // (Nim 1.0.6 readLine; a final line without '\n' keeps a trailing '\r')
 __device__ __forceinline__ void line_span(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t j,
-                                          uint64_t& s, uint64_t& e) {
+                                          uint64_t& s, uint64_t& e, bool has_cr = true) {
   s = line_off[j];
   const uint64_t nlpos = line_off[j + 1] - 1;     // position of the (real or implied) '\n'
   e = nlpos;
-  if (nlpos < n && e > s && base[e - 1] == '\r') --e;
+  if (has_cr && nlpos < n && e > s && base[e - 1] == '\r') --e;      // (has_cr: kernel-uniform, from the index pass)
 }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
@@ -141,11 +145,11 @@ __device__ __forceinline__ void load_head64(const uint8_t* base, uint64_t n, uin
 
 // D1: one thread per header line
 __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
-                                                      uint64_t seed, uint32_t hash_bits, uint64_t* keys, uint32_t* idx) {
+                                                      uint64_t seed, uint32_t hash_bits, uint64_t* keys, uint32_t* idx, bool has_cr) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_hdr) return;
   uint64_t s, e;
-  line_span(base, n, line_off, 4 * i, s, e);
+  line_span(base, n, line_off, 4 * i, s, e, has_cr);
   const uint64_t len = e - s;
   uint64_t h = seed ^ (len * 0x9E3779B97F4A7C15ull);
   uint64_t w[8];
@@ -163,10 +167,10 @@ __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint
   idx[i] = (uint32_t)i;
 }
 
-__device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t ra, uint64_t rb) {
+__device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t ra, uint64_t rb, bool has_cr) {
   uint64_t sa, ea, sb, eb;
-  line_span(base, n, line_off, 4 * ra, sa, ea);
-  line_span(base, n, line_off, 4 * rb, sb, eb);
+  line_span(base, n, line_off, 4 * ra, sa, ea, has_cr);
+  line_span(base, n, line_off, 4 * rb, sb, eb, has_cr);
   if (ea - sa != eb - sb) return false;
   const uint64_t len = ea - sa;
   uint64_t wa[8], wb[8];
@@ -185,7 +189,7 @@ __device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, con
 // neighbour p-1: either it is the same string, or the run is a genuine collision and is a handful of entries long)
 __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
                                                          const uint64_t* keys_sorted, const uint32_t* idx_sorted, uint8_t* dup,
-                                                         unsigned long long* counters /* [0] dups, [1] hash collisions */) {
+                                                         unsigned long long* counters /* [0] dups, [1] hash collisions */, bool has_cr) {
   const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n_hdr) return;
   const uint64_t key = keys_sorted[p];
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, u
   bool is_dup = false;
   uint32_t collided = 0;
   for (uint64_t q = p; q > 0 && keys_sorted[q - 1] == key; --q) {
-    if (same_header(base, n, line_off, idx_sorted[q - 1], me)) { is_dup = true; break; }
+    if (same_header(base, n, line_off, idx_sorted[q - 1], me, has_cr)) { is_dup = true; break; }
     ++collided;
   }
   if (is_dup) {                       // dup[] was zeroed: only the duplicates pay a scattered byte store
@@ -205,11 +209,15 @@ __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, u
 
 // D4: bytes record i echoes (0 when dropped): its lines 4i .. min(4i+3, lines-1), each text + '\n'
 __global__ __launch_bounds__(256) void dd_record_lengths(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
-                                                        uint64_t n_hdr, const uint8_t* dup, uint64_t* out_len) {
+                                                        uint64_t n_hdr, const uint8_t* dup, uint64_t* out_len, bool has_cr) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_hdr) return;
   uint64_t total = 0;
-  if (!dup[i]) {
+  if (!dup[i] && !has_cr) {
+    // no "\r\n" anywhere: a record echoes exactly its own bytes (a final line without '\n' gains the one its sentinel implies)
+    const uint64_t j1 = (4 * i + 4 < lines) ? 4 * i + 4 : lines;
+    total = line_off[j1] - line_off[4 * i];
+  } else if (!dup[i]) {
     for (uint64_t j = 4 * i; j < 4 * i + 4 && j < lines; ++j) {
       uint64_t s, e;
       line_span(base, n, line_off, j, s, e);
@@ -285,20 +293,31 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
     std::fprintf(stderr, "scfq dedup: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  int rc = scfq_index_lines(d_in, n, nullptr, 0, &lines);
-  if (rc) return rc;
-  mark("count lines (K1 + K2)");
+  // the line index in ONE pass (count and offsets together): its size is guessed first — a FASTQ line is rarely shorter
+  // than 24 bytes on average — and only a wrong guess costs a second pass with the exact size
+  int rc = SCFQ_OK;
+  uint32_t index_flags = 1;
+  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp;
+  {
+    uint64_t cap = n / 24 + 1024;
+    if ((rc = line_off.alloc(cap * 8, stream))) return rc;
+    DCHK(hipStreamSynchronize(stream));       // scfq_index_lines works on the library's own stream
+    rc = scfq_index_lines_ex(d_in, n, line_off.as<uint64_t>(), cap, &lines, &index_flags);
+    if (rc) return rc;
+    if (lines + 1 > cap) {
+      (void)hipFreeAsync(line_off.release(), stream);
+      if ((rc = line_off.alloc((lines + 1) * 8, stream))) return rc;
+      DCHK(hipStreamSynchronize(stream));
+      rc = scfq_index_lines_ex(d_in, n, line_off.as<uint64_t>(), lines + 1, &lines, &index_flags);
+      if (rc) return rc;
+    }
+  }
+  const bool has_cr = (index_flags & 1u) != 0;
   st->total_reads = lines / 4;                       // n_reads = i div 4      src/fq_dedup.nim:49
   const uint64_t n_hdr = (lines + 3) / 4;            // header lines: 0-based index i mod 4 == 0 (:43,57)
   if (n_hdr >= (1ull << 31)) { std::snprintf(g_derr, sizeof g_derr, "more than 2^31 records in one input"); return SCFQ_EARG; }
   if (n_hdr == 0) return SCFQ_OK;
-  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp;
-  if ((rc = line_off.alloc((lines + 1) * 8, stream))) return rc;
-  DCHK(hipStreamSynchronize(stream));       // scfq_index_lines works on the library's own stream
-  mark("alloc line index");
-  rc = scfq_index_lines(d_in, n, line_off.as<uint64_t>(), lines + 1, &lines);
-  if (rc) return rc;
-  mark("line index (K1 + K2 + K5)");
+  mark("line index (K5, one pass)");
   if ((rc = keys.alloc(n_hdr * 8, stream)) || (rc = keys2.alloc(n_hdr * 8, stream)) || (rc = idx.alloc(n_hdr * 4, stream)) ||
       (rc = idx2.alloc(n_hdr * 4, stream)) || (rc = dup.alloc(n_hdr, stream)) || (rc = out_len.alloc((n_hdr + 1) * 8, stream)) ||
       (rc = out_off.alloc((n_hdr + 1) * 8, stream)) || (rc = counters.alloc(16, stream)))
@@ -308,28 +327,30 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
   static const uint32_t hash_bits = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); int v = e ? std::atoi(e) : 64; return (uint32_t)std::min(64, std::max(1, v)); }();
   hipLaunchKernelGGL(dd_hash_headers, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
-                     0x5CF0DED0B1A5ull, hash_bits, keys.as<uint64_t>(), idx.as<uint32_t>());
+                     0x5CF0DED0B1A5ull, hash_bits, keys.as<uint64_t>(), idx.as<uint32_t>(), has_cr);
   DCHK(hipGetLastError());
   mark("hash headers");
   size_t tmp_bytes = 0;
-  DCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(),
-                                          idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
+  DCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
+                                 (size_t)n_hdr, 0u, hash_bits, stream));
   size_t scan_bytes = 0;
-  DCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (int)(n_hdr + 1), stream));
+  DCHK(rocprim::exclusive_scan(nullptr, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_hdr + 1),
+                               rocprim::plus<uint64_t>(), stream));
   if ((rc = tmp.alloc(std::max(tmp_bytes, scan_bytes), stream))) return rc;
-  DCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(),
-                                          idx2.as<uint32_t>(), (int)n_hdr, 0, (int)hash_bits, stream));
+  DCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
+                                 (size_t)n_hdr, 0u, hash_bits, stream));
   mark("radix sort");
   DCHK(hipMemsetAsync(dup.p, 0, n_hdr, stream));
   hipLaunchKernelGGL(dd_mark_duplicates, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
-                     keys2.as<uint64_t>(), idx2.as<uint32_t>(), dup.as<uint8_t>(), counters.as<unsigned long long>());
+                     keys2.as<uint64_t>(), idx2.as<uint32_t>(), dup.as<uint8_t>(), counters.as<unsigned long long>(), has_cr);
   DCHK(hipGetLastError());
   mark("mark duplicates");
   hipLaunchKernelGGL(dd_record_lengths, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
-                     dup.as<uint8_t>(), out_len.as<uint64_t>());
+                     dup.as<uint8_t>(), out_len.as<uint64_t>(), has_cr);
   DCHK(hipGetLastError());
   DCHK(hipMemsetAsync(out_len.as<uint64_t>() + n_hdr, 0, 8, stream));       // the scan's last output is the total
-  DCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (int)(n_hdr + 1), stream));
+  DCHK(rocprim::exclusive_scan(tmp.p, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_hdr + 1),
+                               rocprim::plus<uint64_t>(), stream));
   uint64_t h[3] = {0, 0, 0};
   DCHK(hipMemcpyAsync(&h[0], out_off.as<uint64_t>() + n_hdr, 8, hipMemcpyDeviceToHost, stream));
   DCHK(hipMemcpyAsync(&h[1], counters.p, 16, hipMemcpyDeviceToHost, stream));
