@@ -72,7 +72,7 @@ __device__ inline uint32_t make_entry(int kind, uint32_t sym, uint32_t nbits, co
 
 // Canonical Huffman code -> two-level table in LDS (serial; called by lane 0 only).  lens: code length per symbol.
 // Returns false for an over-subscribed code or an incomplete one that zlib rejects.
-__device__ inline bool build_table(const uint8_t* lens, int n, int kind, uint32_t* tab, int root, int cap,
+__device__ __attribute__((noinline)) bool build_table(const uint8_t* lens, int n, int kind, uint32_t* tab, int root, int cap,
                                    uint16_t* sorted, uint16_t* count /*[16]*/, uint16_t* offs /*[16]*/,
                                    const uint32_t* s_len, const uint32_t* s_dist) {
   for (int k = 0; k < 16; ++k) count[k] = 0;
@@ -155,6 +155,177 @@ __device__ inline uint32_t x_pow_8n(uint32_t n) {      // x^(8 n) mod P, n < 2^2
 // doing it 64 times over on the vector ALU with exec-mask bookkeeping around every check.
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// ---- the symbol loop of one Huffman block, shared by bgzf_inflate (bytes) and gz_segment_decode (16-bit symbols) -------------
+// A separate, NOT inlined function: inside the kernels the loop inherited the register pressure of everything around it
+// (header parsing, table construction, CRC) — 350 spilled SGPRs, among them the prefetched input dwords, which the compiler
+// then had to WAIT for right after requesting them in order to spill them (the prefetch hid nothing).  As a function the loop
+// has the scalar registers to itself: its state comes in and goes out through a small struct in private memory, once per
+// deflate block.
+//
+// The loop holds no divergent branch: stores are predicated through the buffer descriptor (a lane that must not write gets an
+// out-of-range offset, which the hardware drops), so every branch below is a scalar branch on wave-uniform state and the
+// compiler emits the loop as written (with `if (lane == 0)` regions inside, the CFG structuriser wrapped every exit of the
+// loop in a state machine: about 35 scalar instructions per literal on top of the decode).  For the same reason it has ONE
+// exit at the bottom and if/else instead of break/continue.
+// One refill per pass is enough: a literal/length code, its extra bits, a distance code and its extra bits are at most
+// 15 + 5 + 15 + 13 = 48 of the 56 bits a refill guarantees.
+// Checks are lazy where the hardware already bounds the access: writes beyond the output's end are dropped by the descriptor
+// and end the loop (pos > limit); bits taken beyond the input's end are found by the position check after the loop.
+// A match's store is DEFERRED: the load is issued, the wave goes on decoding, and the store follows when the next match is
+// about to load (it must be in the memory pipeline before a load that may read those bytes) or when the block ends, so the
+// load's latency overlaps the next symbols instead of stalling the wave.  pend_off is out of range in every lane while nothing
+// is pending.  The bytes a match reads were stored by this same wave (lane 0's literals, other lanes' earlier copies): vector
+// memory instructions of one wave reach the CU's L1 in issue order and the write-through L1 serves later loads of the same CU
+// coherently, so no s_waitcnt vmcnt(0) is needed; every member's CRC-32 is verified on the device either way.
+// The table addresses are formed on the vector ALU (lit_v / dist_v look per-lane to the compiler): the loop is bound by the
+// CU's one scalar ALU, every instruction moved off it counts.
+struct SymState {
+  uint64_t bb;               // bit buffer
+  uint32_t bc, ip, pos, err; // bits in bb | bytes consumed | output position (symbols) | error (kErrData / kErrLength)
+  uint32_t pf[4], pf_sh;     // the input dwords requested one refill ahead, and their byte shift
+};
+
+typedef uint32_t dword4_t __attribute__((ext_vector_type(4)));
+typedef const dword4_t __attribute__((address_space(4), aligned(4))) const_dword4_t;
+typedef const uint8_t __attribute__((address_space(4))) const_byte_t;
+
+// SYM16: output symbols are 16 bits wide (gz_segment_decode), else bytes.  limit: output symbols the buffer holds.
+template <bool SYM16>
+__device__ __attribute__((noinline)) void symbol_loop(SymState* stp, const uint8_t* in_aligned /* 4-byte aligned base of the scalar loads */,
+                                                     uint32_t in_off, uint32_t ip_end, void* out_base, uint32_t limit,
+                                                     uint32_t lit_lds, uint32_t dist_lds /* LDS byte offsets of the two tables */) {
+  const uint32_t lane = threadIdx.x & 63;
+  // arguments of a device function arrive in vector registers: say that they are wave-uniform, so that the input goes through
+  // the scalar cache and the descriptor is built from scalars
+  const uint64_t in_u = ((uint64_t)uni((uint32_t)((uintptr_t)in_aligned >> 32)) << 32) | uni((uint32_t)(uintptr_t)in_aligned);
+  const uint64_t out_u = ((uint64_t)uni((uint32_t)((uintptr_t)out_base >> 32)) << 32) | uni((uint32_t)(uintptr_t)out_base);
+  const_byte_t* const in4 = (const_byte_t*)in_u;
+  out_base = (void*)out_u;
+  in_off = uni(in_off);
+  ip_end = uni(ip_end);
+  limit = uni(limit);
+  uint64_t bb = ((uint64_t)uni((uint32_t)(stp->bb >> 32)) << 32) | uni((uint32_t)stp->bb);
+  uint32_t bc = uni(stp->bc), ip = uni(stp->ip), pos = uni(stp->pos), err = kOk;
+  dword4_t pf;
+  pf.x = uni(stp->pf[0]); pf.y = uni(stp->pf[1]); pf.z = uni(stp->pf[2]); pf.w = uni(stp->pf[3]);
+  uint32_t pf_sh = uni(stp->pf_sh);
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_base, 0, (int)(limit * (SYM16 ? 2u : 1u)), 0x00020000);
+  const uint32_t not_lane0 = lane == 0 ? 0u : 0xFFFFFFFFu;
+  uint32_t lane_zero;                                  // 0 in every lane, opaque to the compiler's uniformity analysis
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  // (LDS address space, so that the table reads are ds_read and wait for lgkmcnt only: as generic pointers they were flat loads
+  // that also waited for every outstanding store)
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  lds_u32* const lit_v = (lds_u32*)(uintptr_t)uni(lit_lds) + lane_zero;
+  lds_u32* const dist_v = (lds_u32*)(uintptr_t)uni(dist_lds) + lane_zero;
+#define SCFQ_LPREFETCH()                                                                       \
+  do {                                                                                         \
+    const uint32_t a_ = in_off + (ip < ip_end ? ip : ip_end);                                  \
+    pf_sh = (a_ & 3u) << 3;                                                                    \
+    pf = *(const_dword4_t*)(in4 + (a_ & ~3u));                                                 \
+  } while (0)
+#define SCFQ_LREFILL()                                                                         \
+  do {                                                                                         \
+    const uint32_t up_ = 31u - pf_sh;           /* (x << 1) << up_ == x << (32 - pf_sh), also for pf_sh == 0 */ \
+    const uint32_t lo_ = (pf.x >> pf_sh) | ((pf.y << 1) << up_), hi_ = (pf.y >> pf_sh) | ((pf.z << 1) << up_); \
+    bb |= (((uint64_t)hi_ << 32) | lo_) << bc;                                                 \
+    ip += (63u - bc) >> 3;                                                                     \
+    bc |= 56u;                                                                                 \
+    SCFQ_LPREFETCH();                                                                          \
+  } while (0)
+#define SCFQ_LTAKE(n_) do { bb >>= (n_); bc -= (n_); } while (0)
+  auto store_sym = [&](uint32_t v, uint32_t off) {
+    if (SYM16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, orsrc, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, orsrc, off, 0, 0);
+  };
+  auto load_sym = [&](uint32_t off) -> uint32_t {
+    if (SYM16) return __builtin_amdgcn_raw_buffer_load_b16(orsrc, off, 0, 1 /*sc0*/);
+    return __builtin_amdgcn_raw_buffer_load_b8(orsrc, off, 0, 1 /*sc0*/);
+  };
+  constexpr uint32_t kSh = SYM16 ? 1u : 0u;            // symbol index -> byte offset
+  uint32_t done = 0;
+  uint32_t pend_off = 0xFFFFFFFFu;
+  uint32_t pend_v = 0;
+  do {
+    if (bc < 48) SCFQ_LREFILL();           // (the prefetched dwords stay valid: ip only moves in a refill)
+    if (SCFQ_DABLATE & 8) {                // measurement only: ten more scalar instructions per symbol
+      uint32_t t_ = pos;
+#pragma unroll
+      for (int q_ = 0; q_ < 10; ++q_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(t_) : : "scc");
+      asm volatile("" : : "s"(t_));
+    }
+    if (SCFQ_DABLATE & 16) {               // measurement only: ten more vector instructions per symbol
+      uint32_t t_ = lane;
+#pragma unroll
+      for (int q_ = 0; q_ < 10; ++q_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_));
+      asm volatile("" : : "v"(t_));
+    }
+    uint32_t e = uni(lit_v[bb & ((1u << kLitRoot) - 1)]);
+    if (e & kSub) {
+      SCFQ_LTAKE(kLitRoot);
+      e = uni(lit_v[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 4) & 15)) - 1))]);
+    }
+    SCFQ_LTAKE(e & 15);
+    if (e & kLit) {
+      if (!(SCFQ_DABLATE & 4)) store_sym(e >> 16, (pos << kSh) | not_lane0);
+      ++pos;
+    } else if (e & kVal) {
+      const uint32_t lx = (e >> 4) & 15;
+      const uint32_t mlen = (e >> 16) + ((uint32_t)bb & ((1u << lx) - 1));
+      SCFQ_LTAKE(lx);
+      uint32_t d = uni(dist_v[bb & ((1u << kDistRoot) - 1)]);
+      if (d & kSub) {
+        SCFQ_LTAKE(kDistRoot);
+        d = uni(dist_v[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 4) & 15)) - 1))]);
+      }
+      SCFQ_LTAKE(d & 15);
+      const uint32_t dx = (d >> 4) & 15;
+      const uint32_t off = (d >> 16) + ((uint32_t)bb & ((1u << dx) - 1));
+      SCFQ_LTAKE(dx);
+      if (off - 1u >= pos) {               // off > pos (nothing that far back), or off == 0: the entry of an unassigned
+                                           // distance code has base 0 and no extra bits
+        err = kErrData; done = 1;
+      } else {
+        const uint32_t src0 = pos - off;
+        store_sym(pend_v, pend_off);
+        pend_off = 0xFFFFFFFFu;
+        if (SCFQ_DABLATE & 1) {
+        } else if (mlen <= 64) {           // one pass of the wave (nested ifs: a combined condition costs the scalar ALU more)
+          if (off >= mlen) {
+            pend_v = load_sym((src0 + lane) << kSh);
+            pend_off = lane < mlen ? (pos + lane) << kSh : 0xFFFFFFFFu;
+          } else {                         // the match overlaps its own output: period `off`
+            const uint32_t j = off == 1 ? 0u : lane % off;
+            const uint32_t v = load_sym((src0 + j) << kSh);
+            store_sym(v, lane < mlen ? (pos + lane) << kSh : 0xFFFFFFFFu);
+          }
+        } else {
+          for (uint32_t base = 0; base < mlen; base += 64) {
+            const uint32_t k = base + lane;
+            const uint32_t j = off >= mlen ? k : (off == 1 ? 0u : k % off);
+            const uint32_t v = load_sym((src0 + j) << kSh);
+            store_sym(v, k < mlen ? (pos + k) << kSh : 0xFFFFFFFFu);
+          }
+        }
+        pos += mlen;
+      }
+    } else {                               // end of block, or a code that is not assigned
+      if (!(e & kEob)) err = kErrData;
+      done = 1;
+    }
+    // (sign-bit arithmetic keeps both tests on the scalar unit; all four values are below 2^30, the callers see to it)
+    done |= (limit - pos) >> 31;           // pos > limit: the descriptor dropped the excess, the stream is malformed (or the room too small)
+    done |= (ip_end + 16u - ip) >> 31;     // a malformed stream reading (clamped) bytes far past the end of the data
+  } while (!done);
+  store_sym(pend_v, pend_off);
+#undef SCFQ_LREFILL
+#undef SCFQ_LPREFETCH
+#undef SCFQ_LTAKE
+  // (private memory is per lane: every lane stores the same wave-uniform values into its own copy)
+  stp->bb = bb; stp->bc = bc; stp->ip = ip; stp->pos = pos; stp->err = err;
+  stp->pf[0] = pf.x; stp->pf[1] = pf.y; stp->pf[2] = pf.z; stp->pf[3] = pf.w; stp->pf_sh = pf_sh;
+}
+
 __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks,
                                                                 uint32_t n_blocks, uint8_t* out, uint32_t* status /* one word, OR of (1 << error) */) {
   extern __shared__ uint32_t lds[];
@@ -182,10 +353,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   uint8_t* const o = out + blk.out_off;
   const uint32_t isize = blk.isize;
   // the member's output as a buffer descriptor: an offset outside [0, isize) is dropped (store) or reads 0 (load)
-  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)isize, 0x00020000);
-  const uint32_t not_lane0 = lane == 0 ? 0u : 0xFFFFFFFFu;
-  uint32_t lane_zero;                                  // 0 in every lane, opaque to the compiler's uniformity analysis
-  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
   uint64_t bb = 0;
   uint32_t bc = 0;                                     // bits in bb: 56..63 after every refill
   uint32_t pos = 0, err = kOk;
@@ -307,116 +474,23 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     }
     __builtin_amdgcn_wave_barrier();
     if (!__builtin_amdgcn_readfirstlane((int)build_ok[wave])) { err = kErrData; break; }
-    // ---- symbols --------------------------------------------------------------------------------------------------
-    // The loop holds no divergent branch: stores are predicated through the buffer descriptor (a lane that must not write
-    // gets an out-of-range offset, which the hardware drops), so every branch below is a scalar branch on wave-uniform
-    // state and the compiler emits the loop as written (with `if (lane == 0)` regions inside, the CFG structuriser wrapped
-    // every exit of the loop in a state machine: about 35 scalar instructions per literal on top of the decode).  For the
-    // same reason it has ONE exit at the bottom and if/else instead of break/continue.
-    // One refill per pass is enough: a literal/length code, its extra bits, a distance code and its extra bits are at
-    // most 15 + 5 + 15 + 13 = 48 of the 56 bits a refill guarantees.
-    // Checks are lazy where the hardware already bounds the access: writes beyond ISIZE are dropped by the descriptor
-    // and end the loop (pos > isize); bits taken beyond the member's end are found by the position check after the loop.
-    // A match's store is DEFERRED: the load is issued, the wave goes on decoding, and the store follows when the next
-    // match is about to load (it must be in the memory pipeline before a load that may read those bytes) or when the
-    // block ends, so the load's latency overlaps the next symbols instead of stalling the wave.  pend_off is out of range
-    // in every lane while nothing is pending.
-    // The table addresses are formed on the vector ALU (lit_v / dist_v look per-lane to the compiler): the loop is bound
-    // by the CU's one scalar ALU, every instruction moved off it counts.
-    uint32_t* const lit_v = lit + lane_zero;
-    uint32_t* const dist_v = dist + lane_zero;
-    uint32_t done = 0;
-    uint32_t pend_off = 0xFFFFFFFFu;
-    uint8_t pend_v = 0;
+    // ---- symbols (symbol_loop above) -----------------------------------------------------------------------------------
 #ifdef SCFQ_DSTATS
     ++n_blk;
 #endif
-    do {
-      if (bc < 48) SCFQ_DREFILL();           // (the prefetched dwords stay valid: ip only moves in a refill)
-      if (SCFQ_DABLATE & 8) {                // measurement only: ten more scalar instructions per symbol
-        uint32_t t_ = pos;
-#pragma unroll
-        for (int q_ = 0; q_ < 10; ++q_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(t_) : : "scc");
-        asm volatile("" : : "s"(t_));
-      }
-      if (SCFQ_DABLATE & 16) {               // measurement only: ten more vector instructions per symbol
-        uint32_t t_ = lane;
-#pragma unroll
-        for (int q_ = 0; q_ < 10; ++q_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_));
-        asm volatile("" : : "v"(t_));
-      }
-      uint32_t e = uni(lit_v[bb & ((1u << kLitRoot) - 1)]);
-      if (e & kSub) {
-        SCFQ_DTAKE(kLitRoot);
-        e = uni(lit_v[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 4) & 15)) - 1))]);
-      }
-      SCFQ_DTAKE(e & 15);
-      if (e & kLit) {
-        if (!(SCFQ_DABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(e >> 16), orsrc, pos | not_lane0, 0, 0);
-        ++pos;
-#ifdef SCFQ_DSTATS
-        ++n_lit;
-#endif
-      } else if (e & kVal) {
-        const uint32_t lx = (e >> 4) & 15;
-        const uint32_t mlen = (e >> 16) + ((uint32_t)bb & ((1u << lx) - 1));
-        SCFQ_DTAKE(lx);
-        uint32_t d = uni(dist_v[bb & ((1u << kDistRoot) - 1)]);
-        if (d & kSub) {
-          SCFQ_DTAKE(kDistRoot);
-          d = uni(dist_v[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 4) & 15)) - 1))]);
-        }
-        SCFQ_DTAKE(d & 15);
-        const uint32_t dx = (d >> 4) & 15;
-        const uint32_t off = (d >> 16) + ((uint32_t)bb & ((1u << dx) - 1));
-        SCFQ_DTAKE(dx);
-        if (off - 1u >= pos) {               // off > pos (a BGZF member starts with an empty window), or off == 0: the
-                                             // entry of an unassigned distance code has base 0 and no extra bits
-          err = kErrData; done = 1;
-        } else {
-          // The bytes the match reads were stored by this same wave (lane 0's literals, other lanes' earlier copies).
-          // Vector memory instructions of one wave reach the CU's L1 in issue order and the write-through L1 serves later
-          // loads of the same CU coherently (the workgroup-scope rule of the AMDGPU memory model: no cache maintenance
-          // inside a CU), so no s_waitcnt vmcnt(0) is needed here.  SCFQ_DINFLATE_FENCE builds the conservative form
-          // (measured: same speed); every member's CRC-32 is verified on the device either way.
-#ifdef SCFQ_DINFLATE_FENCE
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
-          const uint32_t src0 = pos - off;
-          __builtin_amdgcn_raw_buffer_store_b8(pend_v, orsrc, pend_off, 0, 0);
-          pend_off = 0xFFFFFFFFu;
-          if (SCFQ_DABLATE & 1) {
-          } else if (mlen <= 64) {           // one pass of the wave (nested ifs: a combined condition costs the scalar ALU more)
-            if (off >= mlen) {
-              pend_v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + lane, 0, 1 /*sc0*/);
-              pend_off = lane < mlen ? pos + lane : 0xFFFFFFFFu;
-            } else {                         // the match overlaps its own output: period `off`
-              const uint32_t j = off == 1 ? 0u : lane % off;
-              const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + j, 0, 1 /*sc0*/);
-              __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, lane < mlen ? pos + lane : 0xFFFFFFFFu, 0, 0);
-            }
-          } else {
-            for (uint32_t base = 0; base < mlen; base += 64) {
-              const uint32_t k = base + lane;
-              const uint32_t j = off >= mlen ? k : (off == 1 ? 0u : k % off);
-              const uint8_t v = __builtin_amdgcn_raw_buffer_load_b8(orsrc, src0 + j, 0, 1 /*sc0*/);
-              __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, k < mlen ? pos + k : 0xFFFFFFFFu, 0, 0);
-            }
-          }
-          pos += mlen;
-#ifdef SCFQ_DSTATS
-          ++n_match; n_mbytes += mlen; n_overlap += off < mlen; n_long += mlen > 64;
-#endif
-        }
-      } else {                               // end of block, or a code that is not assigned
-        if (!(e & kEob)) err = kErrData;
-        done = 1;
-      }
-      done |= (isize - pos) >> 31;           // pos > isize (both below 2^17): the descriptor dropped the excess, the stream is malformed
-    } while (!done);
+    {
+      SymState sst;
+      sst.bb = bb; sst.bc = bc; sst.ip = ip; sst.pos = pos; sst.err = kOk;
+      sst.pf[0] = pf.x; sst.pf[1] = pf.y; sst.pf[2] = pf.z; sst.pf[3] = pf.w; sst.pf_sh = pf_sh;
+      symbol_loop<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      // (every lane holds the same state in its private copy: read it back as wave-uniform values)
+      bb = ((uint64_t)uni((uint32_t)(sst.bb >> 32)) << 32) | uni((uint32_t)sst.bb);
+      bc = uni(sst.bc); ip = uni(sst.ip); pos = uni(sst.pos);
+      const uint32_t e2 = uni(sst.err);
+      pf.x = uni(sst.pf[0]); pf.y = uni(sst.pf[1]); pf.z = uni(sst.pf[2]); pf.w = uni(sst.pf[3]); pf_sh = uni(sst.pf_sh);
+      if (e2) err = e2;
+    }
     if (pos > isize && err == kOk) err = kErrLength;
-    __builtin_amdgcn_raw_buffer_store_b8(pend_v, orsrc, pend_off, 0, 0);
   }
   // bits taken beyond the end of the deflate data (they were trailer bytes, or the clamped load's): the stream is malformed
   if (err == kOk && (uint64_t)ip * 8 - bc > (uint64_t)ip_end * 8) err = kErrData;

@@ -10,13 +10,15 @@
 //      HBM -> LDS with non-temporal LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB coalesced
 //      per instruction, 4 per tile, a 2-slot ring per wave, no VGPR staging, no barriers: a wave only
 //      ever reads LDS bytes it loaded itself).  Each lane then owns 64 contiguous bytes of the tile
-//      (4 x ds_read_b128), turns them into 64-bit match masks ('\n', G|C, N [, '@', '+']) with
-//      byte-transposed carry-SWAR compares, gets its line phase from a DPP wave prefix-sum of newline
-//      counts, and adds per-segment popcounts into 8-bit packed per-class fields (4 classes in one
-//      VGPR; the class index is a shift amount, never a register index).  No MFMA: this is an
-//      HBM-bound byte reduction.
+//      (4 x ds_read_b128), turns them into 64-bit match masks ('\n', G|C, N [, '@', '+']) with the
+//      bit-plane classifier (v_perm byte transpose, masked block swaps into 8 bit planes, one 8-input AND per
+//      symbol in v_bitop3), gets its line phase from a DPP wave prefix-sum of newline counts, and adds
+//      per-segment popcounts into 8-bit packed per-class fields (4 classes in one VGPR; the class index is a
+//      shift amount, never a register index).  No MFMA: this is an HBM-bound byte reduction.
 // K2 fq_fold_fused : ordered (non-commutative) fold of the per-range partials, one launch.
-// K3 / K4          : quality-byte histogram / '@','+' structure check, fused variants of K1.
+// K3 / K4          : quality-byte histogram / '@','+' structure check, fused variants of K1.  K3's default form counts
+//      quality bytes over small alphabets straight from the bit planes (hist_tile_planes), LDS atomics only otherwise.
+// K5 fq_index_masks + fq_index_expand : line index (record-boundary detection) in one pass over the input.
 //
 // Byte semantics follow Nim 1.0.6 readLine as used by the reference: '\n' ends a line, a '\r'
 // directly before that '\n' is not part of the line; G/C/N are case-sensitive (fq_count.nim:43-44).

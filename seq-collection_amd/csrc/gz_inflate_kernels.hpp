@@ -193,16 +193,14 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint
   const GzSeg sg = segs[b];
   const uint64_t seg_byte = sg.start_bit >> 3;                       // the read position `ip` counts bytes from here
   const uint64_t left = comp_bytes - seg_byte;
-  const uint32_t ip_end = left < 0xF0000000ull ? (uint32_t)left : 0xF0000000u;
+  // (a segment reads at most 1 GiB of input — the symbol loop's bounds tests use sign-bit arithmetic; one that would need more
+  // ends with a data error and the file goes to the host path)
+  const uint32_t ip_end = left < 0x3FFFFFFFull ? (uint32_t)left : 0x3FFFFFFFu;
   const uint64_t stop64 = sg.stop_bit > seg_byte * 8 ? sg.stop_bit - seg_byte * 8 : 0;
   const uint32_t stop_rel = stop64 < 0xF0000000ull ? (uint32_t)stop64 : 0xF0000000u;     // bit position relative to seg_byte
   uint32_t ip = 0;
   uint16_t* const o = syms + sg.sym_off;
   const uint32_t cap_total = kGzWindow + sg.cap;                      // symbols, markers included
-  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)(cap_total * 2u), 0x00020000);
-  const uint32_t not_lane0 = lane == 0 ? 0u : 0xFFFFFFFFu;
-  uint32_t lane_zero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
   // the window this segment does not have: 32768 markers in front of its output
   for (uint32_t k = lane; k < kGzWindow / 2; k += 64)
     reinterpret_cast<uint32_t*>(o)[k] = (0x8000u | (2u * k)) | ((0x8000u | (2u * k + 1u)) << 16);
@@ -314,71 +312,20 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint
     }
     __builtin_amdgcn_wave_barrier();
     if (!__builtin_amdgcn_readfirstlane((int)build_ok[wave])) { err = kGzErrData; break; }
-    // ---- symbols: the loop of bgzf_inflate, 16 bits per output symbol (see there for why it is shaped this way) --------
-    uint32_t* const lit_v = lit + lane_zero;
-    uint32_t* const dist_v = dist + lane_zero;
-    uint32_t done = 0;
-    uint32_t pend_off = 0xFFFFFFFFu;
-    uint16_t pend_v = 0;
-    do {
-      if (bc < 48) SCFQ_GREFILL();
-      uint32_t e = uni(lit_v[bb & ((1u << kLitRoot) - 1)]);
-      if (e & kSub) {
-        SCFQ_GTAKE(kLitRoot);
-        e = uni(lit_v[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 4) & 15)) - 1))]);
-      }
-      SCFQ_GTAKE(e & 15);
-      if (e & kLit) {
-        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(e >> 16), orsrc, (pos * 2u) | not_lane0, 0, 0);
-        ++pos;
-      } else if (e & kVal) {
-        const uint32_t lx = (e >> 4) & 15;
-        const uint32_t mlen = (e >> 16) + ((uint32_t)bb & ((1u << lx) - 1));
-        SCFQ_GTAKE(lx);
-        uint32_t d = uni(dist_v[bb & ((1u << kDistRoot) - 1)]);
-        if (d & kSub) {
-          SCFQ_GTAKE(kDistRoot);
-          d = uni(dist_v[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 4) & 15)) - 1))]);
-        }
-        SCFQ_GTAKE(d & 15);
-        const uint32_t dx = (d >> 4) & 15;
-        const uint32_t off = (d >> 16) + ((uint32_t)bb & ((1u << dx) - 1));
-        SCFQ_GTAKE(dx);
-        if (off == 0u) {                     // the entry of an unassigned distance code (a distance never exceeds 32768 <= pos)
-          err = kGzErrData; done = 1;
-        } else {
-          const uint32_t src0 = pos - off;
-          __builtin_amdgcn_raw_buffer_store_b16(pend_v, orsrc, pend_off, 0, 0);
-          pend_off = 0xFFFFFFFFu;
-          if (mlen <= 64) {
-            if (off >= mlen) {
-              pend_v = __builtin_amdgcn_raw_buffer_load_b16(orsrc, (src0 + lane) * 2u, 0, 1 /*sc0*/);
-              pend_off = lane < mlen ? (pos + lane) * 2u : 0xFFFFFFFFu;
-            } else {
-              const uint32_t j = off == 1 ? 0u : lane % off;
-              const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(orsrc, (src0 + j) * 2u, 0, 1 /*sc0*/);
-              __builtin_amdgcn_raw_buffer_store_b16(v, orsrc, lane < mlen ? (pos + lane) * 2u : 0xFFFFFFFFu, 0, 0);
-            }
-          } else {
-            for (uint32_t base = 0; base < mlen; base += 64) {
-              const uint32_t k = base + lane;
-              const uint32_t j = off >= mlen ? k : (off == 1 ? 0u : k % off);
-              const uint16_t v = __builtin_amdgcn_raw_buffer_load_b16(orsrc, (src0 + j) * 2u, 0, 1 /*sc0*/);
-              __builtin_amdgcn_raw_buffer_store_b16(v, orsrc, k < mlen ? (pos + k) * 2u : 0xFFFFFFFFu, 0, 0);
-            }
-          }
-          pos += mlen;
-        }
-      } else {
-        if (!(e & kEob)) err = kGzErrData;
-        done = 1;
-      }
-      done |= (cap_total - pos) >> 31;       // pos > cap_total: the descriptor dropped the excess
-      done |= ip > ip_end + 16u ? 1u : 0u;   // a malformed stream reading (clamped) bytes far past the end of the data
-    } while (!done);
+    // ---- symbols: symbol_loop of bgzf_inflate_kernel.hpp, 16 bits per output symbol ------------------------------------
+    {
+      SymState sst;
+      sst.bb = bb; sst.bc = bc; sst.ip = ip; sst.pos = pos; sst.err = kOk;
+      sst.pf[0] = pf.x; sst.pf[1] = pf.y; sst.pf[2] = pf.z; sst.pf[3] = pf.w; sst.pf_sh = pf_sh;
+      symbol_loop<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      bb = ((uint64_t)uni((uint32_t)(sst.bb >> 32)) << 32) | uni((uint32_t)sst.bb);
+      bc = uni(sst.bc); ip = uni(sst.ip); pos = uni(sst.pos);
+      const uint32_t e2 = uni(sst.err);
+      pf.x = uni(sst.pf[0]); pf.y = uni(sst.pf[1]); pf.z = uni(sst.pf[2]); pf.w = uni(sst.pf[3]); pf_sh = uni(sst.pf_sh);
+      if (e2) err = kGzErrData;
+    }
     if (pos > cap_total && err == kGzOk) err = kGzErrOverflow;
     if (ip > ip_end + 16 && err == kGzOk) err = kGzErrData;
-    __builtin_amdgcn_raw_buffer_store_b16(pend_v, orsrc, pend_off, 0, 0);
   }
   if (err == kGzOk && (uint64_t)ip * 8 - bc > (uint64_t)ip_end * 8) err = kGzErrData;     // bits taken beyond the data
 #undef SCFQ_GREFILL
@@ -420,16 +367,18 @@ __global__ __launch_bounds__(1024) void gz_window_chain(const GzChain* __restric
   };
   load_meta(k0);
   __syncthreads();
-  // The usual case — a segment of at least 32768 symbols: the new window is its last 32768 symbols, thread t owns 32
-  // consecutive ones (sixteen 4-byte loads in flight at once: the run starts at any symbol).  The loads of segment k + 1 are
-  // issued before segment k is resolved, so the chain pays LDS time per segment, not a memory round trip.
+  // The usual case — a segment of at least 32768 symbols: the new window is its last 32768 symbols.  Thread t owns the symbol
+  // pairs t, t + 1024, ... (sixteen 4-byte loads in flight at once, each wave instruction 256 contiguous bytes: with 32
+  // consecutive symbols per thread every load instruction touched 64 cache lines and the step took 4.8 us instead of ~2).
+  // The loads of segment k + 1 are issued before segment k is resolved, so the chain pays LDS time per segment, not a memory
+  // round trip.
   uint32_t w[16], wn[16];
   auto fetch = [&](uint32_t k, uint32_t* dst) {
     const uint32_t n_k = m_n[(k - k0) & 1023u];
     if (n_k < kGzWindow) return;
-    const uint16_t* src = syms + m_off[(k - k0) & 1023u] + kGzWindow + (n_k - kGzWindow) + tid * 32u;
+    const uint16_t* src = syms + m_off[(k - k0) & 1023u] + kGzWindow + (n_k - kGzWindow);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) __builtin_memcpy(&dst[q], src + 2 * q, 4);
+    for (int q = 0; q < 16; ++q) __builtin_memcpy(&dst[q], src + 2u * (tid + 1024u * q), 4);     // (the run starts at any symbol: 2-byte aligned)
   };
   if (k0 < k1) fetch(k0, w);
   uint32_t cur = 0;
@@ -447,16 +396,14 @@ __global__ __launch_bounds__(1024) void gz_window_chain(const GzChain* __restric
     }
     if (k + 2 < k1) fetch(k + 1, wn);                        // (only resolved when it is not the chain's last segment)
     if (n >= kGzWindow) {
-      uint32_t o8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint16_t* dst = reinterpret_cast<uint16_t*>(W[cur ^ 1]);
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const uint32_t sy = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-        const uint32_t v = (sy & 0x8000u) ? (uint32_t)W[cur][sy & 0x7FFFu] : (sy & 0xFFu);
-        o8[j >> 2] |= v << ((j & 3) * 8);
+      for (int q = 0; q < 16; ++q) {
+        const uint32_t s0 = w[q] & 0xFFFFu, s1 = w[q] >> 16;
+        const uint32_t v0 = (s0 & 0x8000u) ? (uint32_t)W[cur][s0 & 0x7FFFu] : (s0 & 0xFFu);
+        const uint32_t v1 = (s1 & 0x8000u) ? (uint32_t)W[cur][s1 & 0x7FFFu] : (s1 & 0xFFu);
+        dst[tid + 1024u * q] = (uint16_t)(v0 | (v1 << 8));
       }
-      uint32_t* dst = reinterpret_cast<uint32_t*>(W[cur ^ 1]) + tid * 8u;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) dst[q] = o8[q];
     } else {
       const uint16_t* s = syms + sym_off + kGzWindow;        // the segment's output symbols
       for (uint32_t i = tid; i < kGzWindow; i += 1024) {

@@ -697,6 +697,11 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
                          dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
                          c->d_comp[b], c->d_blk[b], nb, base, c->d_dstatus);
       HIPCHK(hipGetLastError());
+      // measurement aid: one line per bgzf_inflate dispatch (members, compressed bytes, inflated bytes), in dispatch order, so
+      // that a rocprofv3 kernel trace of the same run can be priced in GB/s per dispatch (scripts/gpu_profile_inflate.sh)
+      if (const char* lp = std::getenv("SCFQ_BGZF_LAUNCH_LOG")) {
+        if (FILE* lf = std::fopen(lp, "a")) { std::fprintf(lf, "%u\t%llu\t%llu\n", nb, (unsigned long long)used, (unsigned long long)ob); std::fclose(lf); }
+      }
     }
     if (ob) {
       rc = scan_async(c, base, ob, prev_base ? -2 : -1, flags & ~SCFQ_PREV_IN_MEMORY, timing);

@@ -25,6 +25,7 @@ type
     device_ids: ptr int32
     flags, reserved: uint32
     chunk_bytes: uint64
+    wait_stream: pointer        # hipStream_t of the caller, read when SCFQ_WAIT_STREAM is set in flags (unused here)
 
 const
   SCFQ_OK = 0
