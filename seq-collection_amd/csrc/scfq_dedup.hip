@@ -126,53 +126,90 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x;
 }
 
-// The first 64 bytes of a header as eight 64-bit words, bytes past the header zeroed.  All eight loads are issued before
-// any is used (one memory round trip instead of eight dependent ones: these kernels are latency-bound, every thread
-// chases its own header); addresses are clamped to stay inside the input.
-__device__ __forceinline__ void load_head64(const uint8_t* base, uint64_t n, uint64_t s, uint64_t len, uint64_t w[8]) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    uint64_t a = s + 8u * k;
-    uint32_t shift = 0;
-    if (a + 8 > n) { const uint64_t a2 = (n >= 8) ? n - 8 : 0; shift = (uint32_t)(a - a2) * 8; a = a2; }   // last bytes of the input
-    uint64_t v = 0;
-    if (8u * k < len && n >= 8) { __builtin_memcpy(&v, base + a, 8); v = (shift < 64) ? (v >> shift) : 0; }
-    else if (8u * k < len) { for (uint64_t b = 0; b < 8 && a + b < n; ++b) v |= (uint64_t)base[a + b] << (8 * b); }
-    const uint64_t valid = (len > 8u * k) ? len - 8u * k : 0;          // bytes of this word that belong to the header
-    w[k] = (valid >= 8) ? v : (valid ? (v & ((1ull << (8 * valid)) - 1)) : 0);
-  }
+// Word k (bytes [8k, 8k + 8)) of the header that starts at s and is len bytes long, bytes past the header zeroed; addresses are
+// clamped to stay inside the input.
+__device__ __forceinline__ uint64_t load_head_word(const uint8_t* base, uint64_t n, uint64_t s, uint64_t len, uint32_t k) {
+  uint64_t a = s + 8u * k;
+  uint32_t shift = 0;
+  if (a + 8 > n) { const uint64_t a2 = (n >= 8) ? n - 8 : 0; shift = (uint32_t)(a - a2) * 8; a = a2; }   // last bytes of the input
+  uint64_t v = 0;
+  if (8u * k < len && n >= 8) { __builtin_memcpy(&v, base + a, 8); v = (shift < 64) ? (v >> shift) : 0; }
+  else if (8u * k < len) { for (uint64_t b = 0; b < 8 && a + b < n; ++b) v |= (uint64_t)base[a + b] << (8 * b); }
+  const uint64_t valid = (len > 8u * k) ? len - 8u * k : 0;          // bytes of this word that belong to the header
+  return (valid >= 8) ? v : (valid ? (v & ((1ull << (8 * valid)) - 1)) : 0);
 }
 
-// D1: one thread per header line
-__global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
-                                                      uint64_t seed, uint32_t hash_bits, uint64_t* keys, uint32_t* idx, bool has_cr) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_hdr) return;
-  uint64_t s, e;
-  line_span(base, n, line_off, 4 * i, s, e, has_cr);
-  const uint64_t len = e - s;
+// The first 64 bytes of a header as eight 64-bit words.  All eight loads are issued before any is used (one memory round trip
+// instead of eight dependent ones: the compare kernel is latency-bound, every thread chases its own header).
+__device__ __forceinline__ void load_head64(const uint8_t* base, uint64_t n, uint64_t s, uint64_t len, uint64_t w[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = load_head_word(base, n, s, len, (uint32_t)k);
+}
+
+__device__ __forceinline__ uint64_t hash_words(uint64_t seed, uint64_t len, const uint64_t w[8]) {
   uint64_t h = seed ^ (len * 0x9E3779B97F4A7C15ull);
-  uint64_t w[8];
-  load_head64(base, n, s, len, w);
 #pragma unroll
   for (int k = 0; k < 8; ++k) h = mix64(h ^ w[k]) + 0x9E3779B97F4A7C15ull;
+  return h;
+}
+
+// D1: one thread per header line, the first 64 bytes fetched COOPERATIVELY: the headers of a wave are ~360 B apart, so eight
+// loads per thread touched 64 cache lines per instruction (512 line look-ups per wave for ~100 distinct lines).  Instead lane l
+// fetches word l & 7 of header 8 j + (l >> 3) in step j — eight consecutive lanes read 64 consecutive bytes — and the words go
+// through LDS back to the lane that owns the header.  Same hash as a per-thread fetch.
+__global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
+                                                      uint64_t seed, uint32_t hash_bits, uint64_t* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
+  __shared__ uint64_t sh_s[4][64];
+  __shared__ uint32_t sh_len[4][64];
+  __shared__ uint64_t sh_w[4][64][9];                   // (9: the owner's eight 8-byte reads of consecutive lanes spread over the banks)
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t s = 0, e = 0;
+  if (i < n_hdr) line_span(base, n, line_off, 4 * i, s, e, has_cr);
+  const uint64_t len = e - s;
+  sh_s[wv][lane] = s;
+  sh_len[wv][lane] = (uint32_t)(len < 64 ? len : 64);
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t h = 8u * j + (lane >> 3), k = lane & 7u;
+    sh_w[wv][h][k] = load_head_word(base, n, sh_s[wv][h], sh_len[wv][h], k);
+  }
+  __syncthreads();
+  if (i >= n_hdr) return;
+  hdr[i] = s | ((len < 0xFFFFFFull ? len : 0xFFFFFFull) << 40);      // start (40 bits: inputs up to 1 TiB) | length, saturated
+  uint64_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = sh_w[wv][lane][k];
+  uint64_t h = hash_words(seed, len, w);
   for (uint64_t p = s + 64; p < e; p += 8) {         // headers longer than 64 bytes: the rest, 8 bytes per step
     uint64_t v = 0;
     if (p + 8 <= e) __builtin_memcpy(&v, base + p, 8);
     else for (uint64_t b = 0; p + b < e; ++b) v |= (uint64_t)base[p + b] << (8 * b);
     h = mix64(h ^ v) + 0x9E3779B97F4A7C15ull;
   }
-  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // test hook: forces collisions
+  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // (40 by default; the tests force collisions with 4)
   keys[i] = h;
   idx[i] = (uint32_t)i;
 }
 
-__device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t ra, uint64_t rb, bool has_cr) {
-  uint64_t sa, ea, sb, eb;
-  line_span(base, n, line_off, 4 * ra, sa, ea, has_cr);
-  line_span(base, n, line_off, 4 * rb, sb, eb, has_cr);
-  if (ea - sa != eb - sb) return false;
-  const uint64_t len = ea - sa;
+// header i is bytes [start, start + length): (start, length) packed by dd_hash_headers; a saturated length (a 16 MiB header)
+// is looked up again through the line index
+__device__ __forceinline__ void header_span(const uint8_t* base, uint64_t n, const uint64_t* line_off, const uint64_t* hdr, uint64_t r, bool has_cr,
+                                            uint64_t& s, uint64_t& len) {
+  const uint64_t h = hdr[r];
+  s = h & ((1ull << 40) - 1);
+  len = h >> 40;
+  if (len == 0xFFFFFFull) { uint64_t e; line_span(base, n, line_off, 4 * r, s, e, has_cr); len = e - s; }
+}
+
+__device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, const uint64_t* line_off, const uint64_t* hdr, uint64_t ra, uint64_t rb,
+                                            bool has_cr) {
+  uint64_t sa, la, sb, lb;
+  header_span(base, n, line_off, hdr, ra, has_cr, sa, la);
+  header_span(base, n, line_off, hdr, rb, has_cr, sb, lb);
+  if (la != lb) return false;
+  const uint64_t len = la;
   uint64_t wa[8], wb[8];
   load_head64(base, n, sa, len, wa);
   load_head64(base, n, sb, len, wb);
@@ -185,20 +222,81 @@ __device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, con
   return true;
 }
 
-// D3: sorted position p; walk back through the run of equal hashes until an equal header is found (normally the
-// neighbour p-1: either it is the same string, or the run is a genuine collision and is a handful of entries long)
-__global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
-                                                         const uint64_t* keys_sorted, const uint32_t* idx_sorted, uint8_t* dup,
-                                                         unsigned long long* counters /* [0] dups, [1] hash collisions */, bool has_cr) {
+// D3a: the sorted positions whose hash equals their predecessor's (the only records that can be duplicates), compacted:
+// with one record in six a duplicate, most lanes of the compare kernel had nothing to do while the others waited on memory
+__global__ __launch_bounds__(256) void dd_find_equal(const uint64_t* keys_sorted, uint64_t n_hdr, uint32_t* cand, uint32_t* n_cand) {
+  __shared__ uint32_t wave_cnt[4], block_base;
   const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= n_hdr) return;
-  const uint64_t key = keys_sorted[p];
-  const uint32_t me = idx_sorted[p];
+  const bool eq = p > 0 && p < n_hdr && keys_sorted[p] == keys_sorted[p - 1];
+  const uint64_t bal = __builtin_amdgcn_ballot_w64(eq);
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[w] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    block_base = tot ? atomicAdd(n_cand, tot) : 0u;
+  }
+  __syncthreads();
+  if (eq) {
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < w; ++k) before += wave_cnt[k];
+    cand[block_base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1))] = (uint32_t)p;
+  }
+}
+
+// D3b: candidate position p of the sorted order: is an EARLIER record of its equal-hash run the same string?  Normally the
+// neighbour p-1 decides (either it is the same string, or the run is a genuine collision and is a handful of entries long).
+// The first 64 bytes of both headers of every candidate of a wave are fetched cooperatively, as in dd_hash_headers (lane l:
+// word l & 7 of header 8 j + (l >> 3), 16 steps for 128 headers) and compared from LDS; longer headers and longer runs take
+// the per-thread walk.
+__global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, uint64_t n, const uint64_t* line_off, const uint64_t* hdr,
+                                                         const uint64_t* keys_sorted, const uint32_t* idx_sorted, const uint32_t* cand,
+                                                         const uint32_t* n_cand, uint8_t* dup,
+                                                         unsigned long long* counters /* [0] dups, [1] hash collisions */, bool has_cr) {
+  __shared__ uint64_t sh_s[4][128];
+  __shared__ uint32_t sh_len[4][128];
+  __shared__ uint64_t sh_w[4][128][9];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t total = *n_cand;
+  if ((uint64_t)blockIdx.x * 256 >= total) return;            // (block-uniform: the barriers below are reached by all or none)
+  const bool active = t < total;
+  uint64_t p = 0, key = 0;
+  uint32_t me = 0, other = 0;
+  uint64_t sa = 0, la = 0, sb = 0, lb = 0;
+  if (active) {
+    p = cand[t];
+    key = keys_sorted[p];
+    me = idx_sorted[p];
+    other = idx_sorted[p - 1];                                // (a candidate has p >= 1 and keys[p - 1] == keys[p])
+    header_span(base, n, line_off, hdr, me, has_cr, sa, la);
+    header_span(base, n, line_off, hdr, other, has_cr, sb, lb);
+  }
+  sh_s[wv][2 * lane] = sa; sh_len[wv][2 * lane] = (uint32_t)(la < 64 ? la : 64);
+  sh_s[wv][2 * lane + 1] = sb; sh_len[wv][2 * lane + 1] = (uint32_t)(lb < 64 ? lb : 64);
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < 16; ++j) {
+    const uint32_t h = 8u * j + (lane >> 3), k = lane & 7u;
+    sh_w[wv][h][k] = load_head_word(base, n, sh_s[wv][h], sh_len[wv][h], k);
+  }
+  __syncthreads();
+  if (!active) return;
   bool is_dup = false;
   uint32_t collided = 0;
-  for (uint64_t q = p; q > 0 && keys_sorted[q - 1] == key; --q) {
-    if (same_header(base, n, line_off, idx_sorted[q - 1], me, has_cr)) { is_dup = true; break; }
-    ++collided;
+  {
+    uint64_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) diff |= sh_w[wv][2 * lane][k] ^ sh_w[wv][2 * lane + 1][k];
+    bool same = (la == lb) && diff == 0;
+    for (uint64_t k = 64; same && k < la; ++k) same = base[sa + k] == base[sb + k];
+    if (same) is_dup = true; else collided = 1;
+  }
+  if (!is_dup) {                                              // a collision: the rest of the run, one by one
+    for (uint64_t q = p - 1; q > 0 && keys_sorted[q - 1] == key; --q) {
+      if (same_header(base, n, line_off, hdr, idx_sorted[q - 1], me, has_cr)) { is_dup = true; break; }
+      ++collided;
+    }
   }
   if (is_dup) {                       // dup[] was zeroed: only the duplicates pay a scattered byte store
     dup[me] = 1;
@@ -297,7 +395,7 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   // than 24 bytes on average — and only a wrong guess costs a second pass with the exact size
   int rc = SCFQ_OK;
   uint32_t index_flags = 1;
-  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp;
+  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp, hdr, cand;
   {
     uint64_t cap = n / 24 + 1024;
     if ((rc = line_off.alloc(cap * 8, stream))) return rc;
@@ -320,14 +418,17 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   mark("line index (K5, one pass)");
   if ((rc = keys.alloc(n_hdr * 8, stream)) || (rc = keys2.alloc(n_hdr * 8, stream)) || (rc = idx.alloc(n_hdr * 4, stream)) ||
       (rc = idx2.alloc(n_hdr * 4, stream)) || (rc = dup.alloc(n_hdr, stream)) || (rc = out_len.alloc((n_hdr + 1) * 8, stream)) ||
-      (rc = out_off.alloc((n_hdr + 1) * 8, stream)) || (rc = counters.alloc(16, stream)))
+      (rc = out_off.alloc((n_hdr + 1) * 8, stream)) || (rc = counters.alloc(32, stream)) || (rc = hdr.alloc(n_hdr * 8, stream)) ||
+      (rc = cand.alloc(n_hdr * 4, stream)))
     return rc;
   mark("alloc scratch");
-  DCHK(hipMemsetAsync(counters.p, 0, 16, stream));
+  DCHK(hipMemsetAsync(counters.p, 0, 32, stream));
   const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
-  static const uint32_t hash_bits = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); int v = e ? std::atoi(e) : 64; return (uint32_t)std::min(64, std::max(1, v)); }();
+  // 40 bits of hash: the radix sort makes 5 passes over the (key, record) pairs instead of 8, and the exact compare behind the
+  // sort makes collisions (n^2 / 2^41 pairs: ~350 among 28 M records) a matter of time, never of correctness
+  static const uint32_t hash_bits = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); int v = e ? std::atoi(e) : 40; return (uint32_t)std::min(64, std::max(1, v)); }();
   hipLaunchKernelGGL(dd_hash_headers, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
-                     0x5CF0DED0B1A5ull, hash_bits, keys.as<uint64_t>(), idx.as<uint32_t>(), has_cr);
+                     0x5CF0DED0B1A5ull, hash_bits, keys.as<uint64_t>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
   DCHK(hipGetLastError());
   mark("hash headers");
   size_t tmp_bytes = 0;
@@ -341,8 +442,13 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
                                  (size_t)n_hdr, 0u, hash_bits, stream));
   mark("radix sort");
   DCHK(hipMemsetAsync(dup.p, 0, n_hdr, stream));
-  hipLaunchKernelGGL(dd_mark_duplicates, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
-                     keys2.as<uint64_t>(), idx2.as<uint32_t>(), dup.as<uint8_t>(), counters.as<unsigned long long>(), has_cr);
+  uint32_t* n_cand = reinterpret_cast<uint32_t*>(counters.as<unsigned long long>() + 2);
+  hipLaunchKernelGGL(dd_find_equal, dim3(blocks), dim3(256), 0, stream, keys2.as<uint64_t>(), n_hdr, cand.as<uint32_t>(), n_cand);
+  DCHK(hipGetLastError());
+  // (the launch covers the worst case; blocks past the candidate count leave at once)
+  hipLaunchKernelGGL(dd_mark_duplicates, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), hdr.as<uint64_t>(),
+                     keys2.as<uint64_t>(), idx2.as<uint32_t>(), cand.as<uint32_t>(), n_cand, dup.as<uint8_t>(),
+                     counters.as<unsigned long long>(), has_cr);
   DCHK(hipGetLastError());
   mark("mark duplicates");
   hipLaunchKernelGGL(dd_record_lengths, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
