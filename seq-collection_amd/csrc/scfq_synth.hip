@@ -9,7 +9,8 @@
 #include "../../include/sc_fqcount.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>        // (rocprim's texture iterator calls memset from host code)
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -294,16 +295,21 @@ int scfq_synth_device(int kind, uint64_t seed, uint64_t first_record, uint64_t r
   hipLaunchKernelGGL(synth::k_lengths, dim3((unsigned)((records + 255) / 256)), dim3(256), 0, 0, kind, seed,
                      first_record, records, d_len);
   SYN_HIP(hipGetLastError());
-  SYN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_len, d_off, (size_t)records));
+  SYN_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, d_len, d_off, (uint64_t)0, (size_t)records, rocprim::plus<uint64_t>()));
   SYN_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-  SYN_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_len, d_off, (size_t)records));
+  SYN_HIP(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_len, d_off, (uint64_t)0, (size_t)records, rocprim::plus<uint64_t>()));
   SYN_HIP(hipMemcpy(&last_len, d_len + records - 1, sizeof(uint64_t), hipMemcpyDeviceToHost));
   SYN_HIP(hipMemcpy(&last_off, d_off + records - 1, sizeof(uint64_t), hipMemcpyDeviceToHost));
   info->bytes = last_off + last_len;
   if (info->bytes > cap) { rc = SCFQ_EARG; goto done; }
-  hipLaunchKernelGGL(synth::k_write, dim3((unsigned)((records + 3) / 4)), dim3(256), 0, 0, kind, seed, first_record,
-                     records, d_off, static_cast<uint8_t*>(dst_device), d_tally);
-  SYN_HIP(hipGetLastError());
+  // (one wave per record; a launch is limited to 2^32 threads in total — 25 GB of 150 bp reads are 69.5 M waves = 4.4 G threads,
+  // which the runtime wrapped to the low 32 bits without an error — so the records go out in launches of 8 M)
+  for (uint64_t r0 = 0; r0 < records; r0 += (8ull << 20)) {
+    const uint64_t nr = std::min<uint64_t>(8ull << 20, records - r0);
+    hipLaunchKernelGGL(synth::k_write, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, 0, kind, seed, first_record + r0,
+                       nr, d_off + r0, static_cast<uint8_t*>(dst_device), d_tally);
+    SYN_HIP(hipGetLastError());
+  }
   SYN_HIP(hipDeviceSynchronize());
   SYN_HIP(hipMemcpy(tally, d_tally, sizeof tally, hipMemcpyDeviceToHost));
   info->gc_bases = tally[0];

@@ -130,6 +130,15 @@ def test_bench_exchange_path_single_rank_rccl(gpu):
     assert j2["counters"] == j["counters"] and "torch.distributed" in j2["config"]["exchange"]
 
 
+def test_bench_full_size_shard_of_the_scaling_run(gpu):
+    """one rank's share of BASELINE configs[2] — 25 GB, 69.5 M records — generated, scanned and exchanged exactly as in the 8-GPU
+    run (at this size the generator's one-wave-per-record launch once exceeded 2^32 threads and silently wrote 3 % of the shard)"""
+    j = _bench(["--gpus", "1", "--exchange-at-1", "--bytes-per-gpu", "25e9", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], timeout=900)
+    assert j["counters"]["matches_generator_tally"] is True
+    assert j["config"]["bytes_per_gpu"] >= 25_000_000_000 and j["counters"]["reads"] > 69_000_000
+    assert j["roofline"]["frac"] > 0.5
+
+
 def test_bench_two_ranks_launched_like_the_driver(gpu):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (gloo on one device: RCCL cannot put two ranks on
     one GPU): two shards of one record stream cut at an arbitrary byte, exchange, counters == generator tallies"""
