@@ -55,7 +55,10 @@ else:
     how = "zlib level 6, one member, 64 MiB pieces joined by sync flushes (as pigz writes it)"
 sys.stderr.write("%s took %.0f s\n" % (how, time.time() - t0))
 expect = [plan.records, info.gc_bases, info.n_bases, info.bases]
-for mode, env in (("device", {"SCFQ_VERBOSE": "1"}), ("host (parallel single-member reader)", {"SCFQ_GZ_DEVICE": "0"})):
+modes = [("device", {"SCFQ_VERBOSE": "1"}), ("host (parallel single-member reader)", {"SCFQ_GZ_DEVICE": "0"})]
+if os.environ.get("SCFQ_MEASURE_VARIANTS"):      # A/B runs of the device path: JSON list of {"name": ..., "env": {...}}
+    modes = [("device " + v["name"], dict(v["env"], SCFQ_VERBOSE="1")) for v in json.loads(os.environ["SCFQ_MEASURE_VARIANTS"])]
+for mode, env in modes:
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", plain + ".gz"], env=dict(os.environ, **env), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     if os.environ.get("SCFQ_MEASURE_LOG"):
@@ -65,10 +68,10 @@ for mode, env in (("device", {"SCFQ_VERBOSE": "1"}), ("host (parallel single-mem
     best = min(rows, key=lambda j: j["wall_s"])
     assert best.pop("counts") == expect
     best.update({"path": how, "inflate": mode, "gz_bytes": os.path.getsize(plain + ".gz"), "first_call_wall_s": rows[0]["wall_s"]})
-    if mode == "device":
+    if mode.startswith("device"):
         reps = re.split(r"scfq rep \d+\n", r.stderr)
         k = rows.index(min(rows, key=lambda j: j["wall_s"])) + 1
         best["phases_ms"] = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"scfq gzdev: ([a-zA-Z|\- ]+?)\s+([0-9.]+) ms", reps[k])}
-        best["summary"] = [l for l in reps[k].splitlines() if "on the chain" in l or "round" in l]
+        best["summary"] = [l for l in reps[k].splitlines() if "on the chain" in l or "round" in l or "host:" in l]
     print(json.dumps(best), flush=True)
 os.remove(plain); os.remove(plain + ".gz")

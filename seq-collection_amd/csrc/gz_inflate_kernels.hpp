@@ -14,7 +14,8 @@
 //                         not have yet"); back-references copy symbols whether known or not.  Ends at the first block
 //                         boundary at or after the next segment's start, or with the member's final block.
 //   G3 gz_window_chain    the 32 KiB window in front of every segment, sequentially along the chain (one workgroup, two
-//                         windows in LDS): W[k+1] = last 32 KiB of (W[k] ++ symbols of k), markers resolved through W[k].
+//      gz_window_maps     windows in LDS): W[k+1] = last 32 KiB of (W[k] ++ symbols of k), markers resolved through W[k];
+//                         long chains in three short walks over groups of 64 segments (window maps compose).
 //   G4 gz_resolve         every symbol becomes a byte (markers through the segment's window), written at the segment's
 //                         offset of the inflated stream; a marker that points before the member's start is corrupt data.
 //   G5 gz_crc32_tiles     raw CRC-32 (zero init) of 1 MiB tiles of the inflated bytes; the host folds the tiles and checks
@@ -352,15 +353,30 @@ struct GzChain {           // one entry per segment of the validated chain, in s
 
 // windows[k] = the 32 KiB in front of segment k (only its last valid_before bytes mean anything).  One workgroup per
 // member (blockIdx.x = chain id, the entries of a chain are contiguous: [first[c], first[c + 1])).
+// win_init (optional): the window in front of the FIRST chain's first segment (a member that began in an earlier batch);
+// win_final (optional): receives the window behind the LAST chain's last segment (a member that goes on in the next batch);
+// win_each (optional): chain c starts from win_each[c] (the third step of the grouped form below).
+//
+// A chain of thousands of segments is not walked in one go: what a run of segments does to the window is a MAP (byte i of
+// the window behind the run = a literal, or byte j of the window in front of it), maps compose, and composition is
+// associative.  So the host cuts every chain into groups of <= 64 entries and launches
+//   1. gz_window_maps   one workgroup per group: the group's map, from the identity, entry by entry (16-bit symbols in LDS)
+//   2. gz_window_chain  over the MAPS of a chain (a map has the form of a segment of 32768 symbols): the window in front of every group
+//   3. gz_window_chain  one workgroup per group, started from its window (win_each): the window in front of every entry
+// — three short sequential walks (<= 64, n / 64, <= 64 steps) instead of one of n steps.
 __global__ __launch_bounds__(1024) void gz_window_chain(const GzChain* __restrict__ chain, const uint32_t* __restrict__ first, const uint16_t* __restrict__ syms,
-                                                       uint8_t* __restrict__ windows) {
+                                                       uint8_t* __restrict__ windows, const uint8_t* __restrict__ win_init, uint8_t* __restrict__ win_final,
+                                                       const uint8_t* __restrict__ win_each) {
   __shared__ __attribute__((aligned(16))) uint8_t W[2][kGzWindow];
   // the chain entries of the next 1024 segments, so that the loop never waits for a dependent global load: [k & 1023]
   __shared__ uint64_t m_off[1024];
   __shared__ uint32_t m_n[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t k0 = first[blockIdx.x], k1 = first[blockIdx.x + 1];
-  for (uint32_t i = tid; i < kGzWindow / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;
+  const bool carry_out = win_final != nullptr && blockIdx.x + 1 == gridDim.x;
+  const uint8_t* w0 = win_each ? win_each + (uint64_t)blockIdx.x * kGzWindow : ((win_init != nullptr && blockIdx.x == 0) ? win_init : nullptr);
+  for (uint32_t i = tid; i < kGzWindow / 4; i += 1024)
+    reinterpret_cast<uint32_t*>(W[0])[i] = w0 ? reinterpret_cast<const uint32_t*>(w0)[i] : 0u;
   auto load_meta = [&](uint32_t base) {      // entries [base, base + 1024) into slots [0, 1024)
     const uint32_t k = base + tid;
     if (k < k1) { m_off[tid] = chain[k].sym_off; m_n[tid] = chain[k].n_sym; }
@@ -388,13 +404,13 @@ __global__ __launch_bounds__(1024) void gz_window_chain(const GzChain* __restric
     uint8_t* wout = windows + (uint64_t)k * kGzWindow;
     for (uint32_t i = tid; i < kGzWindow / 16; i += 1024)
       reinterpret_cast<uint4*>(wout)[i] = reinterpret_cast<const uint4*>(W[cur])[i];
-    if (k + 1 == k1) break;                                  // nobody needs the window after the chain's last segment
-    if (((k + 1 - k0) & 1023u) == 0) {                       // the next 1024 entries (everyone has read entry k by now)
+    if (k + 1 == k1 && !carry_out) break;                    // nobody needs the window after the chain's last segment
+    if (k + 1 < k1 && ((k + 1 - k0) & 1023u) == 0) {         // the next 1024 entries (everyone has read entry k by now)
       __syncthreads();
       load_meta(k + 1);
       __syncthreads();
     }
-    if (k + 2 < k1) fetch(k + 1, wn);                        // (only resolved when it is not the chain's last segment)
+    if (k + 2 < k1 || (k + 1 < k1 && carry_out)) fetch(k + 1, wn);      // (entry k + 1 is resolved when it is not the last, or the window goes on)
     if (n >= kGzWindow) {
       uint16_t* dst = reinterpret_cast<uint16_t*>(W[cur ^ 1]);
 #pragma unroll
@@ -422,6 +438,80 @@ __global__ __launch_bounds__(1024) void gz_window_chain(const GzChain* __restric
 #pragma unroll
     for (int q = 0; q < 16; ++q) w[q] = wn[q];
   }
+  if (carry_out && k0 < k1) {
+    for (uint32_t i = tid; i < kGzWindow / 16; i += 1024)
+      reinterpret_cast<uint4*>(win_final)[i] = reinterpret_cast<const uint4*>(W[cur])[i];
+  }
+}
+
+// step 1 of the grouped form: maps[(g + 1) * 32768 ..] = the map of group g = entries [gfirst[g], gfirst[g + 1]) (at most 64),
+// as 32768 symbols: a literal, or 0x8000 | j = byte j of the window in front of the group
+__global__ __launch_bounds__(1024) void gz_window_maps(const GzChain* __restrict__ chain, const uint32_t* __restrict__ gfirst, const uint16_t* __restrict__ syms,
+                                                      uint16_t* __restrict__ maps) {
+  __shared__ __attribute__((aligned(16))) uint16_t W[kGzWindow];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t k0 = gfirst[blockIdx.x], k1 = gfirst[blockIdx.x + 1];
+  // the group's entries live in the lanes of every wave (entry j in lane j): no dependent global load inside the loop
+  uint32_t my_n = 0, my_lo = 0, my_hi = 0;
+  if (k0 + lane < k1) { const uint64_t o = chain[k0 + lane].sym_off; my_n = chain[k0 + lane].n_sym; my_lo = (uint32_t)o; my_hi = (uint32_t)(o >> 32); }
+  for (uint32_t q = 0; q < 16; ++q) {
+    const uint32_t i = 2u * (tid + 1024u * q);
+    reinterpret_cast<uint32_t*>(W)[tid + 1024u * q] = (0x8000u | i) | ((0x8000u | (i + 1u)) << 16);
+  }
+  __syncthreads();
+  uint32_t w[16], wn[16], r[16];
+  auto entry = [&](uint32_t j, uint32_t* n, uint64_t* off) {
+    *n = (uint32_t)__shfl((int)my_n, (int)j);
+    *off = (uint64_t)(uint32_t)__shfl((int)my_lo, (int)j) | ((uint64_t)(uint32_t)__shfl((int)my_hi, (int)j) << 32);
+  };
+  auto fetch = [&](uint32_t j, uint32_t* dst) {
+    uint32_t n_k; uint64_t off;
+    entry(j, &n_k, &off);
+    if (n_k < kGzWindow) return;
+    const uint16_t* src = syms + off + kGzWindow + (n_k - kGzWindow);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) __builtin_memcpy(&dst[q], src + 2u * (tid + 1024u * q), 4);
+  };
+  const uint32_t cnt = k1 - k0;
+  if (cnt) fetch(0, w);
+  for (uint32_t j = 0; j < cnt; ++j) {
+    uint32_t n; uint64_t off;
+    entry(j, &n, &off);
+    if (j + 1 < cnt) fetch(j + 1, wn);
+    if (n >= kGzWindow) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const uint32_t s0 = w[q] & 0xFFFFu, s1 = w[q] >> 16;
+        const uint32_t v0 = (s0 & 0x8000u) ? (uint32_t)W[s0 & 0x7FFFu] : (s0 & 0xFFu);
+        const uint32_t v1 = (s1 & 0x8000u) ? (uint32_t)W[s1 & 0x7FFFu] : (s1 & 0xFFu);
+        r[q] = v0 | (v1 << 16);
+      }
+    } else {
+      const uint16_t* sg = syms + off + kGzWindow;           // a short segment: the window slides by n
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        uint32_t v[2];
+        for (uint32_t h = 0; h < 2; ++h) {
+          const uint32_t i = 2u * (tid + 1024u * q) + h;
+          if (i >= kGzWindow - n) {
+            const uint32_t sy = sg[n - kGzWindow + i];
+            v[h] = (sy & 0x8000u) ? (uint32_t)W[sy & 0x7FFFu] : (sy & 0xFFu);
+          } else {
+            v[h] = W[i + n];
+          }
+        }
+        r[q] = v[0] | (v[1] << 16);
+      }
+    }
+    __syncthreads();                                         // everyone has read the old window
+#pragma unroll
+    for (int q = 0; q < 16; ++q) reinterpret_cast<uint32_t*>(W)[tid + 1024u * q] = r[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w[q] = wn[q];
+  }
+  uint16_t* out = maps + (uint64_t)(blockIdx.x + 1) * kGzWindow;
+  for (uint32_t i = tid; i < kGzWindow / 8; i += 1024) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(W)[i];
 }
 
 // ---- G4 ----------------------------------------------------------------------------------------------------------------

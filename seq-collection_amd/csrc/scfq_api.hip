@@ -53,13 +53,25 @@ constexpr uint64_t kDefaultChunk = 64ull << 20;
 constexpr int kStateWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS + scfq::kExtWords;   // partial | hist[4][256] | ext (K3 speculation)
 constexpr int kExtAt = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;
 
+struct GzSlot {            // one batch being decoded: symbols + its segment tables (device and pinned mirror)
+  uint16_t* d_sym = nullptr;  uint64_t sym_cap = 0;
+  uint8_t* d_meta = nullptr;  uint64_t meta_cap = 0;
+  uint8_t* h_meta = nullptr;  uint64_t hmeta_cap = 0;
+};
 struct GzDevBuffers {      // grow-only, kept in the context between calls (a driver allocation of tens of GB costs more than the inflate)
-  uint8_t* d_comp = nullptr;  uint64_t comp_cap = 0;
-  uint16_t* d_sym = nullptr;  uint64_t sym_cap = 0;      // symbols
-  uint8_t* d_out = nullptr;   uint64_t out_cap = 0;
-  uint8_t* d_win = nullptr;   uint64_t win_cap = 0;
-  uint8_t* d_meta = nullptr;  uint64_t meta_cap = 0;     // segment tables, results, chain, work lists, tile CRCs
-  uint8_t* h_meta = nullptr;  uint64_t hmeta_cap = 0;    // pinned mirror
+  uint8_t* d_comp[3] = {nullptr, nullptr, nullptr};  uint64_t comp_cap[3] = {0, 0, 0};      // compressed bytes of three batches in flight
+  GzSlot slot[2];
+  uint8_t* d_pmeta[2] = {nullptr, nullptr};  uint64_t pmeta_cap[2] = {0, 0};                // chain, work lists, gap searches of a batch
+  uint8_t* h_pmeta[2] = {nullptr, nullptr};  uint64_t hpmeta_cap[2] = {0, 0};
+  uint8_t* d_out = nullptr;   uint64_t out_cap = 0;      // inflated bytes of one batch
+  uint8_t* d_win = nullptr;   uint64_t win_cap = 0;      // the window in front of every chain entry of one batch
+  uint8_t* d_wcarry = nullptr; uint64_t wcarry_cap = 0;  // the window that crosses a batch border (two, alternating)
+  uint8_t* d_maps = nullptr;  uint64_t maps_cap = 0;     // window maps of the chain groups of one batch (16-bit symbols)
+  uint8_t* d_gwin = nullptr;  uint64_t gwin_cap = 0;     // the window in front of every group
+  uint8_t* d_crc = nullptr;   uint64_t crc_cap = 0;      // status words, then the tile CRCs of the whole file
+  uint8_t* h_crc = nullptr;   uint64_t hcrc_cap = 0;
+  hipStream_t s_search = nullptr, s_decode[2] = {nullptr, nullptr};
+  hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
 };
 
 struct Ctx {

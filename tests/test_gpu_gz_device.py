@@ -17,6 +17,11 @@ pytestmark = pytest.mark.gpu
 
 SC = os.path.join(PKG, "sc")
 DEV_ENV = {"SCFQ_GZ_DEVICE_MIN_MB": "0", "SCFQ_GZ_DEVICE_SEGMENT_KB": "32", "SCFQ_VERBOSE": "1"}
+# the same with 8 segments per batch: a few MB cross a dozen batch borders (window, look-behind byte, CRC parts and the
+# chain position are carried from batch to batch; three batches are in flight at once), window chains in groups of 3 entries
+BATCH_ENV = dict(DEV_ENV, SCFQ_GZ_DEVICE_BATCH_SEGMENTS="8", SCFQ_GZ_DEVICE_CHAIN_GROUP="3")
+# one batch, its chain of ~50-200 entries walked in groups of 5 (maps, group windows, entry windows)
+GROUP_ENV = dict(DEV_ENV, SCFQ_GZ_DEVICE_CHAIN_GROUP="5")
 
 
 def run(path, **env):
@@ -29,11 +34,15 @@ def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
 
 
 def check(oracle, path, data, expect_device=True):
-    r = run(path, **DEV_ENV)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stdout == oracle.tsv(oracle.count(np.frombuffer(data, dtype=np.uint8))) + "\n", r.stderr[-2000:]
-    on_device = "on the chain" in r.stderr
-    assert on_device == expect_device, r.stderr[-3000:]
+    want = oracle.tsv(oracle.count(np.frombuffer(data, dtype=np.uint8))) + "\n"
+    for env in (BATCH_ENV, GROUP_ENV, DEV_ENV):
+        r = run(path, **env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout == want, r.stderr[-2000:]
+        on_device = "on the chain" in r.stderr
+        assert on_device == expect_device, r.stderr[-3000:]
+        if on_device and env is BATCH_ENV and len(data) > 2_000_000:
+            assert " 1 batch(es)" not in r.stderr and "batch(es)" in r.stderr, r.stderr[-1000:]
     return r
 
 
@@ -108,11 +117,12 @@ def test_damaged_files_behave_as_on_the_host_path(gpu, oracle, tmp_path):
     for name, raw in cases.items():
         f = tmp_path / (name + ".fq.gz")
         f.write_bytes(raw)
-        dev = run(f, **DEV_ENV)
         host = run(f, SCFQ_GZ_DEVICE="0")
-        assert (dev.returncode, dev.stdout) == (host.returncode, host.stdout), (name, dev.stderr[-1500:], host.stderr[-500:])
         strip = lambda s: "\n".join(l for l in s.splitlines() if not l.startswith("scfq"))     # noqa: E731
-        assert strip(dev.stderr) == strip(host.stderr), name
+        for env in (DEV_ENV, BATCH_ENV, GROUP_ENV):
+            dev = run(f, **env)
+            assert (dev.returncode, dev.stdout) == (host.returncode, host.stdout), (name, dev.stderr[-1500:], host.stderr[-500:])
+            assert strip(dev.stderr) == strip(host.stderr), name
         try:
             zlib_ok = gzip.decompress(raw) is not None
         except Exception:      # noqa: BLE001
