@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace scfq_dinflate {
 
@@ -326,8 +327,271 @@ __device__ __attribute__((noinline)) void symbol_loop(SymState* stp, const uint8
   stp->pf[0] = pf.x; stp->pf[1] = pf.y; stp->pf[2] = pf.z; stp->pf[3] = pf.w; stp->pf_sh = pf_sh;
 }
 
+// ---- the symbol loop, lane-parallel form ---------------------------------------------------------------------------------
+// The serial loop above spends a wave's time in chains of dependent round trips — per symbol the LDS look-ups, per match (70 % of
+// the symbols) a load of bytes this wave has just stored, which the L1 does not hold (stores write through and do not allocate):
+// a round trip to the L2 with the wave waiting — and 63 lanes idle.  Here the lanes do the work, in ROUNDS over the next 64
+// bits of the stream:
+//  1. decode: lane i assumes that a symbol starts at bit i and decodes it completely — literal/length code, extra bits, distance
+//     code, extra bits: four LDS gathers and ~50 vector instructions for all 64 positions at once;
+//  2. walk: the scalar unit only FOLLOWS the chain of real symbols (0 -> next[0] -> next[next[0]] ..., two v_readlane per symbol,
+//     4-5 symbols per round for level-6 FASTQ), noting each symbol at the lane of its first OUTPUT byte;
+//  3. emit: lane t is output byte t of the round.  It finds its symbol (highest noted start at or below t), and is a literal
+//     or byte t - start of a match, whose source is simply `distance` bytes back: ONE load and ONE store instruction for the whole
+//     round.  The store waits for the load only at the NEXT round's emit, after that round's decode and walk, so the L2 round
+//     trip is hidden once per round instead of paid once per match.
+// A round whose matches read bytes the round itself produces (distance < start + length, e.g. runs), or that puts out more than
+// 64 bytes, takes the slow path: the matches one after the other, as the serial loop does.
+// A lane off the chain decodes garbage, harmlessly: every table entry is either a valid one or 0 (unassigned), so indices stay
+// inside the tables and no lane consumes more than 48 bits.  The next round's window is requested from the scalar cache as soon
+// as the chain has been followed.
+#ifdef SCFQ_LPROF      // measurement builds only (scripts/gpu_lanes_prof.sh): where a round's cycles go, summed over all waves
+__device__ unsigned long long g_lprof[16];
+#define SCFQ_LP_T(var_) const uint64_t var_ = __builtin_readcyclecounter()
+#define SCFQ_LP_ADD(slot_, v_) lp[slot_] += (v_)
+#else
+#define SCFQ_LP_T(var_) do {} while (0)
+#define SCFQ_LP_ADD(slot_, v_) do {} while (0)
+#endif
+typedef uint32_t dword8_t __attribute__((ext_vector_type(8)));
+typedef const dword8_t __attribute__((address_space(4), aligned(4))) const_dword8_t;
+typedef const uint32_t __attribute__((address_space(4), aligned(4))) const_dword1_t;
+
+// inclusive prefix sum over the 64 lanes (row_shr 1, 2, 4, 8, then row_bcast 15 and 31)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t ddpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dscan(uint32_t v) {
+  v = ddpp_add<0x111, 0xf>(v);
+  v = ddpp_add<0x112, 0xf>(v);
+  v = ddpp_add<0x114, 0xf>(v);
+  v = ddpp_add<0x118, 0xf>(v);
+  v = ddpp_add<0x142, 0xa>(v);
+  v = ddpp_add<0x143, 0xc>(v);
+  return v;
+}
+
+template <bool SYM16>
+__device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const uint8_t* in_aligned, uint32_t in_off, uint32_t ip_end, void* out_base,
+                                                           uint32_t limit, uint32_t lit_lds, uint32_t dist_lds,
+                                                           uint32_t scratch_lds /* 64 dwords of the wave's own LDS (the table builder's work area is free here) */) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t in_u = ((uint64_t)uni((uint32_t)((uintptr_t)in_aligned >> 32)) << 32) | uni((uint32_t)(uintptr_t)in_aligned);
+  const uint64_t out_u = ((uint64_t)uni((uint32_t)((uintptr_t)out_base >> 32)) << 32) | uni((uint32_t)(uintptr_t)out_base);
+  const_byte_t* const in4 = (const_byte_t*)in_u;
+  out_base = (void*)out_u;
+  in_off = uni(in_off);
+  ip_end = uni(ip_end);
+  limit = uni(limit);
+  uint32_t pos = uni(stp->pos), err = kOk;
+  uint64_t bit = (uint64_t)uni(stp->ip) * 8u - uni(stp->bc);          // the exact position in the stream, in bits from in_aligned + in_off
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_base, 0, (int)(limit * (SYM16 ? 2u : 1u)), 0x00020000);
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  lds_u32* const litp = (lds_u32*)(uintptr_t)uni(lit_lds);
+  lds_u32* const distp = (lds_u32*)(uintptr_t)uni(dist_lds);
+  // (volatile: the lanes talk to each other through these words — to the compiler a lane that has just stored 0 and did not store
+  // anything else itself would still read 0)
+  volatile lds_u32* const scr = (volatile lds_u32*)(uintptr_t)uni(scratch_lds);
+  auto store_sym = [&](uint32_t v, uint32_t off) {
+    if (SYM16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, orsrc, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, orsrc, off, 0, 0);
+  };
+  auto load_sym = [&](uint32_t off) -> uint32_t {
+    if (SYM16) return __builtin_amdgcn_raw_buffer_load_b16(orsrc, off, 0, 1 /*sc0*/);
+    return __builtin_amdgcn_raw_buffer_load_b8(orsrc, off, 0, 1 /*sc0*/);
+  };
+  auto store_raw = [&](auto v, uint32_t off) {           // (no widening on the way: see pend_ld)
+    if constexpr (SYM16) __builtin_amdgcn_raw_buffer_store_b16(v, orsrc, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, off, 0, 0);
+  };
+  auto load_raw = [&](uint32_t off) {
+    if constexpr (SYM16) return __builtin_amdgcn_raw_buffer_load_b16(orsrc, off, 0, 1 /*sc0*/);
+    else return __builtin_amdgcn_raw_buffer_load_b8(orsrc, off, 0, 1 /*sc0*/);
+  };
+  constexpr uint32_t kSh = SYM16 ? 1u : 0u;
+  constexpr uint32_t kOob = 0xFFFFFFFFu;               // an offset the buffer descriptor drops
+  const uint32_t sft = lane & 31u;
+  const bool upper = lane >= 32u;
+  // bits 0 .. lane of a 64-bit mask
+  const uint32_t le_lo = lane >= 31u ? 0xFFFFFFFFu : (2u << lane) - 1u;
+  const uint32_t le_hi = lane < 32u ? 0u : (lane == 63u ? 0xFFFFFFFFu : (2u << (lane - 32u)) - 1u);
+  // eight dwords from the (clamped) byte the position lies in: five of them hold the 128 bits of a round
+#define SCFQ_WBYTE(bit_) (((uint32_t)((bit_) >> 3)) < ip_end ? (uint32_t)((bit_) >> 3) : ip_end)
+  // (x4 + x1, not x8: the three dwords of an x8 nobody reads are registers the compiler re-uses at once, and re-using the target of a
+  // load in flight means waiting for the load right where it was issued)
+#define SCFQ_WLOAD(bit_)                                                           \
+  do {                                                                             \
+    const uint32_t a_ = (in_off + SCFQ_WBYTE(bit_)) & ~3u;                         \
+    D = *(const_dword4_t*)(in4 + a_);                                              \
+    D4 = *(const_dword1_t*)(in4 + a_ + 16u);                                       \
+  } while (0)
+  dword4_t D;
+  uint32_t D4;
+  SCFQ_WLOAD(bit);
+  uint32_t done = 0;
+  // the previous round's output: loaded symbol | 0x100 + literal, offset.  (The loaded symbol keeps the load's own type until it is
+  // stored: widened to 32 bits it would be masked — and so waited for — at the bottom of the round that loaded it.)
+  typedef typename std::conditional<SYM16, uint16_t, uint8_t>::type sym_t;
+  sym_t pend_ld = 0;
+  uint32_t pend_sel = 0, pend_off = kOob;
+#ifdef SCFQ_LPROF
+  uint64_t lp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  do {
+    SCFQ_LP_T(t0);
+    const uint32_t sh = (((in_off + SCFQ_WBYTE(bit)) & 3u) << 3) | ((uint32_t)bit & 7u);
+    const uint32_t W0 = (uint32_t)((((uint64_t)D.y << 32) | D.x) >> sh), W1 = (uint32_t)((((uint64_t)D.z << 32) | D.y) >> sh),
+                   W2 = (uint32_t)((((uint64_t)D.w << 32) | D.z) >> sh), W3 = (uint32_t)((((uint64_t)D4 << 32) | D.w) >> sh);
+#ifdef SCFQ_LPROF
+    asm volatile("" : : "s"(W0), "s"(W1), "s"(W2), "s"(W3));
+#endif
+    SCFQ_LP_T(t1);
+    // ---- 1. every lane: the symbol that would start at bit `lane` ---------------------------------------------------------------
+    const uint32_t wa = upper ? W1 : W0, wb = upper ? W2 : W1, wc = upper ? W3 : W2;
+    const uint32_t x0 = __builtin_amdgcn_alignbit(wb, wa, sft), x1 = __builtin_amdgcn_alignbit(wc, wb, sft);      // 64 bits from bit `lane` on
+    const uint32_t e1 = litp[x0 & ((1u << kLitRoot) - 1u)];
+    const bool sub = (e1 & kSub) != 0u;
+    const uint32_t i2 = sub ? (e1 >> 16) + __builtin_amdgcn_ubfe(x0, kLitRoot, (e1 >> 4) & 15u) : 0u;
+    const uint32_t e2 = litp[i2];
+    const uint32_t ef = sub ? e2 : e1;
+    const uint32_t n1 = sub ? (uint32_t)kLitRoot + (e2 & 15u) : (e1 & 15u);                                        // <= 15
+    const uint32_t y0 = __builtin_amdgcn_alignbit(x1, x0, n1), y1 = x1 >> n1;
+    const uint32_t lx = (ef >> 4) & 15u;                                                                           // <= 5 for a length code
+    const uint32_t mlen = (ef >> 16) + __builtin_amdgcn_ubfe(y0, 0, lx);
+    const uint32_t z0 = __builtin_amdgcn_alignbit(y1, y0, lx);
+    const uint32_t d1 = distp[z0 & ((1u << kDistRoot) - 1u)];
+    const bool dsub = (d1 & kSub) != 0u;
+    const uint32_t j2 = dsub ? (d1 >> 16) + __builtin_amdgcn_ubfe(z0, kDistRoot, (d1 >> 4) & 15u) : 0u;
+    const uint32_t d2 = distp[j2];
+    const uint32_t df = dsub ? d2 : d1;
+    const uint32_t dn = dsub ? (uint32_t)kDistRoot + (d2 & 15u) : (d1 & 15u);                                      // <= 15
+    const uint32_t dx = (df >> 4) & 15u;                                                                           // <= 13
+    const uint32_t moff = (df >> 16) + __builtin_amdgcn_ubfe(z0 >> dn, 0, dx);
+    // 0 literal, 1 match, 2 end of block, 3 a code that is not assigned (the distance of an unassigned code is 0: caught in the walk)
+    const uint32_t kind = (ef & kLit) ? 0u : ((ef & kVal) ? 1u : ((ef & kEob) ? 2u : 3u));
+    const uint32_t tot = kind == 1u ? n1 + lx + dn + dx : n1;                                                      // <= 48
+    const uint32_t A = (lane + tot) | (kind << 7) | ((kind == 0u ? ((ef >> 16) & 0xFFu) : mlen) << 9);
+    const uint32_t B = (df & kVal) ? moff : 0u;
+#ifdef SCFQ_LPROF
+    asm volatile("" : : "v"(A), "v"(B));
+#endif
+    SCFQ_LP_T(t2);
+    // ---- 2. the chain of real symbols: lane 0, then wherever each one ends.  The scalar unit ONLY follows it (it is what every
+    // wave of the CU shares: with positions, checks and bookkeeping in this loop it was 55 instructions per symbol and two thirds of
+    // the round's time); everything else about the symbols is vector work on the chain's lane mask, below.
+    uint32_t cur = 0, a;
+    uint64_t chain = 0;
+    for (;;) {
+      a = (uint32_t)__builtin_amdgcn_readlane((int)A, (int)cur);
+      if (a & 0x100u) break;                           // an end-of-block code or one that is not assigned: where the chain ends
+      chain |= 1ull << cur;
+      cur = a & 127u;
+      if (cur >= 64u) break;
+    }
+    const bool stopped = (a & 0x100u) != 0u;           // (then `cur` is the lane of that code and a & 127 the bit behind it)
+#ifdef SCFQ_LPROF
+    asm volatile("" : : "s"(chain), "s"(cur));
+#endif
+    SCFQ_LP_T(t3);
+    // ---- 3. where every symbol's output goes: a wave scan over the chain lanes ----------------------------------------------------
+    const bool on = ((chain >> lane) & 1ull) != 0ull;
+    const uint32_t len = on ? (kind ? A >> 9 : 1u) : 0u;
+    const uint32_t incl = dscan(len);
+    const uint32_t st = incl - len;                    // output offset inside the round
+    // A round ends in front of a symbol it cannot take in one go: a match that reads output of this very round (not in memory when the
+    // round's one load is issued), that reaches back further than there is output (or whose distance code is not assigned), or
+    // output beyond the round's 64 lanes.  The symbol starts the next round; if it IS the first, it is done alone, the serial way.
+    const bool cut_here = on && ((kind == 1u && (st + len > B || B - 1u >= pos + st)) || st + len > 64u);
+    const uint64_t cuts = __builtin_amdgcn_ballot_w64(cut_here);
+    uint32_t R, adv, stop = 0, alone = 0, c = 64u;
+    if (cuts == 0ull) {
+      R = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      adv = stopped ? (a & 127u) : cur;
+      if (stopped) { stop = 1; if (((a >> 7) & 3u) == 3u) err = kErrData; }
+    } else {
+      c = (uint32_t)__builtin_ctzll(cuts);
+      R = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)c);
+      adv = c;
+      alone = c == 0u ? 1u : 0u;
+    }
+    // ---- 4. output ------------------------------------------------------------------------------------------------------------
+    store_raw((pend_sel & 0x100u) ? (sym_t)(pend_sel & 0xFFu) : pend_ld, pend_off);         // the round before: its load has had this round's decode and walk to arrive
+#ifdef SCFQ_LPROF
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#endif
+    SCFQ_LP_T(t4);
+    {
+      // every lane is one output byte of the round: its symbol is the one noted at the highest start at or below it
+      scr[lane] = 0u;
+      __builtin_amdgcn_wave_barrier();
+      if (on && lane < c) scr[st] = 0x08000000u | ((A >> 7) & 0x7FFu) | (B << 11);          // kind, literal / length, distance
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t starts = __builtin_amdgcn_ballot_w64(scr[lane] != 0u);
+      const uint32_t m_lo = (uint32_t)starts & le_lo, m_hi = (uint32_t)(starts >> 32) & le_hi;
+      const uint32_t s = m_hi ? 63u - (uint32_t)__builtin_clz(m_hi) : 31u - (uint32_t)__builtin_clz(m_lo | 1u);
+      const uint32_t sv = scr[s];
+      const bool act = lane < R;
+      const bool is_match = (sv & 3u) == 1u;
+      pend_ld = load_raw((act && is_match) ? (pos + lane - ((sv >> 11) & 0xFFFFu)) << kSh : kOob);     // a match byte is `distance` symbols back
+      pend_sel = is_match ? 0u : 0x100u | ((sv >> 2) & 0xFFu);
+      pend_off = act ? (pos + lane) << kSh : kOob;
+    }
+    pos += R;
+    if (alone) {
+      // the round's first symbol is a match the lanes cannot do at once (it overlaps its own output, or is longer than 64): the serial way
+      const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)A, 0);
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)B, 0);
+      const uint32_t mlen_s = a0 >> 9;
+      if (off - 1u >= pos) {                           // further back than there is output, or the distance code is not assigned
+        err = kErrData; stop = 1;
+      } else {
+        const uint32_t src0 = pos - off;
+        for (uint32_t base = 0; base < mlen_s; base += 64) {
+          const uint32_t k = base + lane;
+          const uint32_t j = off >= mlen_s ? k : (off == 1 ? 0u : k % off);    // (overlapping its own output: period `off`)
+          const uint32_t v = load_sym((src0 + j) << kSh);
+          store_sym(v, k < mlen_s ? (pos + k) << kSh : kOob);
+        }
+        pos += mlen_s;
+        adv = a0 & 127u;
+      }
+    }
+    bit += adv;                                        // (an end-of-block code's bits included)
+    SCFQ_WLOAD(bit);
+    done = stop;
+    done |= (limit - pos) >> 31;                       // pos > limit: the descriptor dropped the excess
+    done |= (ip_end + 16u - (uint32_t)(bit >> 3)) >> 31;       // a malformed stream reading (clamped) bytes far past the end of the data
+#ifdef SCFQ_LPROF
+    { SCFQ_LP_T(t5);
+      SCFQ_LP_ADD(0, t1 - t0); SCFQ_LP_ADD(1, t2 - t1); SCFQ_LP_ADD(2, t3 - t2); SCFQ_LP_ADD(3, t4 - t3); SCFQ_LP_ADD(4, t5 - t4);
+      SCFQ_LP_ADD(5, 1); SCFQ_LP_ADD(6, (uint64_t)__builtin_popcountll(c < 64u ? chain & ((1ull << c) - 1ull) : chain) + alone); SCFQ_LP_ADD(7, alone); }
+#endif
+  } while (!done);
+#ifdef SCFQ_LPROF
+  if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&g_lprof[q], (unsigned long long)lp[q]);
+#endif
+  store_raw((pend_sel & 0x100u) ? (sym_t)(pend_sel & 0xFFu) : pend_ld, pend_off);
+  // back to the byte-wise reader of the caller: whole bytes consumed, the rest of the last one in the bit buffer, and its prefetch
+  const uint32_t ipn = (uint32_t)((bit + 7u) >> 3);
+  const uint32_t bcn = (uint32_t)((uint64_t)ipn * 8u - bit);
+  uint32_t bbn = 0;
+  if (bcn) {
+    const uint32_t a_ = in_off + (ipn - 1u < ip_end ? ipn - 1u : ip_end);
+    const uint32_t dw = *(const_dword1_t*)(in4 + (a_ & ~3u));
+    bbn = ((dw >> ((a_ & 3u) << 3)) & 0xFFu) >> (8u - bcn);
+  }
+  const uint32_t a2 = in_off + (ipn < ip_end ? ipn : ip_end);
+  const dword4_t pf = *(const_dword4_t*)(in4 + (a2 & ~3u));
+#undef SCFQ_WLOAD
+#undef SCFQ_WBYTE
+  stp->bb = bbn; stp->bc = bcn; stp->ip = ipn; stp->pos = pos; stp->err = err;
+  stp->pf[0] = pf.x; stp->pf[1] = pf.y; stp->pf[2] = pf.z; stp->pf[3] = pf.w; stp->pf_sh = (a2 & 3u) << 3;
+}
+
 __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks,
-                                                                uint32_t n_blocks, uint8_t* out, uint32_t* status /* one word, OR of (1 << error) */) {
+                                                                uint32_t n_blocks, uint8_t* out, uint32_t* status /* one word, OR of (1 << error) */,
+                                                                uint32_t serial_loop /* 1: the serial symbol loop (A/B measurements) */) {
   extern __shared__ uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -482,7 +746,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       SymState sst;
       sst.bb = bb; sst.bc = bc; sst.ip = ip; sst.pos = pos; sst.err = kOk;
       sst.pf[0] = pf.x; sst.pf[1] = pf.y; sst.pf[2] = pf.z; sst.pf[3] = pf.w; sst.pf_sh = pf_sh;
-      symbol_loop<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      if (serial_loop) symbol_loop<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      else symbol_loop_lanes<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist, (uint32_t)(uintptr_t)lens);
       // (every lane holds the same state in its private copy: read it back as wave-uniform values)
       bb = ((uint64_t)uni((uint32_t)(sst.bb >> 32)) << 32) | uni((uint32_t)sst.bb);
       bc = uni(sst.bc); ip = uni(sst.ip); pos = uni(sst.pos);

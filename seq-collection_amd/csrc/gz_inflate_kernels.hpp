@@ -172,7 +172,7 @@ struct GzSegOut {
 enum : uint32_t { kGzOk = 0, kGzMemberEnd = 1, kGzErrData = 2, kGzErrOverflow = 3 };
 
 __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint8_t* __restrict__ comp, uint64_t comp_bytes, const GzSeg* __restrict__ segs,
-                                                                     uint32_t n_seg, uint16_t* syms, GzSegOut* __restrict__ outs) {
+                                                                     uint32_t n_seg, uint16_t* syms, GzSegOut* __restrict__ outs, uint32_t serial_loop) {
   extern __shared__ uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -318,7 +318,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint
       SymState sst;
       sst.bb = bb; sst.bc = bc; sst.ip = ip; sst.pos = pos; sst.err = kOk;
       sst.pf[0] = pf.x; sst.pf[1] = pf.y; sst.pf[2] = pf.z; sst.pf[3] = pf.w; sst.pf_sh = pf_sh;
-      symbol_loop<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      if (serial_loop) symbol_loop<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      else symbol_loop_lanes<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist, (uint32_t)(uintptr_t)lens);
       bb = ((uint64_t)uni((uint32_t)(sst.bb >> 32)) << 32) | uni((uint32_t)sst.bb);
       bc = uni(sst.bc); ip = uni(sst.ip); pos = uni(sst.pos);
       const uint32_t e2 = uni(sst.err);

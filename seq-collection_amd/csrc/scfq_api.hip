@@ -569,6 +569,11 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
 
 // ---- BGZF with device-side inflate: the host only walks the member headers and moves COMPRESSED bytes ---------------
 constexpr uint32_t kMaxBlocksPerChunk = 1u << 18;
+// SCFQ_INFLATE_LOOP=serial: the device inflate kernels use the serial symbol loop (A/B measurements); default: the lane-parallel one
+inline uint32_t inflate_serial_loop() {
+  static const uint32_t v = [] { const char* e = std::getenv("SCFQ_INFLATE_LOOP"); return (e && e[0] == 's') ? 1u : 0u; }();
+  return v;
+}
 constexpr int kFallbackToHost = 1;        // ingest_bgzf_device: could not set up, nothing queued
 constexpr int kNotPureBgzf = 2;           // ingest_bgzf_device: the file holds something other than BGZF members <= 64 KiB (found on the
                                           // way: the header walk runs chunk by chunk under the device's work); queue drained, session to restart
@@ -707,7 +712,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
     if (nb) {
       hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
                          dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
-                         c->d_comp[b], c->d_blk[b], nb, base, c->d_dstatus);
+                         c->d_comp[b], c->d_blk[b], nb, base, c->d_dstatus, inflate_serial_loop());
       HIPCHK(hipGetLastError());
       // measurement aid: one line per bgzf_inflate dispatch (members, compressed bytes, inflated bytes), in dispatch order, so
       // that a rocprofv3 kernel trace of the same run can be priced in GB/s per dispatch (scripts/gpu_profile_inflate.sh)
@@ -1211,7 +1216,7 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
               if (nb) {
                 hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
                                    dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes,
-                                   c->compute, c->d_comp[b], c->d_blk[b], nb, d_buf + off, c->d_dstatus);
+                                   c->compute, c->d_comp[b], c->d_blk[b], nb, d_buf + off, c->d_dstatus, inflate_serial_loop());
                 HIPCHK(hipGetLastError());
               }
               HIPCHK(hipEventRecord(c->ev_scanned[b], c->compute));
@@ -1369,7 +1374,7 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
     HIPCHK(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->compute));
     hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
                        dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
-                       d_comp, d_blocks, nb, d_out, d_status);
+                       d_comp, d_blocks, nb, d_out, d_status, inflate_serial_loop());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(out) + total, d_out, (size_t)ob, hipMemcpyDeviceToHost, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
@@ -1378,6 +1383,13 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
   }
   uint32_t st = 0;
   HIPCHK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
+#ifdef SCFQ_LPROF
+  { unsigned long long w[16]; HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(scfq_dinflate::g_lprof), sizeof w));
+    const double r = (double)std::max<unsigned long long>(1, w[5]);
+    std::fprintf(stderr, "lprof: rounds %llu symbols/round %.2f slow rounds %.3f | cycles per round: window wait %.0f decode %.0f walk %.0f pending store (load wait) %.0f emit %.0f\n", w[5],
+                 w[6] / r, w[7] / r, w[0] / r, w[1] / r, w[2] / r, w[3] / r, w[4] / r);
+    unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(scfq_dinflate::g_lprof), z, sizeof z)); }
+#endif
 #ifdef SCFQ_DSTATS
   { uint32_t w[8]; HIPCHK(hipMemcpy(w, d_status, 32, hipMemcpyDeviceToHost));
     std::fprintf(stderr, "dstats: deflate blocks %u literals %u matches %u match bytes %llu overlapping %u longer than 64: %u\n", w[1], w[2], w[3], (unsigned long long)w[4] << 4, w[5], w[6]); }

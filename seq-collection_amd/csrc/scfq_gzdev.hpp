@@ -321,7 +321,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
       HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs, h_segs, sizeof(GzSeg) * n_seg, hipMemcpyHostToDevice, sd));
       hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, sd,
                          vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs), n_seg, sl.d_sym,
-                         reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs));
+                         reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs), inflate_serial_loop());
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(sl.h_meta + off_outs, sl.d_meta + off_outs, sizeof(GzSegOut) * n_seg, hipMemcpyDeviceToHost, sd));
       span_end(sp_decode, sd);
@@ -465,7 +465,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
       HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs + sizeof(GzSeg) * first, h_segs + first, sizeof(GzSeg) * (n_seg - first), hipMemcpyHostToDevice, c->compute));
       hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg - first + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, c->compute,
                          vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs) + first, n_seg - first, sl.d_sym,
-                         reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs) + first);
+                         reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs) + first, inflate_serial_loop());
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(h_outs + first, sl.d_meta + off_outs + sizeof(GzSegOut) * first, sizeof(GzSegOut) * (n_seg - first), hipMemcpyDeviceToHost, c->compute));
       HIPCHK(hipStreamSynchronize(c->compute));
