@@ -480,15 +480,24 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
     // ---- 2. the chain of real symbols: lane 0, then wherever each one ends.  The scalar unit ONLY follows it (it is what every
     // wave of the CU shares: with positions, checks and bookkeeping in this loop it was 55 instructions per symbol and two thirds of
     // the round's time); everything else about the symbols is vector work on the chain's lane mask, below.
-    uint32_t cur = 0, a;
-    uint64_t chain = 0;
-    for (;;) {
-      a = (uint32_t)__builtin_amdgcn_readlane((int)A, (int)cur);
-      if (a & 0x100u) break;                           // an end-of-block code or one that is not assigned: where the chain ends
-      chain |= 1ull << cur;
-      cur = a & 127u;
-      if (cur >= 64u) break;
-    }
+    // (by hand: seven scalar instructions per symbol; the compiler's form of the same loop had twelve)
+    uint32_t cur, a;
+    uint64_t chain;
+    asm volatile(
+        "s_mov_b32 %[cur], 0\n\t"
+        "s_mov_b64 %[chain], 0\n"
+        "1:\n\t"
+        "v_readlane_b32 %[a], %[A], %[cur]\n\t"
+        "s_bitcmp1_b32 %[a], 8\n\t"               // an end-of-block code or one that is not assigned: where the chain ends
+        "s_cbranch_scc1 2f\n\t"
+        "s_bitset1_b64 %[chain], %[cur]\n\t"
+        "s_and_b32 %[cur], %[a], 0x7f\n\t"
+        "s_cmp_lt_u32 %[cur], 64\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n"
+        : [cur] "=&s"(cur), [a] "=&s"(a), [chain] "=&s"(chain)
+        : [A] "v"(A)
+        : "scc");
     const bool stopped = (a & 0x100u) != 0u;           // (then `cur` is the lane of that code and a & 127 the bit behind it)
 #ifdef SCFQ_LPROF
     asm volatile("" : : "s"(chain), "s"(cur));
@@ -502,7 +511,8 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
     // A round ends in front of a symbol it cannot take in one go: a match that reads output of this very round (not in memory when the
     // round's one load is issued), that reaches back further than there is output (or whose distance code is not assigned), or
     // output beyond the round's 64 lanes.  The symbol starts the next round; if it IS the first, it is done alone, the serial way.
-    const bool cut_here = on && ((kind == 1u && (st + len > B || B - 1u >= pos + st)) || st + len > 64u);
+    // (bitwise, not && / ||: short-circuit evaluation became three nested exec-mask regions)
+    const bool cut_here = on & (((kind == 1u) & ((st + len > B) | (B - 1u >= pos + st))) | (st + len > 64u));
     const uint64_t cuts = __builtin_amdgcn_ballot_w64(cut_here);
     uint32_t R, adv, stop = 0, alone = 0, c = 64u;
     if (cuts == 0ull) {
