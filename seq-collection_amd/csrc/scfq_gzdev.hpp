@@ -99,10 +99,10 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   for (int b = 0; b < 3; ++b) if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
   for (int b = 0; b < 2; ++b) {
     if (!g.s_decode[b]) {
-      // The decode kernels fill every CU they may use with waves that run for tens of milliseconds, and whatever else the
-      // pipeline launches meanwhile (copy and fill kernels of the runtime, search, window chain, resolve, CRC, scan) would
-      // wait for their slots: the decode streams leave a few CUs alone (CU mask), the other streams find them free.
-      static const int reserve = std::max(0, env_int("SCFQ_GZ_DEVICE_RESERVE_CUS", 16));
+      // The decode kernels fill the device with waves that run for tens of milliseconds, and whatever else the pipeline launches
+      // meanwhile (copies, search, window chain, resolve, CRC, scan) has to get in between.  SCFQ_GZ_DEVICE_RESERVE_CUS=n keeps
+      // the decode streams off n CUs (a CU mask); measured, that costs the decode more than it gives the rest: off by default.
+      static const int reserve = std::max(0, env_int("SCFQ_GZ_DEVICE_RESERVE_CUS", 0));
       hipError_t e = hipErrorNotSupported;
       if (reserve > 0 && c->n_cu > 2 * reserve) {
         std::vector<uint32_t> mask((size_t)(c->n_cu + 31) / 32, 0u);
@@ -131,20 +131,22 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   // ---- plan ----------------------------------------------------------------------------------------------------------------
   const uint64_t data0 = (uint64_t)h0;
   const uint64_t comp = fsize - data0;
-  // Segments: 128 KiB of compressed data each for files up to 1 GiB, larger ones (up to 320 KiB) beyond, so that a file of up to
-  // 2.5 GiB compressed (10 GB of FASTQ) is ONE batch of at most 8192 segments: measured, the decode kernel fills the device with
-  // waves that run for tens of milliseconds, and the copies and short kernels of a neighbouring batch get through it at a
-  // quarter of their speed (10 GB: one batch 313 ms, five overlapping batches 330 ms), so batches are for bounding the
-  // memory of big files, not for speed.
+  // Segments: 128 KiB of compressed data each for files up to 1 GiB, larger ones (up to 320 KiB) beyond; batches of about 4096
+  // segments — the decode kernel's resident waves — of equal size.  Two batches in flight is what pays (10 GB of FASTQ, 2.4 GB
+  // compressed: one batch 199 ms, two 165 ms, five 217 ms): the second half of the file crosses PCIe while the first is decoded,
+  // and a batch's windows, bytes, CRC and scan run under the next one's decode; with more, smaller batches the copies and short
+  // kernels crawl between the long-running decode waves.
   static const int seg_kb_env = env_int("SCFQ_GZ_DEVICE_SEGMENT_KB", 0);
-  static const uint32_t batch_segs = (uint32_t)std::max(2, env_int("SCFQ_GZ_DEVICE_BATCH_SEGMENTS", 8192));
+  static const uint32_t batch_segs = (uint32_t)std::max(2, env_int("SCFQ_GZ_DEVICE_BATCH_SEGMENTS", 4096));
   const uint64_t seg_bytes = seg_kb_env > 0 ? ((((uint64_t)std::max(32, seg_kb_env)) << 10) + 4095) & ~4095ull
                                             : std::min<uint64_t>(320u << 10, std::max<uint64_t>(128u << 10, ((comp + 8191) / 8192 + 4095) & ~4095ull));
-  static const uint32_t first_batch_segs = (uint32_t)std::min<int>((int)batch_segs, std::max(2, env_int("SCFQ_GZ_DEVICE_FIRST_BATCH_SEGMENTS", (int)batch_segs)));
   static const uint64_t ratio = (uint64_t)std::max(2, env_int("SCFQ_GZ_DEVICE_MAX_RATIO", 7));   // output symbols a segment may produce per compressed byte
   const uint64_t n_plan = std::max<uint64_t>(1, (comp + seg_bytes - 1) / seg_bytes);
   std::vector<uint64_t> bstart{0};                     // planned segments [bstart[k], bstart[k + 1]) make batch k
-  for (uint64_t at = 0; at < n_plan;) { at = std::min<uint64_t>(n_plan, at + (bstart.size() == 1 ? first_batch_segs : batch_segs)); bstart.push_back(at); }
+  {
+    const uint64_t n_batches = (n_plan + batch_segs - 1) / batch_segs, per = (n_plan + n_batches - 1) / n_batches;
+    for (uint64_t at = 0; at < n_plan;) { at = std::min<uint64_t>(n_plan, at + per); bstart.push_back(at); }
+  }
   const uint32_t nb = (uint32_t)bstart.size() - 1;
   const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
   const uint64_t comp_pad = 256;
