@@ -468,17 +468,26 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   DCHK(rocprim::exclusive_scan(tmp.p, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_hdr + 1),
                                rocprim::plus<uint64_t>(), stream));
   uint64_t h[3] = {0, 0, 0};
+  const uint64_t n_groups = (n_hdr + kGatherGroup - 1) / kGatherGroup;
+  // a caller's buffer that holds the whole input holds any result: the gather goes out behind the scan at once, and the one
+  // wait of the call is the one at the end (otherwise the size has to come back first — the result is allocated to fit)
+  const bool gather_first = !sized_only && user_out && user_cap >= n;
+  if (gather_first) {
+    hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                       out_off.as<uint64_t>(), out_len.as<uint64_t>(), user_out);
+    DCHK(hipGetLastError());
+  }
   DCHK(hipMemcpyAsync(&h[0], out_off.as<uint64_t>() + n_hdr, 8, hipMemcpyDeviceToHost, stream));
   DCHK(hipMemcpyAsync(&h[1], counters.p, 16, hipMemcpyDeviceToHost, stream));
   DCHK(hipStreamSynchronize(stream));
-  mark("lengths + scan + readback");
+  mark(gather_first ? "lengths + scan + gather + readback" : "lengths + scan + readback");
   st->duplicates = h[1];
   st->hash_collisions = h[2];
   st->records_out = n_hdr - h[1];
   st->bytes_out = h[0];
   st->false_positive = 0;
   *out_bytes = h[0];
-  if (sized_only || h[0] == 0) return SCFQ_OK;
+  if (sized_only || h[0] == 0 || gather_first) return SCFQ_OK;
   DevBuf own;
   uint8_t* o = user_out;
   if (!o) {
@@ -487,7 +496,6 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   } else if (user_cap < h[0]) {
     return SCFQ_EARG;
   }
-  const uint64_t n_groups = (n_hdr + kGatherGroup - 1) / kGatherGroup;
   hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
                      out_off.as<uint64_t>(), out_len.as<uint64_t>(), o);
   DCHK(hipGetLastError());
