@@ -131,15 +131,18 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   // ---- plan ----------------------------------------------------------------------------------------------------------------
   const uint64_t data0 = (uint64_t)h0;
   const uint64_t comp = fsize - data0;
-  // Segments: 128 KiB of compressed data each for files up to 1 GiB, larger ones (up to 320 KiB) beyond; batches of about 4096
-  // segments — the decode kernel's resident waves — of equal size.  Two batches in flight is what pays (10 GB of FASTQ, 2.4 GB
+  // Segments of 48 to 320 KiB of compressed data (below); batches of about 4096 segments — the decode kernel's resident
+  // waves — of equal size.  Two batches in flight is what pays (10 GB of FASTQ, 2.4 GB
   // compressed: one batch 199 ms, two 165 ms, five 217 ms): the second half of the file crosses PCIe while the first is decoded,
   // and a batch's windows, bytes, CRC and scan run under the next one's decode; with more, smaller batches the copies and short
   // kernels crawl between the long-running decode waves.
   static const int seg_kb_env = env_int("SCFQ_GZ_DEVICE_SEGMENT_KB", 0);
   static const uint32_t batch_segs = (uint32_t)std::max(2, env_int("SCFQ_GZ_DEVICE_BATCH_SEGMENTS", 4096));
+  // (a file of up to 512 MiB is cut into about 4096 segments — one wave each, the device filled once — of at least 48 KiB; a
+  // bigger one into about 8192 of at most 320 KiB: every segment costs 32768 marker symbols and a step of the window chain)
+  const uint64_t target_segs = comp <= (512ull << 20) ? 4096 : 8192;
   const uint64_t seg_bytes = seg_kb_env > 0 ? ((((uint64_t)std::max(32, seg_kb_env)) << 10) + 4095) & ~4095ull
-                                            : std::min<uint64_t>(320u << 10, std::max<uint64_t>(128u << 10, ((comp + 8191) / 8192 + 4095) & ~4095ull));
+                                            : std::min<uint64_t>(320u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull));
   static const uint64_t ratio = (uint64_t)std::max(2, env_int("SCFQ_GZ_DEVICE_MAX_RATIO", 7));   // output symbols a segment may produce per compressed byte
   const uint64_t n_plan = std::max<uint64_t>(1, (comp + seg_bytes - 1) / seg_bytes);
   std::vector<uint64_t> bstart{0};                     // planned segments [bstart[k], bstart[k + 1]) make batch k
