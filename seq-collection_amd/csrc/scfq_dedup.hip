@@ -157,8 +157,10 @@ __device__ __forceinline__ uint64_t hash_words(uint64_t seed, uint64_t len, cons
 // loads per thread touched 64 cache lines per instruction (512 line look-ups per wave for ~100 distinct lines).  Instead lane l
 // fetches word l & 7 of header 8 j + (l >> 3) in step j — eight consecutive lanes read 64 consecutive bytes — and the words go
 // through LDS back to the lane that owns the header.  Same hash as a per-thread fetch.
+// K: the type the sorted hash is kept in (uint32_t when SCFQ_DEDUP_HASH_BITS <= 32: 4 radix passes over 8-byte pairs; else uint64_t)
+template <typename K>
 __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
-                                                      uint64_t seed, uint32_t hash_bits, uint64_t* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
+                                                      uint64_t seed, uint32_t hash_bits, K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
   __shared__ uint64_t sh_s[4][64];
   __shared__ uint32_t sh_len[4][64];
   __shared__ uint64_t sh_w[4][64][9];                   // (9: the owner's eight 8-byte reads of consecutive lanes spread over the banks)
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint
     else for (uint64_t b = 0; p + b < e; ++b) v |= (uint64_t)base[p + b] << (8 * b);
     h = mix64(h ^ v) + 0x9E3779B97F4A7C15ull;
   }
-  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // (40 by default; the tests force collisions with 4)
-  keys[i] = h;
+  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // (32 or 40 by default; the tests force collisions with 4)
+  keys[i] = (K)h;
   idx[i] = (uint32_t)i;
 }
 
@@ -224,7 +226,8 @@ __device__ __forceinline__ bool same_header(const uint8_t* base, uint64_t n, con
 
 // D3a: the sorted positions whose hash equals their predecessor's (the only records that can be duplicates), compacted:
 // with one record in six a duplicate, most lanes of the compare kernel had nothing to do while the others waited on memory
-__global__ __launch_bounds__(256) void dd_find_equal(const uint64_t* keys_sorted, uint64_t n_hdr, uint32_t* cand, uint32_t* n_cand) {
+template <typename K>
+__global__ __launch_bounds__(256) void dd_find_equal(const K* keys_sorted, uint64_t n_hdr, uint32_t* cand, uint32_t* n_cand) {
   // a block takes 2048 positions (8 per thread, position = base + 256 j + thread) and ONE atomic: with a block per 256 positions
   // the 109 K atomics on the one counter were the kernel's whole time (1.0 ms for 445 MB of keys)
   __shared__ uint32_t wave_cnt[8][4], block_base;
@@ -259,8 +262,9 @@ __global__ __launch_bounds__(256) void dd_find_equal(const uint64_t* keys_sorted
 // The first 64 bytes of both headers of every candidate of a wave are fetched cooperatively, as in dd_hash_headers (lane l:
 // word l & 7 of header 8 j + (l >> 3), 16 steps for 128 headers) and compared from LDS; longer headers and longer runs take
 // the per-thread walk.
+template <typename K>
 __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, uint64_t n, const uint64_t* line_off, const uint64_t* hdr,
-                                                         const uint64_t* keys_sorted, const uint32_t* idx_sorted, const uint32_t* cand,
+                                                         const K* keys_sorted, const uint32_t* idx_sorted, const uint32_t* cand,
                                                          const uint32_t* n_cand, uint8_t* dup,
                                                          unsigned long long* counters /* [0] dups, [1] hash collisions */, bool has_cr) {
   __shared__ uint64_t sh_s[4][128];
@@ -271,7 +275,8 @@ __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, u
   const uint32_t total = *n_cand;
   if ((uint64_t)blockIdx.x * 256 >= total) return;            // (block-uniform: the barriers below are reached by all or none)
   const bool active = t < total;
-  uint64_t p = 0, key = 0;
+  uint64_t p = 0;
+  K key = 0;
   uint32_t me = 0, other = 0;
   uint64_t sa = 0, la = 0, sb = 0, lb = 0;
   if (active) {
@@ -435,31 +440,37 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   DCHK(hipMemsetAsync(counters.p, 0, 32, stream));
   const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
   // 40 bits of hash: the radix sort makes 5 passes over the (key, record) pairs instead of 8, and the exact compare behind the
-  // sort makes collisions (n^2 / 2^41 pairs: ~350 among 28 M records) a matter of time, never of correctness
-  static const uint32_t hash_bits = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); int v = e ? std::atoi(e) : 40; return (uint32_t)std::min(64, std::max(1, v)); }();
-  hipLaunchKernelGGL(dd_hash_headers, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
-                     0x5CF0DED0B1A5ull, hash_bits, keys.as<uint64_t>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
-  DCHK(hipGetLastError());
-  mark("hash headers");
-  size_t tmp_bytes = 0;
-  DCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
-                                 (size_t)n_hdr, 0u, hash_bits, stream));
+  // sort makes collisions (n^2 / 2^41 pairs: ~350 among 28 M records) a matter of time, never of correctness.  (32 bits in
+  // 32-bit keys — SCFQ_DEDUP_HASH_BITS=32 — sort in 0.93 instead of 1.29 ms for 28 M records, but their 88 K colliding pairs
+  // cost the compare kernel 0.48 ms more: measured, not the default.)
+  static const int hash_bits_env = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); return e ? std::min(64, std::max(1, std::atoi(e))) : 0; }();
+  const uint32_t hash_bits = hash_bits_env ? (uint32_t)hash_bits_env : 40u;
   size_t scan_bytes = 0;
   DCHK(rocprim::exclusive_scan(nullptr, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_hdr + 1),
                                rocprim::plus<uint64_t>(), stream));
-  if ((rc = tmp.alloc(std::max(tmp_bytes, scan_bytes), stream))) return rc;
-  DCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
-                                 (size_t)n_hdr, 0u, hash_bits, stream));
-  mark("radix sort");
-  DCHK(hipMemsetAsync(dup.p, 0, n_hdr, stream));
   uint32_t* n_cand = reinterpret_cast<uint32_t*>(counters.as<unsigned long long>() + 2);
-  hipLaunchKernelGGL(dd_find_equal, dim3((unsigned)((n_hdr + 2047) / 2048)), dim3(256), 0, stream, keys2.as<uint64_t>(), n_hdr, cand.as<uint32_t>(), n_cand);
-  DCHK(hipGetLastError());
-  // (the launch covers the worst case; blocks past the candidate count leave at once)
-  hipLaunchKernelGGL(dd_mark_duplicates, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), hdr.as<uint64_t>(),
-                     keys2.as<uint64_t>(), idx2.as<uint32_t>(), cand.as<uint32_t>(), n_cand, dup.as<uint8_t>(),
-                     counters.as<unsigned long long>(), has_cr);
-  DCHK(hipGetLastError());
+  auto hash_sort_mark = [&](auto key_tag) -> int {
+    using K = decltype(key_tag);
+    hipLaunchKernelGGL(dd_hash_headers<K>, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
+                       0x5CF0DED0B1A5ull, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
+    DCHK(hipGetLastError());
+    mark("hash headers");
+    size_t tmp_bytes = 0;
+    DCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<K>(), keys2.as<K>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), (size_t)n_hdr, 0u, hash_bits, stream));
+    if ((rc = tmp.alloc(std::max(tmp_bytes, scan_bytes), stream))) return rc;
+    DCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<K>(), keys2.as<K>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), (size_t)n_hdr, 0u, hash_bits, stream));
+    mark("radix sort");
+    DCHK(hipMemsetAsync(dup.p, 0, n_hdr, stream));
+    hipLaunchKernelGGL(dd_find_equal<K>, dim3((unsigned)((n_hdr + 2047) / 2048)), dim3(256), 0, stream, keys2.as<K>(), n_hdr, cand.as<uint32_t>(), n_cand);
+    DCHK(hipGetLastError());
+    // (the launch covers the worst case; blocks past the candidate count leave at once)
+    hipLaunchKernelGGL(dd_mark_duplicates<K>, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), hdr.as<uint64_t>(),
+                       keys2.as<K>(), idx2.as<uint32_t>(), cand.as<uint32_t>(), n_cand, dup.as<uint8_t>(),
+                       counters.as<unsigned long long>(), has_cr);
+    DCHK(hipGetLastError());
+    return SCFQ_OK;
+  };
+  if ((rc = hash_bits <= 32 ? hash_sort_mark(uint32_t{}) : hash_sort_mark(uint64_t{}))) return rc;
   mark("mark duplicates");
   hipLaunchKernelGGL(dd_record_lengths, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
                      dup.as<uint8_t>(), out_len.as<uint64_t>(), has_cr);
