@@ -40,6 +40,8 @@ def test_corpora_levels_strategies(gpu, scfq):
         "short_period": (b"ACGTN" * 7 + b"\n") * 9_000,
         "two_symbols": bytes(rng.choice(np.frombuffer(b"AB", dtype=np.uint8), 200_000)),
         "skewed": bytes(rng.choice(np.arange(256, dtype=np.uint8), 300_000, p=np.r_[np.full(16, 0.05), np.full(240, 0.2 / 240)])),
+        # matches at the far end of the window (zlib reaches back 32506 bytes), long ones (258) and runs (distance 1) side by side
+        "far_repeats": rng.integers(0, 256, 32_000, dtype=np.uint8).tobytes() * 6 + bytes(3000) + b"Q" * 700,
     }
     for name, data in corpora.items():
         for level in (1, 6, 9):

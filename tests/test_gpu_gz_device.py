@@ -69,6 +69,9 @@ def test_other_corpora(gpu, oracle, tmp_path):
         "long_reads": b"".join(b"@r%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 40_000)) + b"\n+\n" +
                                bytes(rng.integers(34, 74, 40_000, dtype=np.uint8)) + b"\n" for i in range(60)),
         "random_bytes": rng.integers(0, 256, 3_000_000, dtype=np.uint8).tobytes(),
+        # matches at the far end of the window next to fresh bytes (ratio ~2: inside a segment's output room)
+        "far_repeats": b"".join(blk + rng.integers(0, 256, 10_000, dtype=np.uint8).tobytes()
+                                for blk in [rng.integers(0, 256, 20_000, dtype=np.uint8).tobytes()] * 120),
     }
     for name, data in corpora.items():
         f = tmp_path / (name + ".fq.gz")
