@@ -414,7 +414,9 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   {
     uint64_t cap = n / 24 + 1024;
     if ((rc = line_off.alloc(cap * 8, stream))) return rc;
+    mark("alloc line offsets");
     DCHK(hipStreamSynchronize(stream));       // scfq_index_lines works on the library's own stream
+    mark("wait for the caller's stream");
     rc = scfq_index_lines_ex(d_in, n, line_off.as<uint64_t>(), cap, &lines, &index_flags);
     if (rc) return rc;
     if (lines + 1 > cap) {
