@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/dinflate_ablate; mkdir -p $OUT
 S=$R/seq-collection_amd/csrc
 for A in ${ABLATIONS:-0 2 3 7 8 16}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DSCFQ_DABLATE=$A -o /tmp/libscfq_dab$A.so \
-    $S/scfq_api.hip $S/scfq_host.cpp $S/scfq_synth.hip $S/scfq_dedup.hip $S/scfq_meta.cpp -lz -lpthread 2>/dev/null &
+    $S/scfq_api.hip $S/scfq_host.cpp $S/scfq_synth.hip $S/scfq_dedup.hip $S/scfq_meta.cpp $S/scfq_comm.cpp -lz -lpthread -ldl 2>/dev/null &
 done
 wait
 python $R/scripts/measure_bgzf_device.py $N > $OUT/base.jsonl

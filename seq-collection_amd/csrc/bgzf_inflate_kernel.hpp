@@ -27,7 +27,7 @@
 namespace scfq_dinflate {
 
 #ifndef SCFQ_DABLATE
-#define SCFQ_DABLATE 0      // measurement builds only (scripts/gpu_dinflate_ablate.sh): 1 no match copies, 2 no CRC, 4 no literal stores, 8 / 16 ten extra scalar / vector instructions per symbol
+#define SCFQ_DABLATE 0      // measurement builds only (scripts/gpu_dinflate_ablate.sh): 1 no match copies, 2 no CRC, 4 no literal stores (serial loop), 8 / 16 ten extra scalar / vector instructions per symbol (serial loop) or round (lane-parallel loop)
 #endif
 
 struct Block {              // offsets are relative to the chunk's compressed / inflated buffers
@@ -447,6 +447,18 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
     asm volatile("" : : "s"(W0), "s"(W1), "s"(W2), "s"(W3));
 #endif
     SCFQ_LP_T(t1);
+    if (SCFQ_DABLATE & 8) {                // measurement only: ten more scalar instructions per round
+      uint32_t t_ = pos;
+#pragma unroll
+      for (int q_ = 0; q_ < 10; ++q_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(t_) : : "scc");
+      asm volatile("" : : "s"(t_));
+    }
+    if (SCFQ_DABLATE & 16) {               // measurement only: ten more vector instructions per round
+      uint32_t t_ = lane;
+#pragma unroll
+      for (int q_ = 0; q_ < 10; ++q_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_));
+      asm volatile("" : : "v"(t_));
+    }
     // ---- 1. every lane: the symbol that would start at bit `lane` ---------------------------------------------------------------
     const uint32_t wa = upper ? W1 : W0, wb = upper ? W2 : W1, wc = upper ? W3 : W2;
     const uint32_t x0 = __builtin_amdgcn_alignbit(wb, wa, sft), x1 = __builtin_amdgcn_alignbit(wc, wb, sft);      // 64 bits from bit `lane` on
@@ -615,9 +627,29 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   uint16_t* offs = count + 16;
   __shared__ uint32_t build_ok[kWavesPerWg];
   __shared__ uint32_t s_len[32], s_dist[32];           // base << 16 | extra bits << 4 | kVal: table entries minus the code length
+  // CRC-32, four bytes per step: crc_tab[0] is the byte-wise table, crc_tab[k][i] the CRC of byte i followed by k zero bytes;
+  // crc_xp[k] = x^(8 * 2^k) mod P (the shifts that stitch the lanes' slices)
+  __shared__ uint32_t crc_tab[4][256];
+  __shared__ uint32_t crc_xp[20];
+  static_assert(64 * kWavesPerWg == 256, "one table entry per thread");
   if (threadIdx.x < 29) s_len[threadIdx.x] = ((uint32_t)kLenBase[threadIdx.x] << 16) | ((uint32_t)kLenExtra[threadIdx.x] << 4) | kVal;
   if (threadIdx.x < 30) s_dist[threadIdx.x] = ((uint32_t)kDistBase[threadIdx.x] << 16) | ((uint32_t)kDistExtra[threadIdx.x] << 4) | kVal;
+  {
+    uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t = (t >> 1) ^ (0xEDB88320u & (0u - (t & 1u)));
+    crc_tab[0][threadIdx.x] = t;
+    if (threadIdx.x == 0) {
+      uint32_t sq = 1u << 23;                            // x^8
+      for (int k = 0; k < 20; ++k) { crc_xp[k] = sq; sq = gf2_mulmod(sq, sq); }
+    }
+  }
   __syncthreads();
+  for (int k = 1; k < 4; ++k) {
+    const uint32_t t = crc_tab[k - 1][threadIdx.x];
+    crc_tab[k][threadIdx.x] = (t >> 8) ^ crc_tab[0][t & 255u];
+    __syncthreads();
+  }
   if (b >= n_blocks) return;
 
   const Block blk = blocks[b];
@@ -770,24 +802,42 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   // bits taken beyond the end of the deflate data (they were trailer bytes, or the clamped load's): the stream is malformed
   if (err == kOk && (uint64_t)ip * 8 - bc > (uint64_t)ip_end * 8) err = kErrData;
   if (err == kOk && pos != isize) err = kErrLength;
-  // ---- CRC-32 of the member: every lane the standard CRC of a contiguous slice, then 63 combines ------------------------
+  // ---- CRC-32 of the member ------------------------------------------------------------------------------------------------
+  // Every lane takes the RAW CRC (zero initial value, no final inversion: R(M) = M(x) x^32 mod P) of one slice of a virtual message
+  // "pad zero bytes, then the member's output" whose 64 slices are equally long: leading zeros do not change R, and
+  // R(A || B) = R(A) x^(8|B|) + R(B), so the slices are stitched in six steps of a tree with ONE shift per step (x^(8 per 2^j),
+  // each the square of the one before); crc32(M) = R(M) ^ 0xFFFFFFFF x^(8|M|) ^ 0xFFFFFFFF.  Four bytes per step through the
+  // tables above (the first form of this: bit by bit, 24 vector instructions per byte, a tenth of the kernel's time; and 63
+  // serial products with a shift computed bit by bit for the stitching).
   if (err == kOk && !(SCFQ_DABLATE & 2)) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint32_t per = (isize + 63) / 64;
-    const uint32_t lo = lane * per < isize ? lane * per : isize, hi = lo + per < isize ? lo + per : isize;
-    uint32_t c = 0xFFFFFFFFu;
-    for (uint32_t k = lo; k < hi; ++k) c = crc_byte(c, __hip_atomic_load(o + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    c ^= 0xFFFFFFFFu;                                   // the CRC of an empty slice is 0
-    const uint32_t shift_full = x_pow_8n(per);
-    uint32_t total = 0;
-    for (uint32_t l = 0; l < 64; ++l) {
-      const uint32_t c_l = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)l);
-      const uint32_t lo_l = l * per < isize ? l * per : isize, hi_l = lo_l + per < isize ? lo_l + per : isize;
-      const uint32_t n_l = hi_l - lo_l;
-      if (n_l == 0) continue;
-      total = gf2_mulmod(n_l == per ? shift_full : x_pow_8n(n_l), total) ^ c_l;
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)isize, 0x00020000);
+    auto xpow = [&](uint32_t nbytes) {                  // x^(8 nbytes) mod P, nbytes < 2^20
+      uint32_t p = 1u << 31;
+      for (uint32_t k = 0; nbytes; ++k, nbytes >>= 1)
+        if (nbytes & 1u) p = gf2_mulmod(crc_xp[k], p);
+      return p;
+    };
+    const uint32_t per = (((isize + 63u) / 64u) + 3u) & ~3u;            // bytes per lane: whole dwords
+    const uint32_t pad = 64u * per - isize;
+    const uint32_t v0 = lane * per, v1 = v0 + per;                      // the lane's slice of the virtual message
+    const uint32_t lo = v1 <= pad ? 0u : (v0 > pad ? v0 - pad : 0u), hi = v1 <= pad ? 0u : v1 - pad;
+    uint32_t c = 0;
+    uint32_t k = lo;
+    for (; k + 4u <= hi; k += 4u) {
+      c ^= __builtin_amdgcn_raw_buffer_load_b32(crsrc, k, 0, 1 /*sc0*/);
+      c = crc_tab[3][c & 255u] ^ crc_tab[2][(c >> 8) & 255u] ^ crc_tab[1][(c >> 16) & 255u] ^ crc_tab[0][c >> 24];
     }
+    for (; k < hi; ++k) c = crc_tab[0][(c ^ (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(crsrc, k, 0, 1)) & 255u] ^ (c >> 8);
+    uint32_t shift = xpow(per);
+#pragma unroll
+    for (uint32_t j = 0; j < 6; ++j) {
+      const uint32_t right = (uint32_t)__shfl_down((int)c, 1 << j);
+      c = gf2_mulmod(c, shift) ^ right;                  // (meaningful in the lanes that are multiples of 2^(j+1): lane 0 in the end)
+      shift = gf2_mulmod(shift, shift);
+    }
+    const uint32_t total = uni(c) ^ gf2_mulmod(xpow(isize), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
     if (total != blk.crc) err = kErrCrc;
   }
 #undef SCFQ_DREFILL
