@@ -31,7 +31,9 @@ namespace scfq_dinflate {
 constexpr uint32_t kGzWindow = 32768;
 
 // ---- bit access for the search kernel: 64 bits starting at an arbitrary bit position (the buffer is padded) ----------
-__device__ __forceinline__ uint64_t bits64_at(const uint64_t* words, uint64_t bit) {
+// (WP: a pointer to the words in global memory, or to the staged copy of a chunk in LDS)
+template <typename WP>
+__device__ __forceinline__ uint64_t bits64_at(WP words, uint64_t bit) {
   const uint64_t w = bit >> 6;
   const uint32_t sh = (uint32_t)bit & 63u;
   const uint64_t lo = words[w], hi = words[w + 1];
@@ -43,7 +45,8 @@ constexpr uint32_t kSyncChunkBits = 32768;      // positions examined between tw
 constexpr uint32_t kSyncListCap = 1024;
 
 // header of a dynamic block at `bit`: cheap tests first (one lane per position), result = survives / not
-__device__ __forceinline__ bool sync_quick(const uint64_t* words, uint64_t bit) {
+template <typename WP>
+__device__ __forceinline__ bool sync_quick(WP words, uint64_t bit) {
   const uint64_t w = bits64_at(words, bit);
   if (((w >> 1) & 3u) != 2u) return false;                 // BTYPE 10
   if (((w >> 3) & 31u) > 29u) return false;                // HLIT <= 286 - 257
@@ -58,11 +61,36 @@ __device__ __forceinline__ bool sync_quick(const uint64_t* words, uint64_t bit) 
   return kraft == 128u;                                    // complete (zlib rejects anything else for this code)
 }
 
+// The cheap tests of sync_quick for 32 consecutive positions at once (bit i of the result: position bit + i may be a header):
+// BTYPE, HLIT and HDIST are fixed bit patterns, so they are shifts and ANDs of the 64 bits at `bit` (the fields of position
+// bit + 31 end at bit + 47).  About a fifth of the positions survive; only those pay for the Kraft sum.
+template <typename WP>
+__device__ __forceinline__ uint32_t sync_fields32(WP words, uint64_t bit) {
+  const uint64_t x = bits64_at(words, bit);
+  uint64_t m = (~x >> 1) & (x >> 2);                                     // BTYPE 10 (bit + 1 clear, bit + 2 set)
+  m &= ~((x >> 4) & (x >> 5) & (x >> 6) & (x >> 7));                     // HLIT <= 29: not 1111x
+  m &= ~((x >> 9) & (x >> 10) & (x >> 11) & (x >> 12));                  // HDIST <= 29
+  return (uint32_t)m;
+}
+// the code-length code of a position that passed sync_fields32: complete (zlib rejects anything else for this code)
+template <typename WP>
+__device__ __forceinline__ bool sync_kraft(WP words, uint64_t bit) {
+  const uint32_t hclen = (uint32_t)(bits64_at(words, bit + 13) & 15u) + 4u;
+  const uint64_t w2 = bits64_at(words, bit + 17);
+  uint32_t kraft = 0;
+  for (uint32_t k = 0; k < hclen; ++k) {
+    const uint32_t l = (uint32_t)(w2 >> (3u * k)) & 7u;
+    kraft += l ? (128u >> l) : 0u;
+  }
+  return kraft == 128u;
+}
+
 // the rest of the header: decode the HLIT + HDIST code lengths with the code-length code, ask for a complete literal/length
 // code with an end-of-block code and a distance code zlib accepts.  Everything lives in registers (counts and the symbols
 // sorted by code length are packed into 64-bit words), and a candidate is dropped the moment one of its codes is
 // over-subscribed: random bits get there within a few dozen lengths, so the survivors of sync_quick cost little.
-__device__ inline bool sync_deep(const uint64_t* words, uint64_t bit, uint64_t end_bit) {
+template <typename WP>
+__device__ inline bool sync_deep(WP words, uint64_t bit, uint64_t end_bit) {
   const uint64_t w = bits64_at(words, bit);
   const uint32_t hlit = (uint32_t)((w >> 3) & 31u) + 257u, hdist = (uint32_t)((w >> 8) & 31u) + 1u, hclen = (uint32_t)((w >> 13) & 15u) + 4u;
   const uint64_t w2 = bits64_at(words, bit + 17);
@@ -123,24 +151,43 @@ __device__ inline bool sync_deep(const uint64_t* words, uint64_t bit, uint64_t e
   return kraft_d == 32768u || n_d == 0 || (n_d == 1 && max_d == 1);
 }
 
-// found[s] = first bit position >= from[s] (and < from[s] + max_bits, < end_bit) that passes; ~0 when none does
+// found[s] = first bit position >= from[s] (and < from[s] + max_bits, < end_bit) that passes; ~0 when none does.
+// Every chunk of 32768 positions is first STAGED in LDS (4.7 KiB: the chunk and the longest block header behind its last
+// position), one coalesced pass, and both tests read it from there: straight from global memory each of the 128 steps of the
+// quick test and each code length of the deep one was a memory round trip (6.2 ms for 4096 searches over 0.5 GB).
+constexpr uint32_t kSyncStageWords = 600;       // 512 words of positions + 1 (the chunk starts inside a word) + 4600 bits of header + spare
 __global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* __restrict__ words, uint64_t end_bit, const uint64_t* __restrict__ from,
                                                               uint32_t n_seg, uint64_t max_bits, uint64_t* __restrict__ found) {
   __shared__ uint32_t list[kSyncListCap];
   __shared__ uint32_t n_list, best;
+  __shared__ uint64_t stage[kSyncStageWords];
+  typedef __attribute__((address_space(3))) const uint64_t* lds_words;
+  const lds_words sw = (lds_words)(uintptr_t)(uint32_t)(uintptr_t)stage;
   const uint32_t s = blockIdx.x;
   if (s >= n_seg) return;
   const uint64_t base = from[s];
   const uint64_t limit = (base + max_bits < end_bit) ? base + max_bits : end_bit;
+  const uint64_t last_word = (end_bit >> 6) + 3;                         // (the buffer is padded well beyond that)
   uint64_t result = ~0ull;
   for (uint64_t c0 = base; c0 < limit; c0 += kSyncChunkBits) {
+    const uint64_t w0 = c0 >> 6, bit0 = w0 << 6;                         // staged word k = words[w0 + k]; a position p is bit p - bit0 of the stage
     if (threadIdx.x == 0) { n_list = 0; best = 0xFFFFFFFFu; }
+    for (uint32_t k = threadIdx.x; k < kSyncStageWords; k += kSyncThreads) stage[k] = w0 + k <= last_word ? words[w0 + k] : 0ull;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kSyncChunkBits; i += kSyncThreads) {
-      const uint64_t p = c0 + i;
-      if (p + 128 <= limit && sync_quick(words, p)) {
-        const uint32_t at = atomicAdd(&n_list, 1u);
-        if (at < kSyncListCap) list[at] = i;
+    const uint64_t rel_end = end_bit - bit0 < (uint64_t)(kSyncStageWords - 2) * 64u ? end_bit - bit0 : (uint64_t)(kSyncStageWords - 2) * 64u;
+    for (uint32_t j = threadIdx.x; j < kSyncChunkBits / 32u; j += kSyncThreads) {
+      const uint64_t p0 = c0 + 32u * j;
+      uint32_t cand = sync_fields32(sw, p0 - bit0);
+      // (a position must leave 128 bits in front of the limit)
+      if (p0 + 128u > limit) cand = 0;
+      else if (p0 + 31u + 128u > limit) cand &= (2u << (uint32_t)(limit - 128u - p0)) - 1u;
+      while (cand) {
+        const uint32_t i = (uint32_t)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        if (sync_kraft(sw, p0 + i - bit0)) {
+          const uint32_t at = atomicAdd(&n_list, 1u);
+          if (at < kSyncListCap) list[at] = 32u * j + i;
+        }
       }
     }
     __syncthreads();
@@ -148,7 +195,7 @@ __global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* _
     // (a list that overflowed lost some LATER candidates of this chunk at worst out of order: every kept one is still
     // tested, the minimum over them is taken, and a missed earlier true block only makes this segment a gap for the host)
     for (uint32_t t = threadIdx.x; t < n; t += kSyncThreads)
-      if (sync_deep(words, c0 + list[t], end_bit)) atomicMin(&best, list[t]);
+      if (sync_deep(sw, c0 + list[t] - bit0, rel_end)) atomicMin(&best, list[t]);
     __syncthreads();
     if (best != 0xFFFFFFFFu) { result = c0 + best; break; }       // block-uniform
     __syncthreads();
