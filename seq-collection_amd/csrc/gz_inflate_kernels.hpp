@@ -616,7 +616,20 @@ __global__ __launch_bounds__(256) void gz_resolve(const GzChain* __restrict__ ch
 constexpr uint32_t kCrcTile = 1u << 20, kCrcStep = 256u * 64u;
 __global__ __launch_bounds__(256) void gz_crc32_tiles(const uint8_t* __restrict__ data, uint64_t n, uint64_t pad, uint32_t* __restrict__ tile_crc) {
   __shared__ uint32_t red[256];
+  __shared__ uint32_t tab[4][256];               // four bytes per step: tab[0] the byte-wise table, tab[k][i] the CRC of byte i followed by k zero bytes
   const uint32_t t = threadIdx.x;
+  {
+    uint32_t e = t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e = (e >> 1) ^ (0xEDB88320u & (0u - (e & 1u)));
+    tab[0][t] = e;
+    __syncthreads();
+    for (int k = 1; k < 4; ++k) {
+      const uint32_t q = tab[k - 1][t];
+      tab[k][t] = (q >> 8) ^ tab[0][q & 255u];
+      __syncthreads();
+    }
+  }
   const uint64_t tile0 = (uint64_t)blockIdx.x * kCrcTile;    // virtual offset
   const uint32_t x_step = x_pow_8n(kCrcStep);
   uint32_t acc = 0;
@@ -632,8 +645,7 @@ __global__ __launch_bounds__(256) void gz_crc32_tiles(const uint8_t* __restrict_
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         c ^= w[j];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        c = tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24];
       }
     } else {
       for (uint32_t j = 0; j < 64; ++j) {
