@@ -1,0 +1,52 @@
+#!/bin/bash
+# Soak of the device inflate paths: the same BGZF file and the same single-member gzip counted over and over, one and eight host
+# threads (context pool: every session has its own buffers), every result compared with the generator's tally, and every count
+# of the gzip file must have stayed on the device (a CRC or chain failure falls back to the host readers silently otherwise).
+# usage: scripts/gpu_soak_inflate.sh [inflated bytes, default 5e8] [repetitions, default 30]     (GPU box)
+set -e
+N=${1:-5e8}; REPS=${2:-30}
+python - <<PY
+import os, struct, sys, threading, zlib
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, "seq-collection_amd/pyhost")
+import scfq
+plan = scfq.synth_plan(0, 20260101, int(float("$N")))
+data, info = scfq.synth_host(0, 20260101, plan.records)
+want = (plan.records, info.gc_bases, info.n_bases, info.bases)
+def bgzf_block(b):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15); p = co.compress(b) + co.flush(); bs = 18 + len(p) + 8
+    return b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bs - 1) + p + struct.pack("<II", zlib.crc32(b) & 0xFFFFFFFF, len(b))
+def span(a):
+    raw = a.tobytes(); return b"".join(bgzf_block(raw[i:i + 0xff00]) for i in range(0, len(raw), 0xff00))
+parts = [data[i:i + (0xff00 * 256)] for i in range(0, data.size, 0xff00 * 256)]
+with ThreadPoolExecutor(16) as ex:
+    blobs = list(ex.map(span, parts))
+open("/tmp/soak_bgzf.fq.gz", "wb").write(b"".join(blobs))
+step = 64 << 20
+cuts = list(range(0, data.size, step))
+def piece(i):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    return co.compress(data[cuts[i]:cuts[i] + step].tobytes()) + co.flush(zlib.Z_FINISH if i == len(cuts) - 1 else zlib.Z_SYNC_FLUSH)
+with ThreadPoolExecutor(16) as ex:
+    members = list(ex.map(piece, range(len(cuts))))
+crc = 0
+for c0 in cuts: crc = zlib.crc32(data[c0:c0 + step], crc)
+with open("/tmp/soak_gz.fq.gz", "wb") as f:
+    f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03"); [f.write(b) for b in members]
+    f.write(int(crc & 0xFFFFFFFF).to_bytes(4, "little") + int(data.size & 0xFFFFFFFF).to_bytes(4, "little"))
+gz_bytes = os.path.getsize("/tmp/soak_gz.fq.gz")
+bad = []
+def run(tag, path, reps, compressed_over_pcie):
+    for r in range(reps):
+        c = scfq.count_file(path, flags=scfq.SCFQ_TIMING)
+        t = scfq.last_timing()
+        if (c.reads, c.gc_bases, c.n_bases, c.bases) != want: bad.append((tag, r, "counts"))
+        if compressed_over_pcie and not (t.h2d_bytes < 0.5 * data.size): bad.append((tag, r, "host path", t.h2d_bytes))
+run("bgzf", "/tmp/soak_bgzf.fq.gz", $REPS, True)
+run("gzip", "/tmp/soak_gz.fq.gz", $REPS, True)
+print("one thread: %d + %d counts, problems: %s" % ($REPS, $REPS, bad))
+ts = [threading.Thread(target=run, args=("t%d" % k, "/tmp/soak_gz.fq.gz" if k & 1 else "/tmp/soak_bgzf.fq.gz", max(2, $REPS // 6), False)) for k in range(8)]
+[t.start() for t in ts]; [t.join() for t in ts]
+print("eight threads, problems:", bad)
+assert not bad
+PY
