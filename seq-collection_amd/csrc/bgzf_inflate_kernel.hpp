@@ -7,16 +7,17 @@
 // checked on the device.
 //
 // One WAVE per BGZF block.  DEFLATE is serial inside a block (every code's position depends on the previous code's
-// length), so the wave walks the bit stream as one: the bit buffer and every branch are wave-uniform and live on the
-// scalar unit, the compressed bytes arrive through the scalar cache, the Huffman tables live in the wave's own slice of
-// LDS (two-level, 32-bit entries that already hold base value and extra-bit count, built by lane 0 with the construction
-// of zlib's inftrees), literals are stored by lane 0, and the parallelism of the wave goes into the match copies (lane k
-// copies byte k; the store of a match is deferred behind the decoding of the next symbols) and into the CRC (64 slices,
-// one per lane, stitched with a precomputed GF(2) shift).  Throughput comes from the number of blocks in flight
-// (256 CUs x 16 waves), not from one block being fast.
-// What bounds it (measured): the CU's single scalar ALU — about 40 scalar instructions per literal and 90 per
-// match at ~0.8 issued per cycle and CU; more resident waves change nothing.  Level-6 FASTQ is 70 % matches (mean length
-// 10), i.e. ~9 K symbols per 64 KiB member.
+// length), and throughput comes from the number of blocks in flight (256 CUs x 16 waves) — but a wave does not have to walk
+// the stream with 63 lanes idle.  The symbols of a Huffman block are decoded by symbol_loop_lanes below: every lane decodes
+// the symbol that WOULD start at one of the next 64 bit positions (the Huffman tables live in the wave's own slice of LDS:
+// two-level, 32-bit entries that already hold base value and extra-bit count, built by lane 0 with the construction of
+// zlib's inftrees), the scalar unit only follows the chain of the real ones, and the output bytes of a round are produced by
+// one load and one store instruction.  Block headers and code lengths are read by a branch-free bit reader on the scalar unit
+// (compressed bytes through the scalar cache); stored blocks are lane-parallel copies; the member's CRC-32 runs four bytes
+// per step through LDS tables, 64 lane slices stitched in a tree.  Level-6 FASTQ is 70 % matches (mean length 10), i.e.
+// ~9 K symbols per 64 KiB member.  r1's serial symbol loop (one symbol per pass on the scalar unit, ~40 scalar instructions
+// per literal and ~90 per match, every match a round trip to the L2) is kept as symbol_loop for A/B runs
+// (SCFQ_INFLATE_LOOP=serial): 45-49 GB/s against 98 GB/s.
 // Every loop is bounded by the block's input bits or output bytes; a malformed stream sets an error status and ends
 // the wave.
 #pragma once
