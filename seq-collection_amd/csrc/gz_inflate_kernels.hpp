@@ -5,12 +5,13 @@
 // and a back-reference may reach into the 32 KiB before the block.  As pugz / rapidgzip (and csrc/scfq_pgz.hpp on the
 // host) do it, in four kernels over the COMPRESSED bytes resident in HBM:
 //   G1 gz_sync_search     one workgroup per segment scans the bit positions after the segment's nominal start for
-//                         something that parses as a dynamic-Huffman block header (BTYPE, HLIT / HDIST ranges, a complete
-//                         code-length code: one lane per position; the few survivors then decode the code lengths and ask
-//                         for complete literal/length and distance codes and an end-of-block code).  A wrong sync never
+//                         something that parses as a dynamic-Huffman block header (BTYPE, HLIT / HDIST ranges: 32 positions
+//                         per lane at once from a chunk staged in LDS; a complete code-length code; the few survivors
+//                         then decode the code lengths and ask for complete literal/length and distance codes and an
+//                         end-of-block code).  A wrong sync never
 //                         survives the host's chain check: the segment before must arrive at exactly that bit.
-//   G2 gz_segment_decode  one wave per segment (the symbol loop of bgzf_inflate: bit reader on the scalar unit, tables in
-//                         LDS), output = 16-bit symbols behind 32768 marker symbols 0x8000 | k ("byte k of the window I do
+//   G2 gz_segment_decode  one wave per segment (the lane-parallel symbol loop of bgzf_inflate: 64 bit positions decoded at
+//                         once, tables in LDS), output = 16-bit symbols behind 32768 marker symbols 0x8000 | k ("byte k of the window I do
 //                         not have yet"); back-references copy symbols whether known or not.  Ends at the first block
 //                         boundary at or after the next segment's start, or with the member's final block.
 //   G3 gz_window_chain    the 32 KiB window in front of every segment, sequentially along the chain (one workgroup, two
@@ -20,7 +21,7 @@
 //                         offset of the inflated stream; a marker that points before the member's start is corrupt data.
 //   G5 gz_crc32_tiles     raw CRC-32 (zero init) of 1 MiB tiles of the inflated bytes; the host folds the tiles and checks
 //                         every member's CRC-32 / ISIZE trailer.
-// The host (scfq_api.hip: ingest_gz_device) validates the chain, re-decodes gaps (a false sync, the first block of a
+// The host (scfq_gzdev.hpp: ingest_gz_device; batches of ~4096 segments, three in flight) validates the chain, re-decodes gaps (a false sync, the first block of a
 // further member), and falls back to the host readers on anything it cannot prove consistent: results are gzread's
 // byte stream or SCFQ_EGZ, never something in between.
 #pragma once
