@@ -648,7 +648,10 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
 // 16448 members on 4096 wave slots the 64 members of a fifth round ran alone for a fifth of the kernel's time (measured:
 // 24.7 ms for 16448 members, 20.7 ms for 14192).  The member count of a full chunk is therefore a multiple of the slots
 // (CUs x resident waves of bgzf_inflate, asked of the runtime); the byte caps of the chunk still apply.
-static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, bool first = false) {
+// `launch`: 0, 1, 2 ... from the start of the file; the first launches are short (one round of members, one, two), so that the
+// device starts after a quarter of the first copy and each of the next chunks is copied while the one before it is inflated: a
+// full chunk straight behind the first short one left the device idle for 7 ms (its fill and copy take 11, the short launch 3).
+static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, int launch = 3) {
   static const uint32_t slots = [] {
     int dev = 0, cus = 0, wgs = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -661,8 +664,10 @@ static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, bool first = fa
   }();
   const uint64_t fit = inflated_chunk >> 16;           // members of the maximum size (64 KiB) that fit the chunk
   if (!slots || fit < slots) return kMaxBlocksPerChunk;
-  if (first) return slots;                             // the first launch is one round: the device starts after 1/4 of the copy
-  return (uint32_t)std::min<uint64_t>(kMaxBlocksPerChunk, fit / slots * slots);
+  const uint64_t full = std::min<uint64_t>(kMaxBlocksPerChunk, fit / slots * slots);
+  if (launch <= 1) return slots;
+  if (launch == 2) return (uint32_t)std::min<uint64_t>(full, 2ull * slots);
+  return (uint32_t)full;
 }
 
 int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing) {
@@ -686,7 +691,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
     const auto tf = clk::now();
     uint32_t nb = 0;
     uint64_t ob = 0;
-    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, bgzf_members_per_launch(chunk, it == 0), c->h_blk[b], &nb, &ob);
+    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, bgzf_members_per_launch(chunk, (int)std::min(it, 3u)), c->h_blk[b], &nb, &ob);
     if (used < 0) {                                    // not a BGZF member, or a truncated one: the host path decides what it is
       HIPCHK(hipStreamSynchronize(c->copy));
       HIPCHK(hipStreamSynchronize(c->compute));
@@ -694,15 +699,20 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
     }
     if (used == 0) break;
     const uint8_t* src = img + pos;
-    parallel_pieces((uint64_t)used, [&](uint64_t o, uint64_t len) { std::memcpy(c->h_comp[b] + o, src + o, len); return 0; });
-    fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     c->timing.h2d_bytes += (uint64_t)used;
     if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));       // device buffers b were consumed
     if (timing) {
       while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
       HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
     }
-    HIPCHK(hipMemcpyAsync(c->d_comp[b], c->h_comp[b], (size_t)used, hipMemcpyHostToDevice, c->copy));
+    // pinned buffer and PCIe in pieces of 64 MiB: a piece crosses while the next is filled, so the chunk is on the device one
+    // piece after its last byte reached pinned memory
+    for (uint64_t o = 0; o < (uint64_t)used; o += 64ull << 20) {
+      const uint64_t len = std::min<uint64_t>(64ull << 20, (uint64_t)used - o);
+      parallel_pieces(len, [&](uint64_t q, uint64_t l) { std::memcpy(c->h_comp[b] + o + q, src + o + q, l); return 0; });
+      HIPCHK(hipMemcpyAsync(c->d_comp[b] + o, c->h_comp[b] + o, (size_t)len, hipMemcpyHostToDevice, c->copy));
+    }
+    fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
     if (timing) { HIPCHK(hipEventRecord(c->cp_pool[c->cp_used + 1], c->copy)); c->cp_used += 2; }
     HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
