@@ -46,10 +46,14 @@ t = time.time(); blob = zlib.compress(one.tobytes(), 6); comp_s = time.time() - 
 gz1 = os.path.join(tmp, "scfq_one_member.fq.gz")
 with gzip.open(gz1, "wb", compresslevel=6) as f: f.write(one.tobytes())
 oc = scfq.count_host(one); 
-t = time.time(); c = scfq.count_file(gz1, flags=scfq.SCFQ_TIMING); dt = time.time() - t
+# (two calls, the second reported, as for the BGZF row below: the first of a new size also grows the device buffers the context keeps)
+firsts = {}
+for it in range(2):
+    t = time.time(); c = scfq.count_file(gz1, flags=scfq.SCFQ_TIMING); dt = time.time() - t
+    firsts.setdefault("one", round(dt, 3))
 tm = scfq.last_timing()
 assert (c.reads, c.gc_bases, c.n_bases, c.bases) == (oc.reads, oc.gc_bases, oc.n_bases, oc.bases)
-row("gzip -6, one member (host inflate || H2D || scan)", inflated_bytes=one.size, gz_bytes=os.path.getsize(gz1), wall_s=round(dt, 3),
+row("gzip -6, one member (device-side inflate; compressed bytes H2D)", inflated_bytes=one.size, gz_bytes=os.path.getsize(gz1), wall_s=round(dt, 3), first_call_wall_s=firsts["one"],
     inflated_GBps=round(one.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), h2d_copy_ms=round(tm.h2d_ms, 2), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
     ingest_wall_ms=round(tm.ingest_wall_ms, 1), overlap_efficiency=round(tm.host_fill_ms / tm.ingest_wall_ms, 4))
 
@@ -61,9 +65,11 @@ blobs_gz = blobs
 gzm = os.path.join(tmp, "scfq_multi_member.fq.gz")
 with open(gzm, "wb") as f:
     for b in blobs: f.write(b)
-t = time.time(); c = scfq.count_file(gzm, flags=scfq.SCFQ_TIMING); dt = time.time() - t
+for it in range(2):
+    t = time.time(); c = scfq.count_file(gzm, flags=scfq.SCFQ_TIMING); dt = time.time() - t
+    firsts.setdefault("multi", round(dt, 3))
 check(c); tm = scfq.last_timing()
-row("gzip -6, %d concatenated 64 MiB members" % len(parts), inflated_bytes=data.size, gz_bytes=os.path.getsize(gzm), wall_s=round(dt, 3),
+row("gzip -6, %d concatenated 64 MiB members (device-side inflate)" % len(parts), inflated_bytes=data.size, gz_bytes=os.path.getsize(gzm), wall_s=round(dt, 3), first_call_wall_s=firsts["multi"],
     inflated_GBps=round(data.size / dt / 1e9, 3), host_inflate_ms=round(tm.host_fill_ms, 1), h2d_copy_ms=round(tm.h2d_ms, 2), scan_kernel_ms=round(tm.scan_kernel_ms, 3),
     ingest_wall_ms=round(tm.ingest_wall_ms, 1), overlap_efficiency=round(tm.host_fill_ms / tm.ingest_wall_ms, 4))
 # BGZF (what `bgzip` writes): 64 KiB blocks with their compressed size in the header -> block-parallel inflate

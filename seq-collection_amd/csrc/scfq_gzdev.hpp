@@ -195,6 +195,8 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
       (rc = gz_grow(&g.h_crc, &g.hcrc_cap, 4 * (16 + crc_tiles_max), true)))
     return rc;
   uint8_t* const d_out = g.d_out + kStagePad;
+  const double alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
+  if (verbose && alloc_ms > 1.0) std::fprintf(stderr, "scfq gzdev: buffers grown in %.1f ms (kept in the context for the next call)\n", alloc_ms);
   const uint64_t pin_chunk = 64ull << 20;
   rc = ensure_staging(c, pin_chunk, true);
   if (rc) return rc;
