@@ -74,6 +74,14 @@ struct GzDevBuffers {      // grow-only, kept in the context between calls (a dr
   hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
 };
 
+// The buffers of the device gzip path are per DEVICE, not per context, and one file at a time goes through them: a file is
+// inflated at tens of GB/s with the whole device, so sessions that arrive together (`sc fq-count --jobs=8 *.fq.gz`) queue here
+// instead of each growing its own tens of GB of buffers and sharing the CUs among eight sets of decode waves.  (What eight
+// jobs over eight 64 MB files cost against one — 0.85 against 0.4-0.5 s — is the set-up of eight contexts, pinned staging
+// buffers above all, not the inflate: the figure is the same with and without this queue.)
+struct GzShared { std::mutex mu; GzDevBuffers buf; };
+inline GzShared& gz_shared(int dev) { static GzShared g[64]; return g[dev & 63]; }
+
 struct Ctx {
   int dev = -1;
   int n_cu = 256;
@@ -119,7 +127,6 @@ struct Ctx {
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
   hipEvent_t ev_caller = nullptr;      // orders the caller's stream (scfq_opts.wait_stream) before the private ones
   scfq_timing timing{};
-  GzDevBuffers gz;                     // device-side inflate of ordinary gzip members (scfq_gzdev.hpp)
   std::mutex mu;   // one counting session at a time per device context
 };
 
@@ -1149,7 +1156,7 @@ int scfq_shutdown(void) {
       if (c->h_comp[b]) (void)hipHostFree(c->h_comp[b]);
     }
     if (c->d_dstatus) (void)hipFree(c->d_dstatus);
-    gz_free(&c->gz);
+    { GzShared& gs = gz_shared(c->dev); std::lock_guard<std::mutex> lk(gs.mu); gz_free(&gs.buf); }
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

@@ -93,7 +93,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   static const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
   const long h0 = scfq_gzfast::member_header(img, (size_t)fsize);
   if (h0 <= 0 || fsize < 64) return kFallbackToHost;
-  GzDevBuffers& g = c->gz;
+  GzDevBuffers& g = gz_shared(c->dev).buf;             // (the caller holds its mutex)
   int rc;
   if (!g.s_search) HIPCHK(hipStreamCreateWithFlags(&g.s_search, hipStreamNonBlocking));
   for (int b = 0; b < 3; ++b) if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
@@ -670,13 +670,16 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   return SCFQ_OK;
 }
 
-// every stream of the path is idle when this returns, whatever the outcome: the buffers belong to the context's next caller
+// One file at a time per device (gz_shared); every stream of the path is idle when this returns, whatever the outcome — the
+// scan of the last batch included, which reads the shared output buffer: the buffers belong to the next caller.
 int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing) {
+  GzShared& gs = gz_shared(c->dev);
+  std::lock_guard<std::mutex> lk(gs.mu);
   const int rc = ingest_gz_device_batches(c, img, fsize, flags, timing);
-  GzDevBuffers& g = c->gz;
+  GzDevBuffers& g = gs.buf;
   if (c->copy) (void)hipStreamSynchronize(c->copy);
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
   for (int b = 0; b < 2; ++b) if (g.s_decode[b]) (void)hipStreamSynchronize(g.s_decode[b]);
-  if (rc != SCFQ_OK && c->compute) (void)hipStreamSynchronize(c->compute);
+  if (c->compute) (void)hipStreamSynchronize(c->compute);
   return rc;
 }
