@@ -1,7 +1,8 @@
 #!/bin/bash
 # Soak of the device inflate paths: the same BGZF file and the same single-member gzip counted over and over, one and eight host
 # threads (context pool: every session has its own buffers), every result compared with the generator's tally, and every count
-# of the gzip file must have stayed on the device (a CRC or chain failure falls back to the host readers silently otherwise).
+# of the gzip files (one member; many members) must have stayed on the device (a CRC or chain failure falls back to the host
+# readers silently otherwise) — also with eight threads at once, which queue for the device's one set of gzip buffers.
 # usage: scripts/gpu_soak_inflate.sh [inflated bytes, default 5e8] [repetitions, default 30]     (GPU box)
 set -e
 N=${1:-5e8}; REPS=${2:-30}
@@ -34,7 +35,11 @@ for c0 in cuts: crc = zlib.crc32(data[c0:c0 + step], crc)
 with open("/tmp/soak_gz.fq.gz", "wb") as f:
     f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03"); [f.write(b) for b in members]
     f.write(int(crc & 0xFFFFFFFF).to_bytes(4, "little") + int(data.size & 0xFFFFFFFF).to_bytes(4, "little"))
-gz_bytes = os.path.getsize("/tmp/soak_gz.fq.gz")
+# the same bytes as many members (every further member's first block is found in the gap round)
+def whole_member(i):
+    co = zlib.compressobj(6, zlib.DEFLATED, 31); return co.compress(data[cuts[i]:cuts[i] + step].tobytes()) + co.flush()
+with ThreadPoolExecutor(16) as ex:
+    open("/tmp/soak_multi.fq.gz", "wb").write(b"".join(ex.map(whole_member, range(len(cuts)))))
 bad = []
 def run(tag, path, reps, compressed_over_pcie):
     for r in range(reps):
@@ -44,8 +49,10 @@ def run(tag, path, reps, compressed_over_pcie):
         if compressed_over_pcie and not (t.h2d_bytes < 0.5 * data.size): bad.append((tag, r, "host path", t.h2d_bytes))
 run("bgzf", "/tmp/soak_bgzf.fq.gz", $REPS, True)
 run("gzip", "/tmp/soak_gz.fq.gz", $REPS, True)
-print("one thread: %d + %d counts, problems: %s" % ($REPS, $REPS, bad))
-ts = [threading.Thread(target=run, args=("t%d" % k, "/tmp/soak_gz.fq.gz" if k & 1 else "/tmp/soak_bgzf.fq.gz", max(2, $REPS // 6), False)) for k in range(8)]
+run("members", "/tmp/soak_multi.fq.gz", $REPS, True)
+print("one thread: 3 x %d counts, problems: %s" % ($REPS, bad))
+files = ["/tmp/soak_bgzf.fq.gz", "/tmp/soak_gz.fq.gz", "/tmp/soak_multi.fq.gz"]
+ts = [threading.Thread(target=run, args=("t%d" % k, files[k % 3], max(2, $REPS // 6), k % 3 != 0)) for k in range(8)]
 [t.start() for t in ts]; [t.join() for t in ts]
 print("eight threads, problems:", bad)
 assert not bad
