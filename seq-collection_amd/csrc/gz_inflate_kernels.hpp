@@ -45,25 +45,9 @@ constexpr uint32_t kSyncThreads = 256;
 constexpr uint32_t kSyncChunkBits = 32768;      // positions examined between two looks at the survivor list
 constexpr uint32_t kSyncListCap = 1024;
 
-// header of a dynamic block at `bit`: cheap tests first (one lane per position), result = survives / not
-template <typename WP>
-__device__ __forceinline__ bool sync_quick(WP words, uint64_t bit) {
-  const uint64_t w = bits64_at(words, bit);
-  if (((w >> 1) & 3u) != 2u) return false;                 // BTYPE 10
-  if (((w >> 3) & 31u) > 29u) return false;                // HLIT <= 286 - 257
-  if (((w >> 8) & 31u) > 29u) return false;                // HDIST <= 30 - 1
-  const uint32_t hclen = (uint32_t)((w >> 13) & 15u) + 4u;
-  const uint64_t w2 = bits64_at(words, bit + 17);          // the 3-bit code-length code lengths
-  uint32_t kraft = 0;
-  for (uint32_t k = 0; k < hclen; ++k) {
-    const uint32_t l = (uint32_t)(w2 >> (3u * k)) & 7u;
-    kraft += l ? (128u >> l) : 0u;
-  }
-  return kraft == 128u;                                    // complete (zlib rejects anything else for this code)
-}
-
-// The cheap tests of sync_quick for 32 consecutive positions at once (bit i of the result: position bit + i may be a header):
-// BTYPE, HLIT and HDIST are fixed bit patterns, so they are shifts and ANDs of the 64 bits at `bit` (the fields of position
+// A dynamic block's header at position p: BFINAL, BTYPE = 10, HLIT <= 29, HDIST <= 29, HCLEN, then HCLEN + 4 three-bit code
+// lengths that must form a complete code.  The cheap tests for 32 consecutive positions at once (bit i of the result: position
+// bit + i may be a header): BTYPE, HLIT and HDIST are fixed bit patterns, so they are shifts and ANDs of the 64 bits at `bit` (the fields of position
 // bit + 31 end at bit + 47).  About a fifth of the positions survive; only those pay for the Kraft sum.
 template <typename WP>
 __device__ __forceinline__ uint32_t sync_fields32(WP words, uint64_t bit) {
