@@ -73,7 +73,7 @@ __device__ __forceinline__ bool sync_kraft(WP words, uint64_t bit) {
 // the rest of the header: decode the HLIT + HDIST code lengths with the code-length code, ask for a complete literal/length
 // code with an end-of-block code and a distance code zlib accepts.  Everything lives in registers (counts and the symbols
 // sorted by code length are packed into 64-bit words), and a candidate is dropped the moment one of its codes is
-// over-subscribed: random bits get there within a few dozen lengths, so the survivors of sync_quick cost little.
+// over-subscribed: random bits get there within a few dozen lengths, so the survivors of the quick tests cost little.
 template <typename WP>
 __device__ inline bool sync_deep(WP words, uint64_t bit, uint64_t end_bit) {
   const uint64_t w = bits64_at(words, bit);
