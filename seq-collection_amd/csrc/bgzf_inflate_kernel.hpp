@@ -816,7 +816,7 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
     const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)isize, 0x00020000);
     auto xpow = [&](uint32_t nbytes) {                  // x^(8 nbytes) mod P, nbytes < 2^20
       uint32_t p = 1u << 31;
-      for (uint32_t k = 0; nbytes; ++k, nbytes >>= 1)
+      for (uint32_t k = 0; nbytes && k < 20u; ++k, nbytes >>= 1)      // (the host's planner admits members of at most 64 KiB)
         if (nbytes & 1u) p = gf2_mulmod(crc_xp[k], p);
       return p;
     };
