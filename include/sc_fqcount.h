@@ -165,7 +165,11 @@ typedef struct scfq_comm scfq_comm;
 #define SCFQ_COMM_TCP  1         /* host sockets through rank 0: explicit opt-in for hosts without a common RCCL fabric and for
                                     CPU-only tests of the multi-process path; needs no device; never chosen by the library itself */
 
-/* One process per GPU, the host distributes the id itself (rank 0 creates it, every rank passes the same bytes): */
+/* STDOUT: RCCL prints a version banner on stdout when a process's first communicator comes up. While any scfq_comm_init_* call
+ * is in flight (communicator creation plus one warm-up collective) descriptor 1 of the process points at descriptor 2, and what
+ * OTHER threads of the host write to stdout in that window lands on stderr. A host that prints from several threads creates
+ * its communicators before its first row: scfq_prepare() below does that for the in-process multi-device path.
+ * One process per GPU, the host distributes the id itself (rank 0 creates it, every rank passes the same bytes): */
 int scfq_comm_unique_id(void* id, uint64_t cap /* >= SCFQ_COMM_ID_BYTES */);
 int scfq_comm_init_rank(const void* id, int world, int rank, int device, int timeout_ms, scfq_comm** out);
 /* One process per GPU, the library distributes the id: rank 0 listens on host:port (IPv4 name or address, NULL = 127.0.0.1),
@@ -176,6 +180,9 @@ int scfq_comm_init_rendezvous(const char* host, int port, int world, int rank, i
 int scfq_comm_init_all(int n, const int32_t* device_ids, int timeout_ms, scfq_comm** out);
 int scfq_comm_world(const scfq_comm* c);
 int scfq_comm_rank(const scfq_comm* c);
+/* 1 once an exchange on this communicator failed or timed out: every later call fails fast with SCFQ_ERCCL (an answer that
+ * arrives after its deadline is dropped, never handed to a later exchange); destroy it and create a new one. */
+int scfq_comm_is_broken(const scfq_comm* c);
 const char* scfq_comm_transport(const scfq_comm* c);   /* "RCCL 2.x.y" | "tcp"; thread-local static storage */
 /* folded = P_0 (+) P_1 (+) ... (+) P_{world-1}, identical on every rank. hist: NULL on every rank, or uint64_t[SCFQ_HIST_WORDS]
  * on every rank (then hist_folded receives the folded class histograms). */
@@ -189,6 +196,12 @@ int scfq_comm_exchange_finish(scfq_comm* c, scfq_partial* folded, uint64_t* hist
 int scfq_comm_allgather_u64(scfq_comm* c, const uint64_t* mine, uint32_t words, uint64_t* all, int timeout_ms);
 int scfq_comm_destroy(scfq_comm* c);
 const char* scfq_comm_error_detail(void);   /* static, thread-local */
+
+/* Optional warm-up for a host that is about to call scfq_count_file / scfq_count_buffer with these opts: creates the device
+ * context(s) (streams, pinned staging) and, for opts->n_devices > 1 with distinct devices, the in-process RCCL communicators —
+ * i.e. everything that would otherwise happen inside the first counting call, including the stdout window described above.
+ * `sc fq-count` calls it before its first row. Safe to call more than once; returns SCFQ_OK or what the set-up returned. */
+int scfq_prepare(const scfq_opts* opts);
 
 /* fq_count of ONE file by all ranks of a communicator: rank r scans bytes [size*r/world, size*(r+1)/world) of `path` — cut at
  * arbitrary byte offsets, one byte of look-behind — on the current device (or opts->device_ids[0]), the partials are

@@ -404,6 +404,10 @@ int main(int argc, char** argv) {
 
   if (header) std::printf("%s\n", output_header(kHeader, basename, absolute).c_str());   // sc.nim:110-111
   else if (files.empty()) quit_error("No FASTQ specified", 3);                           // sc.nim:112-113
+  // several devices in one process: their RCCL communicators come up BEFORE the first row (while one is created the library
+  // points descriptor 1 at descriptor 2 — RCCL prints a banner on stdout — and a row printed in that window would be lost to
+  // stderr); a failure here is reported by the first counting call
+  if (devices.size() > 1 && !files.empty()) (void)scfq_prepare(&opts);
   if (jobs <= 1 || files.size() <= 1) {
     for (const auto& f : files) fq_count_emit(fq_count_compute(f, basename, absolute, opts, stats));   // sc.nim:114-116
   } else {

@@ -498,10 +498,17 @@ int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_part
     return SCFQ_OK;
   }
   std::vector<scfq_comm*> comms;
+  std::vector<int> key(o.device_ids, o.device_ids + nd);
   {
     std::lock_guard<std::mutex> lk(g_comm_mu);
-    std::vector<int> key(o.device_ids, o.device_ids + nd);
     auto it = g_comms.find(key);
+    if (it != g_comms.end()) {
+      // a set with a broken member (an exchange timed out) is given up here, so that one stuck collective does not fail
+      // every later multi-device count of the process: the next lines build a fresh set
+      bool broken = false;
+      for (scfq_comm* c : it->second) broken = broken || scfq_comm_is_broken(c);
+      if (broken) { for (scfq_comm* c : it->second) scfq_comm_destroy(c); g_comms.erase(it); it = g_comms.end(); }
+    }
     if (it == g_comms.end()) {
       std::vector<scfq_comm*> cs(nd, nullptr);
       const int rc = scfq_comm_init_all(nd, o.device_ids, 0, cs.data());
@@ -510,22 +517,31 @@ int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_part
     }
     comms = it->second;
   }
+  if (!p) return SCFQ_OK;               // scfq_prepare(): only the communicators were wanted
   static std::mutex one_at_a_time;      // exchanges of concurrent sessions on the same communicators must not interleave
   std::lock_guard<std::mutex> lk(one_at_a_time);
-  for (int d = 0; d < nd; ++d) {
-    const int rc = scfq_comm_exchange_start(comms[d], &parts[d], want_hist ? hists[d].data() : nullptr, 0);
-    if (rc) return rc;
-  }
   int rc = SCFQ_OK;
+  int started = 0;
+  for (int d = 0; d < nd && !rc; ++d) {
+    rc = scfq_comm_exchange_start(comms[d], &parts[d], want_hist ? hists[d].data() : nullptr, 0);
+    if (!rc) ++started;
+  }
+  if (rc) std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail());
   std::vector<uint64_t> h2(want_hist ? SCFQ_HIST_WORDS : 0);
-  for (int d = 0; d < nd; ++d) {
+  for (int d = 0; d < started; ++d) {
     scfq_partial q;
     const int r = scfq_comm_exchange_finish(comms[d], d == 0 ? p : &q, want_hist ? (d == 0 ? hist : h2.data()) : nullptr, 0);
     if (r && !rc) { rc = r; std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); }
-    if (!r && d > 0 && (std::memcmp(&q, p, sizeof q) != 0 || (want_hist && std::memcmp(h2.data(), hist, SCFQ_HIST_WORDS * sizeof(uint64_t)) != 0))) {
+    if (!r && !rc && d > 0 && (std::memcmp(&q, p, sizeof q) != 0 || (want_hist && std::memcmp(h2.data(), hist, SCFQ_HIST_WORDS * sizeof(uint64_t)) != 0))) {
       std::snprintf(g_err, sizeof g_err, "exchange: rank %d folded a different result than rank 0", d);
       rc = SCFQ_ERCCL;
     }
+  }
+  if (rc) {
+    // whatever went wrong, this set is not used again (a started exchange that was never finished would answer the next one)
+    std::lock_guard<std::mutex> lk2(g_comm_mu);
+    auto it = g_comms.find(key);
+    if (it != g_comms.end() && it->second == comms) { for (scfq_comm* c : comms) scfq_comm_destroy(c); g_comms.erase(it); }
   }
   return rc;
 }
@@ -1125,6 +1141,29 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
   if (local) return local;
   if (all.reserved[0]) { std::snprintf(g_err, sizeof g_err, "another rank failed to count its shard"); return SCFQ_EIO; }
   return scfq_partial_finalize(&all, want_hist ? hist_all.data() : nullptr, out);
+}
+
+int scfq_prepare(const scfq_opts* opts) {
+  int rc = check_opts(opts);
+  if (rc) return rc;
+  const scfq_opts o = opts_copy(opts);
+  const int nd = std::max(1, o.n_devices);
+  int prev = 0;
+  HIPCHK(hipGetDevice(&prev));
+  for (int d = 0; d < nd && !rc; ++d) {
+    if (o.n_devices >= 1 && hipSetDevice(o.device_ids[d]) != hipSuccess) { rc = SCFQ_EHIP; break; }
+    Ctx* c = nullptr;
+    SessionLock sl;
+    rc = get_ctx(&c, sl);
+    if (!rc) rc = ensure_staging(c, kDefaultChunk, true);
+  }
+  (void)hipSetDevice(prev);
+  if (!rc && o.n_devices > 1 && !exchange_on_host(o.device_ids, o.n_devices)) {
+    const std::vector<scfq_partial> none;
+    const std::vector<std::vector<uint64_t>> none_h;
+    rc = fold_device_partials(o, o.n_devices, none, none_h, false, nullptr, nullptr);
+  }
+  return rc;
 }
 
 int scfq_shutdown(void) {

@@ -30,6 +30,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -145,6 +146,18 @@ bool resolve(const char* host, int port, sockaddr_in* sa) {
 struct Star {
   int world = 1, rank = 0;
   std::vector<int> fds;
+  // shared secret of one launch (FNV-1a of SCFQ_RENDEZVOUS_TOKEN; 0 when unset): a process that does not know it cannot take a
+  // rank's slot.  Rank 0 binds to 127.0.0.1 unless the host names another address explicitly.
+  static uint64_t token() {
+    static const uint64_t t = [] {
+      const char* e = std::getenv("SCFQ_RENDEZVOUS_TOKEN");
+      if (!e || !*e) return (uint64_t)0;
+      uint64_t h = 1469598103934665603ull;
+      for (; *e; ++e) { h ^= (uint8_t)*e; h *= 1099511628211ull; }
+      return h;
+    }();
+    return t;
+  }
   ~Star() { close_all(); }
   void close_all() { for (int& f : fds) if (f >= 0) { close(f); f = -1; } }
 
@@ -174,9 +187,12 @@ struct Star {
         const int fd = accept(ls, nullptr, nullptr);
         if (fd < 0) continue;
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-        int32_t hello[2] = {0, 0};
-        if (!io_all(fd, hello, sizeof hello, false, deadline) || hello[0] != 0x53434651 || hello[1] <= 0 || hello[1] >= world ||
-            fds[hello[1]] >= 0) {
+        // (a connection that is not one of ours — a port scan, a health check — gets one second to say hello, not the whole
+        // deadline; with SCFQ_RENDEZVOUS_TOKEN set in the launcher's environment the hello must carry that token too)
+        int32_t hello[4] = {0, 0, 0, 0};
+        const auto hello_deadline = std::min(deadline, clk::now() + std::chrono::seconds(1));
+        if (!io_all(fd, hello, sizeof hello, false, hello_deadline) || hello[0] != 0x53434651 || hello[1] <= 0 || hello[1] >= world ||
+            hello[2] != (int32_t)(uint32_t)token() || hello[3] != (int32_t)(uint32_t)(token() >> 32) || fds[hello[1]] >= 0) {
           close(fd);     // not one of ours (or a duplicate rank): ignore it and keep waiting
           continue;
         }
@@ -191,7 +207,7 @@ struct Star {
       if (fd < 0) { set_err("socket: %s", std::strerror(errno)); return false; }
       if (connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof sa) == 0) {
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-        int32_t hello[2] = {0x53434651, rank};
+        int32_t hello[4] = {0x53434651, rank, (int32_t)(uint32_t)token(), (int32_t)(uint32_t)(token() >> 32)};
         if (!io_all(fd, hello, sizeof hello, true, deadline)) { close(fd); return false; }
         fds[0] = fd;
         return true;
@@ -227,31 +243,52 @@ struct Star {
 
 constexpr uint32_t kMaxWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;   // 1056: partial | hist[4][256]
 
+// A caller waits a little longer than the worker's own deadline, so that the worker's message (which says WHY) normally wins.
+// SCFQ_COMM_TAKE_SLACK_MS / SCFQ_COMM_TEST_DELAY_MS (the worker sleeps before every gather) exist for the test of the case
+// where it does not: a worker stuck inside the runtime whose answer arrives after its caller gave up.
+int take_slack_ms() { static const int v = [] { const char* e = std::getenv("SCFQ_COMM_TAKE_SLACK_MS"); return e ? std::atoi(e) : 5000; }(); return v; }
+int test_delay_ms() { static const int v = [] { const char* e = std::getenv("SCFQ_COMM_TEST_DELAY_MS"); return e ? std::atoi(e) : 0; }(); return v; }
+int caller_wait_ms(int timeout_ms) { return timeout_ms > 0 ? timeout_ms + take_slack_ms() : 300000 + take_slack_ms(); }
+
 // RCCL 2.27 prints a version banner on STDOUT when the first communicator of a process comes up; this library never
 // writes to stdout (a host's stdout is its TSV, src/fq_count.nim:53).  While a communicator is being created, and until its
-// first collective has run, descriptor 1 points at descriptor 2.
+// first collective has run, descriptor 1 points at descriptor 2.  The redirect is REFERENCE COUNTED: the first creator in
+// flight installs it, the last one restores descriptor 1, and the mutex only guards that bookkeeping — it is never held across
+// the blocking ncclCommInitRank, so two threads of one process may bring up two ranks of the same world at the same time
+// (thread per GPU).  What another thread of the host writes to stdout inside that window lands on stderr: hosts that print
+// rows from several threads create their communicators first (scfq_prepare(), which `sc fq-count --devices=a,b` calls before
+// its first row) — include/sc_fqcount.h says so next to scfq_comm_init_*.
 struct StdoutToStderr {
   static std::mutex& mu() { static std::mutex m; return m; }
-  std::unique_lock<std::mutex> lk{mu()};
-  int saved = -1;
+  static int& users() { static int n = 0; return n; }
+  static int& saved() { static int fd = -1; return fd; }
   StdoutToStderr() {
-    std::fflush(stdout);
-    saved = dup(1);
-    if (saved >= 0) dup2(2, 1);
+    std::lock_guard<std::mutex> lk(mu());
+    if (users()++ == 0) {
+      std::fflush(stdout);
+      saved() = dup(1);
+      if (saved() >= 0) dup2(2, 1);
+    }
   }
   ~StdoutToStderr() {
-    if (saved >= 0) { std::fflush(stdout); dup2(saved, 1); close(saved); }
+    std::lock_guard<std::mutex> lk(mu());
+    if (--users() == 0 && saved() >= 0) { std::fflush(stdout); dup2(saved(), 1); close(saved()); saved() = -1; }
   }
+  StdoutToStderr(const StdoutToStderr&) = delete;
+  StdoutToStderr& operator=(const StdoutToStderr&) = delete;
 };
 
 struct Job {
   enum Kind { kInitRank, kAdopt, kGather, kStop } kind = kGather;
+  uint64_t seq = 0;            // every job carries a ticket and its answer carries the same one: an answer that arrives after
+                               // its caller gave up (deadline) is dropped instead of being handed to the NEXT caller
   std::vector<uint64_t> row;
   bool with_hist = false;
   int timeout_ms = 0;
   ncclUniqueId id{};
 };
 struct Done {
+  uint64_t seq = 0;
   int rc = SCFQ_OK;
   std::vector<uint64_t> all;   // world x words
   uint32_t words = 0;
@@ -276,6 +313,8 @@ struct scfq_comm {
   std::deque<Done> out;
   std::atomic<bool> broken{false};
   uint64_t exchanges = 0;
+  uint64_t next_seq = 1;       // (under mu) ticket of the next job posted
+  std::deque<uint64_t> waiting;   // (under mu) tickets of posted jobs nobody has collected yet, oldest first
 
   int hip_fail(const char* what, hipError_t e, Done* d) {
     char b[256];
@@ -341,7 +380,9 @@ struct scfq_comm {
         in.pop_front();
       }
       if (j.kind == Job::kStop) return;
+      if (j.kind == Job::kGather && test_delay_ms() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(test_delay_ms()));
       Done d;
+      d.seq = j.seq;
       d.words = (uint32_t)j.row.size();
       d.with_hist = j.with_hist;
       if (j.kind == Job::kInitRank || (j.kind == Job::kAdopt && transport == SCFQ_COMM_RCCL)) {
@@ -381,14 +422,28 @@ struct scfq_comm {
   }
 
   void post(Job&& j) {
-    { std::lock_guard<std::mutex> lk(mu); in.push_back(std::move(j)); }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      j.seq = next_seq++;
+      if (j.kind != Job::kStop) waiting.push_back(j.seq);
+      in.push_back(std::move(j));
+    }
     cv_in.notify_one();
   }
 
-  // oldest finished job; SCFQ_ERCCL when the deadline passes first (the communicator is then marked broken)
+  // the answer to the OLDEST job nobody has collected yet; SCFQ_ERCCL when the deadline passes first.  The communicator is then
+  // marked broken and that job's ticket is retired: when its answer arrives after all it is dropped, so the next start / finish
+  // pair can never be handed the previous exchange's rows.
   int take(Done* d, int timeout_ms) {
     std::unique_lock<std::mutex> lk(mu);
-    const bool ok = cv_out.wait_for(lk, std::chrono::milliseconds(timeout_ms > 0 ? timeout_ms : 300000), [&] { return !out.empty(); });
+    if (waiting.empty()) { set_err("no exchange in flight on this communicator (rank %d of %d)", rank, world); return SCFQ_EARG; }
+    const uint64_t want = waiting.front();
+    auto mine = [&] {
+      while (!out.empty() && out.front().seq < want) out.pop_front();      // answers whose callers gave up
+      return !out.empty() && out.front().seq == want;
+    };
+    const bool ok = cv_out.wait_for(lk, std::chrono::milliseconds(timeout_ms > 0 ? timeout_ms : 300000), mine);
+    waiting.pop_front();
     if (!ok) {
       broken = true;
       set_err("no answer from the exchange worker within %d ms (rank %d of %d): a rank is missing or the collective is stuck", timeout_ms, rank, world);
@@ -456,7 +511,7 @@ int start_and_wait(scfq_comm* c, Job&& j, int timeout_ms) {
   c->worker = std::thread([c] { c->run(); });
   c->post(std::move(j));
   Done d;
-  return c->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);     // the worker's own deadline fires first and says why
+  return c->take(&d, caller_wait_ms(timeout_ms));     // the worker's own deadline fires first and says why
 }
 
 }  // namespace
@@ -562,7 +617,7 @@ int scfq_comm_init_all(int n, const int32_t* device_ids, int timeout_ms, scfq_co
   int rc = SCFQ_OK;
   for (int k = 0; k < n; ++k) {
     Done d;
-    const int rk = out[k]->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);
+    const int rk = out[k]->take(&d, caller_wait_ms(timeout_ms));
     if (rk) { out[k]->broken = true; if (!rc) rc = rk; }
   }
   if (rc) {
@@ -571,6 +626,7 @@ int scfq_comm_init_all(int n, const int32_t* device_ids, int timeout_ms, scfq_co
   return rc;
 }
 
+int scfq_comm_is_broken(const scfq_comm* c) { return (c && c->broken) ? 1 : 0; }
 int scfq_comm_world(const scfq_comm* c) { return c ? c->world : SCFQ_EARG; }
 int scfq_comm_rank(const scfq_comm* c) { return c ? c->rank : SCFQ_EARG; }
 const char* scfq_comm_transport(const scfq_comm* c) {
@@ -585,12 +641,13 @@ const char* scfq_comm_transport(const scfq_comm* c) {
 
 int scfq_comm_allgather_u64(scfq_comm* c, const uint64_t* mine, uint32_t words, uint64_t* all, int timeout_ms) {
   if (!c || !mine || !all || words == 0 || words > kMaxWords) return SCFQ_EARG;
+  if (c->broken) { set_err("communicator is broken (an earlier exchange failed or timed out): destroy it and create a new one"); return SCFQ_ERCCL; }
   Job j;
   j.row.assign(mine, mine + words);
   j.timeout_ms = timeout_ms;
   c->post(std::move(j));
   Done d;
-  const int rc = c->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);
+  const int rc = c->take(&d, caller_wait_ms(timeout_ms));
   if (rc) return rc;
   std::memcpy(all, d.all.data(), d.all.size() * sizeof(uint64_t));
   return SCFQ_OK;
@@ -598,6 +655,7 @@ int scfq_comm_allgather_u64(scfq_comm* c, const uint64_t* mine, uint32_t words, 
 
 int scfq_comm_exchange_start(scfq_comm* c, const scfq_partial* mine, const uint64_t* hist, int timeout_ms) {
   if (!c || !mine) return SCFQ_EARG;
+  if (c->broken) { set_err("communicator is broken (an earlier exchange failed or timed out): destroy it and create a new one"); return SCFQ_ERCCL; }
   Job j;
   j.with_hist = hist != nullptr;
   j.row.resize(SCFQ_PARTIAL_WORDS + (hist ? SCFQ_HIST_WORDS : 0));
@@ -612,8 +670,12 @@ int scfq_comm_exchange_start(scfq_comm* c, const scfq_partial* mine, const uint6
 
 int scfq_comm_exchange_finish(scfq_comm* c, scfq_partial* folded, uint64_t* hist_folded, int timeout_ms) {
   if (!c || !folded) return SCFQ_EARG;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->broken && c->waiting.empty()) { set_err("communicator is broken (an earlier exchange failed or timed out)"); return SCFQ_ERCCL; }
+  }
   Done d;
-  const int rc = c->take(&d, timeout_ms > 0 ? timeout_ms + 5000 : 305000);
+  const int rc = c->take(&d, caller_wait_ms(timeout_ms));
   if (rc) return rc;
   return fold_rows(d, c->world, folded, hist_folded);
 }

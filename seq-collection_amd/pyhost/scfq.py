@@ -38,7 +38,7 @@ EXPORTS = [
     "scfq_device_free", "scfq_meta_header", "scfq_meta_file_tsv", "scfq_debug_bgzf_inflate",
     "scfq_set_wait_stream", "scfq_get_wait_stream", "scfq_count_file_sharded",
     "scfq_comm_unique_id", "scfq_comm_init_rank", "scfq_comm_init_rendezvous", "scfq_comm_init_all", "scfq_comm_world",
-    "scfq_comm_rank", "scfq_comm_transport", "scfq_comm_exchange", "scfq_comm_exchange_start", "scfq_comm_exchange_finish",
+    "scfq_comm_rank", "scfq_comm_is_broken", "scfq_prepare", "scfq_comm_transport", "scfq_comm_exchange", "scfq_comm_exchange_start", "scfq_comm_exchange_finish",
     "scfq_comm_allgather_u64", "scfq_comm_destroy", "scfq_comm_error_detail",
 ]
 
@@ -157,6 +157,8 @@ def lib():
         L.scfq_comm_init_all.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, pvp]
         L.scfq_comm_world.argtypes = [vp]
         L.scfq_comm_rank.argtypes = [vp]
+        L.scfq_comm_is_broken.argtypes = [vp]
+        L.scfq_prepare.argtypes = [ctypes.POINTER(Opts)]
         L.scfq_comm_transport.argtypes = [vp]
         L.scfq_comm_transport.restype = ctypes.c_char_p
         L.scfq_comm_exchange.argtypes = [vp, ctypes.POINTER(Partial), vp, ctypes.POINTER(Partial), vp, ctypes.c_int]
@@ -302,6 +304,7 @@ class Comm:
     world = property(lambda self: lib().scfq_comm_world(self.h))
     rank = property(lambda self: lib().scfq_comm_rank(self.h))
     transport = property(lambda self: lib().scfq_comm_transport(self.h).decode())
+    broken = property(lambda self: bool(lib().scfq_comm_is_broken(self.h)))
 
     def exchange(self, partial, hist=None, timeout_ms=0):
         out = Partial()

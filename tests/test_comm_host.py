@@ -146,6 +146,52 @@ def test_stuck_exchange_times_out(scfq):
     assert again and again[0].startswith("again rc=%d" % scfq.SCFQ_ERCCL), msgs
 
 
+def _late_answer_worker(q):
+    os.environ["SCFQ_COMM_TEST_DELAY_MS"] = "1200"      # the worker "hangs" for 1.2 s in every gather
+    os.environ["SCFQ_COMM_TAKE_SLACK_MS"] = "50"        # and the caller gives up 50 ms after the exchange's own deadline
+    sys.path.insert(0, os.path.join(PKG, "pyhost"))
+    import scfq
+    comm = scfq.Comm.init_rendezvous(None, 5000, 1, 0, transport=scfq.SCFQ_COMM_TCP, timeout_ms=5000)
+    first = scfq.identity()
+    first.nl, first.bytes = 3, 1111
+    try:
+        comm.exchange(first, timeout_ms=100)
+        q.put("first: no error")
+    except scfq.ScfqError as e:
+        q.put("first rc=%d" % e.rc)
+    q.put("broken=%d" % comm.broken)
+    time.sleep(1.6)             # the late answer to the FIRST exchange is in the queue by now
+    second = scfq.identity()
+    second.nl, second.bytes = 5, 2222
+    t0 = time.time()
+    try:
+        got = comm.exchange(second, timeout_ms=100)
+        q.put("second: answered with bytes=%d" % got.bytes)      # 1111 here would be the previous exchange's rows
+    except scfq.ScfqError as e:
+        q.put("second rc=%d in %.2fs" % (e.rc, time.time() - t0))
+    try:
+        got = comm.finish(timeout_ms=100)
+        q.put("stray finish: answered with bytes=%d" % got.bytes)
+    except scfq.ScfqError as e:
+        q.put("stray finish rc=%d" % e.rc)
+    comm.destroy()
+
+
+def test_late_answer_is_never_handed_to_the_next_exchange(scfq):
+    """An exchange whose caller gave up at its deadline leaves an answer behind when the worker completes after all: that
+    answer must be dropped — the next start / finish pair may fail, it may never return the previous exchange's fold with rc 0."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_late_answer_worker, args=(q,))
+    p.start()
+    msgs = [q.get(timeout=60) for _ in range(4)]
+    p.join(timeout=60)
+    assert msgs[0] == "first rc=%d" % scfq.SCFQ_ERCCL, msgs
+    assert msgs[1] == "broken=1", msgs
+    assert msgs[2].startswith("second rc=%d" % scfq.SCFQ_ERCCL) and float(msgs[2].split(" in ")[1][:-1]) < 0.5, msgs      # fails fast
+    assert msgs[3].startswith("stray finish rc="), msgs
+
+
 def test_argument_checks(scfq):
     L = scfq.lib()
     h = ctypes.c_void_p()
