@@ -269,6 +269,10 @@ int scfq_format_tsv(const scfq_counts* c, char* buf, uint64_t cap);
 const char* scfq_strerror(int rc);   /* static storage */
 const char* scfq_last_error_detail(void); /* static, thread-local: e.g. the failing HIP call */
 int  scfq_last_timing(scfq_timing* t);
+/* Device memory the library's ingest paths hold in this process (staging, inflate buffers, symbol pools): now, and the most
+ * they ever held. The buffers are kept between calls and given back by scfq_shutdown(). */
+uint64_t scfq_device_bytes_now(void);
+uint64_t scfq_device_bytes_high_water(void);
 int  scfq_device_count(void);        /* number of visible HIP devices, or negative on error */
 /* Default caller stream of THIS host thread for the entry points that take device pointers but no scfq_opts
  * (scfq_index_lines, scfq_dedup_buffer) and for calls without SCFQ_WAIT_STREAM: same contract as scfq_opts.wait_stream.

@@ -74,6 +74,9 @@ for inv in range(n_inv):
     rows.append({"invocation": inv, "process_wall_s": round(dt, 4), "buffers_ms": float(m.group(1)) if m else None,
                  "ingest_wall_ms": float(w.group(1)) if w else None, "hbm_high_water_GB": float(hw.group(1)) if hw else None})
     sys.stderr.write(json.dumps(rows[-1]) + "\n")
+    if os.environ.get("SCFQ_MEASURE_LOG"):
+        with open(os.environ["SCFQ_MEASURE_LOG"], "a") as lf:
+            lf.write("==== %s invocation %d\n%s\n" % (layout, inv, r.stderr))
 out = {"path": how, "inflated_bytes": int(data.size), "gz_bytes": os.path.getsize(path), "what": "`sc fq-count --stats FILE`, one process per invocation, back to back",
        "process_wall_s": [r["process_wall_s"] for r in rows], "first_invocation_GBps": round(data.size / rows[0]["process_wall_s"] / 1e9, 2),
        "worst_invocation_GBps": round(data.size / max(r["process_wall_s"] for r in rows) / 1e9, 2), "rows": rows}

@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <atomic>
+#include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 using clk = std::chrono::steady_clock;
 static double ms_since(clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); }
@@ -34,6 +37,66 @@ int main(int argc, char** argv) {
   CK(hipSetDevice(0));
   CK(hipFree(nullptr));
   std::printf("context up: %.1f ms\n", ms_since(t0));
+  if (argc > 2 && std::string(argv[1]) == "busy") {
+    // alloc_cost busy <GB> <GB> ...: the same allocations while the device is busy the way an ingest keeps it busy — H2D copies of
+    // 16 MiB pieces from pinned memory on one stream, a kernel that streams 4 GB on another
+    hipStream_t s_copy, s_k;
+    CK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+    void *pin = nullptr, *dst = nullptr, *work = nullptr;
+    CK(hipHostMalloc(&pin, 16u << 20, hipHostMallocDefault));
+    CK(hipMalloc(&dst, 16u << 20));
+    CK(hipMalloc(&work, (size_t)4 << 30));
+    std::atomic<bool> stop{false};
+    std::thread feeder([&] {
+      (void)hipSetDevice(0);
+      while (!stop) {
+        for (int i = 0; i < 8; ++i) (void)hipMemcpyAsync(dst, pin, 16u << 20, hipMemcpyHostToDevice, s_copy);
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s_k, (uint64_t*)work, ((size_t)4 << 30) / 8, 9ull);
+        (void)hipStreamSynchronize(s_copy);
+      }
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    double total = 0;
+    for (int i = 2; i < argc; ++i) {
+      const size_t n = (size_t)(std::atof(argv[i]) * 1e9) & ~4095ull;
+      void* p = nullptr;
+      auto t = clk::now();
+      CK(hipMalloc(&p, n));
+      const double a = ms_since(t);
+      total += a;
+      std::printf("  busy hipMalloc %7.3f GB: %9.2f ms\n", n / 1e9, a);
+    }
+    stop = true;
+    feeder.join();
+    std::printf("  all allocations under copies + kernels: %.2f ms\n", total);
+    std::fflush(stdout);
+    _exit(0);
+  }
+  if (argc > 2 && std::string(argv[1]) == "pattern") {
+    // alloc_cost pattern <GB> <GB> ...: the allocations of one process, in order, each timed; every buffer is then written once
+    // and the process exits WITHOUT freeing (what a CLI does) — run it twice back to back to see what the second process pays
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    std::vector<std::pair<void*, size_t>> bufs;
+    double total = 0;
+    for (int i = 2; i < argc; ++i) {
+      const size_t n = (size_t)(std::atof(argv[i]) * 1e9) & ~4095ull;
+      void* p = nullptr;
+      auto t = clk::now();
+      CK(hipMalloc(&p, n));
+      const double a = ms_since(t);
+      total += a;
+      std::printf("  hipMalloc %7.3f GB: %9.2f ms\n", n / 1e9, a);
+      bufs.emplace_back(p, n);
+    }
+    auto t = clk::now();
+    for (auto& b : bufs) hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, st, (uint64_t*)b.first, b.second / 8, 7ull);
+    CK(hipStreamSynchronize(st));
+    std::printf("  all allocations %.2f ms, fill of everything %.2f ms, process up for %.1f ms\n", total, ms_since(t), ms_since(t0));
+    std::fflush(stdout);
+    _exit(0);
+  }
   size_t fr = 0, tot = 0;
   CK(hipMemGetInfo(&fr, &tot));
   std::printf("free %.1f GB of %.1f GB\n", fr / 1e9, tot / 1e9);

@@ -196,10 +196,10 @@ static FileResult fq_count_compute(const std::string& fastq, bool basename, bool
     std::snprintf(js, sizeof js,
                   "{\"file\": \"%s\", \"input_bytes\": %llu, \"scan_kernel_ms\": %.4f, \"fold_kernel_ms\": %.4f, "
                   "\"scan_launches\": %llu, \"scan_GBps\": %.1f, \"hbm_peak_GBps\": 8000, \"roofline_frac\": %.4f, "
-                  "\"host_fill_ms\": %.2f, \"ingest_wall_ms\": %.2f, \"h2d_bytes\": %llu}\n",
+                  "\"host_fill_ms\": %.2f, \"ingest_wall_ms\": %.2f, \"h2d_bytes\": %llu, \"device_bytes_high_water\": %llu}\n",
                   fastq.c_str(), (unsigned long long)c.input_bytes, t.scan_kernel_ms, t.fold_kernel_ms,
                   (unsigned long long)t.scan_launches, gbs, gbs / 8000.0, t.host_fill_ms, t.ingest_wall_ms,
-                  (unsigned long long)t.h2d_bytes);
+                  (unsigned long long)t.h2d_bytes, (unsigned long long)scfq_device_bytes_high_water());
     r.extra += js;
   }
   return r;
@@ -442,6 +442,11 @@ int main(int argc, char** argv) {
     }
     for (auto& th : pool) if (th.joinable()) th.join();
   }
-  scfq_shutdown();
-  return 0;
+  // A process that is about to end does not give its device memory back piece by piece (scfq_shutdown: 40 - 50 ms of frees and
+  // stream destruction after a 10 GB .gz): the rows are out, the driver reclaims everything with the process.  SC_CLEAN_EXIT=1 keeps
+  // the orderly shutdown (leak checkers).
+  std::fflush(stdout);
+  std::fflush(stderr);
+  if (std::getenv("SC_CLEAN_EXIT")) { scfq_shutdown(); return 0; }
+  _exit(0);
 }

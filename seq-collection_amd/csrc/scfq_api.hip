@@ -16,6 +16,7 @@
 #include "scfq_pgz.hpp"
 #include "bgzf_inflate_kernel.hpp"
 #include "gz_inflate_kernels.hpp"
+#include "scfq_arena.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -24,6 +25,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -49,29 +51,60 @@ thread_local char g_err[512] = "";
     }                                                                                         \
   } while (0)
 
+// SCFQ_VERBOSE: where a call's time goes, as milliseconds since the library was loaded (process start, near enough)
+const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
+inline bool trace_on() { static const bool v = std::getenv("SCFQ_VERBOSE") != nullptr; return v; }
+inline void trace(const char* what) {
+  if (!trace_on()) return;
+  std::fprintf(stderr, "scfq t+%8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_loaded).count(), what);
+}
+// device memory the library holds for ingest (staging, inflate buffers, arenas): current and high-water, per process
+std::atomic<uint64_t> g_dev_bytes{0}, g_dev_high{0};
+inline void note_dev_bytes(int64_t delta) {
+  const uint64_t now = g_dev_bytes.fetch_add((uint64_t)delta) + (uint64_t)delta;
+  uint64_t h = g_dev_high.load();
+  while (now > h && !g_dev_high.compare_exchange_weak(h, now)) {}
+}
+
 constexpr uint64_t kDefaultChunk = 64ull << 20;
 constexpr int kStateWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS + scfq::kExtWords;   // partial | hist[4][256] | ext (K3 speculation)
 constexpr int kExtAt = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;
 
-struct GzSlot {            // one batch being decoded: symbols + its segment tables (device and pinned mirror)
-  uint16_t* d_sym = nullptr;  uint64_t sym_cap = 0;
-  uint8_t* d_meta = nullptr;  uint64_t meta_cap = 0;
-  uint8_t* h_meta = nullptr;  uint64_t hmeta_cap = 0;
+using scfq_arena::DevBuf;
+using scfq_arena::SymPool;
+struct GzSlot {            // one batch being decoded: symbols + its segment tables (device and pinned mirror: slices of GzDevBuffers' tables)
+  SymPool sym;                                            // 16-bit symbols of every segment of the batch, markers in front: chunks of 2 GB
+  uint8_t* d_meta = nullptr;
+  uint8_t* h_meta = nullptr;
 };
-struct GzDevBuffers {      // grow-only, kept in the context between calls (a driver allocation of tens of GB costs more than the inflate)
-  uint8_t* d_comp[3] = {nullptr, nullptr, nullptr};  uint64_t comp_cap[3] = {0, 0, 0};      // compressed bytes of three batches in flight
+// Kept between calls, sized by what the batches turn out to need, and never one allocation of tens of GB (scfq_arena.hpp: that was
+// 1.5 - 2.6 s of every first call in round 2).
+struct GzDevBuffers {
+  DevBuf comp[4];                                                                           // compressed bytes of the four batches in flight (copy + search one ahead of the decode)
   GzSlot slot[2];
-  uint8_t* d_pmeta[2] = {nullptr, nullptr};  uint64_t pmeta_cap[2] = {0, 0};                // chain, work lists, gap searches of a batch
-  uint8_t* h_pmeta[2] = {nullptr, nullptr};  uint64_t hpmeta_cap[2] = {0, 0};
-  uint8_t* d_out = nullptr;   uint64_t out_cap = 0;      // inflated bytes of one batch
-  uint8_t* d_win = nullptr;   uint64_t win_cap = 0;      // the window in front of every chain entry of one batch
+  uint8_t* d_tables = nullptr;  uint64_t tables_cap = 0;        // every table of both slots: one device allocation ...
+  uint8_t* h_tables = nullptr;  uint64_t htables_cap = 0;       // ... and one pinned one (+ the tile CRCs' mirror)
+  uint8_t* d_pmeta[2] = {nullptr, nullptr};                     // chain, work lists, gap searches of a batch
+  uint8_t* h_pmeta[2] = {nullptr, nullptr};
+  DevBuf out;                                             // inflated bytes of one batch (kStagePad in front)
+  DevBuf win;                                             // the window in front of every chain entry of one batch
   uint8_t* d_wcarry = nullptr; uint64_t wcarry_cap = 0;  // the window that crosses a batch border (two, alternating)
-  uint8_t* d_maps = nullptr;  uint64_t maps_cap = 0;     // window maps of the chain groups of one batch (16-bit symbols)
-  uint8_t* d_gwin = nullptr;  uint64_t gwin_cap = 0;     // the window in front of every group
-  uint8_t* d_crc = nullptr;   uint64_t crc_cap = 0;      // status words, then the tile CRCs of the whole file
-  uint8_t* h_crc = nullptr;   uint64_t hcrc_cap = 0;
+  DevBuf maps;                                            // window maps of the chain groups of one batch (16-bit symbols)
+  DevBuf gwin;                                            // the window in front of every group
+  DevBuf crc;                                             // status words, then the tile CRCs of the whole file
+  uint8_t* h_crc = nullptr;
+  std::vector<void*> retired;                             // buffers replaced by bigger ones during a call: freed when it ends
+  bool decode_warmed = false;                             // the decode kernel's first (empty) launch has set the device's scratch up
   hipStream_t s_search = nullptr, s_decode[2] = {nullptr, nullptr};
-  hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
+  hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr}, ev_found[4] = {nullptr, nullptr, nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
+  uint8_t* d_search[4] = {nullptr, nullptr, nullptr, nullptr};       // from | found of a batch's block-start search (slices of the tables)
+  uint8_t* h_search[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t held() const {
+    uint64_t t = out.cap + win.cap + maps.cap + gwin.cap + crc.cap + wcarry_cap + tables_cap;
+    for (int b = 0; b < 4; ++b) t += comp[b].cap;
+    for (int b = 0; b < 2; ++b) t += slot[b].sym.bytes();
+    return t;
+  }
 };
 
 // The buffers of the device gzip path are per DEVICE, not per context, and one file at a time goes through them: a file is
@@ -180,22 +213,27 @@ int get_ctx(Ctx** out, SessionLock& sl) {
 }
 
 int new_ctx(int dev, std::unique_ptr<Ctx>* out) {
+  trace("first use of the device: creating a context");
   auto c = std::make_unique<Ctx>();
   c->dev = dev;
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, dev));
-  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int n_cu = 0;
+  HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  c->n_cu = n_cu > 0 ? n_cu : 256;
+  trace("  device attributes read");
   HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
-  HIPCHK(hipMalloc(&c->d_state, kStateWords * sizeof(uint64_t)));
+  trace("  streams created");
+  HIPCHK(hipMalloc(&c->d_state, kStateWords * sizeof(uint64_t) + 64));
+  c->d_ticket = reinterpret_cast<uint32_t*>(c->d_state + kStateWords);      // (the fold's arrival counter lives behind the state words)
   HIPCHK(hipHostMalloc(&c->h_state, kStateWords * sizeof(uint64_t), hipHostMallocDefault));
-  HIPCHK(hipMalloc(&c->d_ticket, sizeof(uint32_t)));
-  HIPCHK(hipMemset(c->d_ticket, 0, sizeof(uint32_t)));
+  trace("  state words allocated (device + pinned)");
+  HIPCHK(hipMemsetAsync(c->d_ticket, 0, sizeof(uint32_t), c->compute));
   for (int b = 0; b < 2; ++b) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_scanned[b], hipEventDisableTiming));
   }
   *out = std::move(c);
+  trace("context up");
   return SCFQ_OK;
 }
 
@@ -246,11 +284,12 @@ int ensure_staging(Ctx* c, uint64_t chunk, bool pinned) {
     }
     c->stage_cap = 0;
     for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc(&c->d_stage[b], chunk));
+    note_dev_bytes((int64_t)(2 * chunk) - (int64_t)(2 * c->stage_cap));
     c->stage_cap = chunk;
   }
   if (pinned) {
     for (int b = 0; b < 2; ++b)
-      if (!c->h_pin[b]) HIPCHK(hipHostMalloc(&c->h_pin[b], c->stage_cap, hipHostMallocDefault));
+      if (!c->h_pin[b]) { HIPCHK(hipHostMalloc(&c->h_pin[b], c->stage_cap, hipHostMallocDefault)); if (b) trace("pinned staging ring allocated"); }
   }
   return SCFQ_OK;
 }
@@ -415,6 +454,7 @@ int end_session(Ctx* c, bool hist, scfq_partial* out, uint64_t* hist_out) {
     HIPCHK(hipEventElapsedTime(&ms, c->cp_pool[k], c->cp_pool[k + 1]));
     c->timing.h2d_ms += ms;
   }
+  trace("session folded");
   std::memcpy(out, c->h_state, sizeof(scfq_partial));
   out->hist_class = 0;
   g_hist_stats[0] = g_hist_stats[1] = 0;
@@ -598,6 +638,7 @@ inline uint32_t inflate_serial_loop() {
   return v;
 }
 constexpr int kFallbackToHost = 1;        // ingest_bgzf_device: could not set up, nothing queued
+constexpr int kFallbackRest = 3;          // device gzip (scfq_gzdev.hpp), internal: a batch without room — the host takes the file from there
 constexpr int kNotPureBgzf = 2;           // ingest_bgzf_device: the file holds something other than BGZF members <= 64 KiB (found on the
                                           // way: the header walk runs chunk by chunk under the device's work); queue drained, session to restart
 constexpr uint64_t kStagePad = 4096;      // inflated chunks start one tile into their buffer: byte [-1] carries the look-behind
@@ -661,8 +702,10 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
       }
       return kFallbackToHost;
     }
+    note_dev_bytes((int64_t)(2 * (want_comp + want_inf)) - (int64_t)(2 * (c->comp_cap + c->inf_cap)));
     c->comp_cap = want_comp;
     c->inf_cap = want_inf;
+    trace("BGZF device buffers allocated");
   }
   return SCFQ_OK;
 }
@@ -820,6 +863,9 @@ int scfq_debug_hist_stats(uint64_t* fast_ranges, uint64_t* redone_ranges) {
   if (redone_ranges) *redone_ranges = g_hist_stats[1];
   return SCFQ_OK;
 }
+
+uint64_t scfq_device_bytes_high_water(void) { return g_dev_high.load(); }
+uint64_t scfq_device_bytes_now(void) { return g_dev_bytes.load(); }
 
 int scfq_last_timing(scfq_timing* t) {
   if (!t || t->struct_size != sizeof(scfq_timing)) return SCFQ_EARG;
@@ -1167,6 +1213,7 @@ int scfq_prepare(const scfq_opts* opts) {
 }
 
 int scfq_shutdown(void) {
+  trace("shutdown");
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_ctx)
    for (auto& up : kv.second) {
@@ -1200,7 +1247,6 @@ int scfq_shutdown(void) {
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->cp_pool) (void)hipEventDestroy(e);
-    if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->ev_caller) (void)hipEventDestroy(c->ev_caller);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -1208,6 +1254,7 @@ int scfq_shutdown(void) {
   scfq_dedup_release_pools();     // fq-dedup keeps its scratch in library-owned stream-ordered pools: give them back
   release_comms();                // communicators of the single-process multi-device path
   g_ctx.clear();
+  trace("shutdown done");
   return SCFQ_OK;
 }
 

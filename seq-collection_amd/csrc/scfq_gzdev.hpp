@@ -22,6 +22,13 @@ inline bool gz_device_enabled() {
   return v;
 }
 
+// every "not on the device" decision says where it was taken (SCFQ_VERBOSE)
+inline int gz_decline(int line, int code = kFallbackToHost) {
+  if (trace_on()) std::fprintf(stderr, "scfq gzdev: declined at scfq_gzdev.hpp:%d\n", line);
+  return code;
+}
+#define SCFQ_GZ_DECLINE gz_decline(__LINE__)
+
 template <typename T>
 int gz_grow(T** p, uint64_t* cap, uint64_t want_bytes, bool pinned = false) {
   if (*cap >= want_bytes) return SCFQ_OK;
@@ -30,35 +37,68 @@ int gz_grow(T** p, uint64_t* cap, uint64_t want_bytes, bool pinned = false) {
   *cap = 0;
   const uint64_t bytes = want_bytes + want_bytes / 8 + 4096;
   const hipError_t e = pinned ? hipHostMalloc(reinterpret_cast<void**>(p), bytes, hipHostMallocDefault) : hipMalloc(reinterpret_cast<void**>(p), bytes);
-  if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return kFallbackToHost; }      // not enough memory: the host path needs none of this
+  if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return SCFQ_GZ_DECLINE; }      // not enough memory: the host path needs none of this
   *cap = bytes;
   return SCFQ_OK;
 }
 
+// a device buffer made big enough; kFallbackToHost when the device cannot give the memory (the host path needs none of this)
+inline double& gz_alloc_ms() { static thread_local double v = 0; return v; }      // host time inside allocations during the current call (SCFQ_VERBOSE)
+inline int gz_buf(GzDevBuffers& g, DevBuf& b, uint64_t want) {
+  int64_t delta = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = b.ensure(want, &g.retired, &delta);
+  gz_alloc_ms() += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  note_dev_bytes(delta);
+  if (e != hipSuccess && trace_on()) std::fprintf(stderr, "scfq gzdev: no device memory for %.3f GB (%s)\n", (double)want / 1e9, hipGetErrorString(e));
+  return e == hipSuccess ? SCFQ_OK : kFallbackToHost;
+}
+inline int gz_take(SymPool& pool, uint64_t n_syms, uint64_t* off) {
+  int64_t delta = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = pool.take(n_syms, off, &delta);
+  gz_alloc_ms() += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  note_dev_bytes(delta);
+  if (e != hipSuccess && trace_on()) std::fprintf(stderr, "scfq gzdev: no device memory for another %.1f GB of symbols (%s)\n", 2.0 * (double)n_syms / 1e9, hipGetErrorString(e));
+  return e == hipSuccess ? SCFQ_OK : kFallbackToHost;
+}
+// buffers that were replaced during a call (a kernel in flight may still have been reading them): the device is idle now
+inline void gz_free_retired(GzDevBuffers* g) {
+  for (void* p : g->retired) (void)hipFree(p);
+  g->retired.clear();
+}
+
 inline void gz_free(GzDevBuffers* g) {
-  for (int b = 0; b < 3; ++b) {
-    if (g->d_comp[b]) (void)hipFree(g->d_comp[b]);
+  note_dev_bytes(-(int64_t)g->held());
+  gz_free_retired(g);
+  for (int b = 0; b < 4; ++b) {
+    g->comp[b].release();
     if (g->ev_copy[b]) (void)hipEventDestroy(g->ev_copy[b]);
+    if (g->ev_found[b]) (void)hipEventDestroy(g->ev_found[b]);
+    g->ev_copy[b] = g->ev_found[b] = nullptr;
+    g->d_search[b] = g->h_search[b] = nullptr;
   }
   for (int b = 0; b < 2; ++b) {
-    if (g->slot[b].d_sym) (void)hipFree(g->slot[b].d_sym);
-    if (g->slot[b].d_meta) (void)hipFree(g->slot[b].d_meta);
-    if (g->slot[b].h_meta) (void)hipHostFree(g->slot[b].h_meta);
-    if (g->d_pmeta[b]) (void)hipFree(g->d_pmeta[b]);
-    if (g->h_pmeta[b]) (void)hipHostFree(g->h_pmeta[b]);
+    g->slot[b].sym.release();
+    g->slot[b].d_meta = g->slot[b].h_meta = nullptr;
+    g->d_pmeta[b] = g->h_pmeta[b] = nullptr;
     if (g->ev_dec[b]) (void)hipEventDestroy(g->ev_dec[b]);
     if (g->ev_post[b]) (void)hipEventDestroy(g->ev_post[b]);
     if (g->s_decode[b]) (void)hipStreamDestroy(g->s_decode[b]);
+    g->ev_dec[b] = g->ev_post[b] = nullptr;
+    g->s_decode[b] = nullptr;
   }
-  if (g->d_out) (void)hipFree(g->d_out);
-  if (g->d_win) (void)hipFree(g->d_win);
+  if (g->d_tables) (void)hipFree(g->d_tables);
+  if (g->h_tables) (void)hipHostFree(g->h_tables);
+  g->d_tables = g->h_tables = g->h_crc = nullptr;
+  g->tables_cap = g->htables_cap = 0;
+  g->decode_warmed = false;
+  g->out.release(); g->win.release(); g->maps.release(); g->gwin.release(); g->crc.release();
   if (g->d_wcarry) (void)hipFree(g->d_wcarry);
-  if (g->d_maps) (void)hipFree(g->d_maps);
-  if (g->d_gwin) (void)hipFree(g->d_gwin);
-  if (g->d_crc) (void)hipFree(g->d_crc);
-  if (g->h_crc) (void)hipHostFree(g->h_crc);
+  g->d_wcarry = nullptr;
+  g->wcarry_cap = 0;
   if (g->s_search) (void)hipStreamDestroy(g->s_search);
-  *g = GzDevBuffers{};
+  g->s_search = nullptr;
 }
 
 // x^(8 n) mod P and products in the reflected representation (as the kernels: bit 31 = x^0)
@@ -90,13 +130,25 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   using namespace scfq_dinflate;
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
+  gz_alloc_ms() = 0;
+  double stage_ms[3] = {0, 0, 0};
   static const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
   const long h0 = scfq_gzfast::member_header(img, (size_t)fsize);
-  if (h0 <= 0 || fsize < 64) return kFallbackToHost;
+  if (h0 <= 0 || fsize < 64) return SCFQ_GZ_DECLINE;
   GzDevBuffers& g = gz_shared(c->dev).buf;             // (the caller holds its mutex)
   int rc;
-  if (!g.s_search) HIPCHK(hipStreamCreateWithFlags(&g.s_search, hipStreamNonBlocking));
-  for (int b = 0; b < 3; ++b) if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
+  if (!g.s_search) {
+    // the search's workgroups are small and short, and the decode of the next batch cannot be cut into segments before they are
+    // through: their stream has priority over the decode streams, whose waves run for tens of milliseconds
+    int least = 0, greatest = 0;
+    static const int hi = env_int("SCFQ_GZ_DEVICE_SEARCH_PRIORITY", 1);
+    if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) HIPCHK(hipStreamCreateWithPriority(&g.s_search, hipStreamNonBlocking, greatest));
+    else HIPCHK(hipStreamCreateWithFlags(&g.s_search, hipStreamNonBlocking));
+  }
+  for (int b = 0; b < 4; ++b) {
+    if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
+    if (!g.ev_found[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_found[b], hipEventDisableTiming));
+  }
   for (int b = 0; b < 2; ++b) {
     if (!g.s_decode[b]) {
       // The decode kernels fill the device with waves that run for tens of milliseconds, and whatever else the pipeline launches
@@ -128,6 +180,26 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     if (!g.ev_post[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_post[b], hipEventDisableTiming));
   }
 
+  // The decode kernel keeps 72 bytes of scratch per lane (its symbol loop is a real function call), and the runtime sets the
+  // device's scratch up inside the FIRST launch of such a kernel: 35 - 50 ms of a process's first call, spent on the host thread.
+  // An empty launch on a helper thread takes that off the critical path: it runs under the plan, the pinned ring's allocation and
+  // the first batch's copy.
+  struct Warm {
+    std::thread th;
+    ~Warm() { if (th.joinable()) th.join(); }
+  } warm;
+  if (!g.decode_warmed) {
+    g.decode_warmed = true;
+    hipStream_t sd = g.s_decode[0];
+    const int dev = c->dev;
+    warm.th = std::thread([sd, dev] {
+      if (hipSetDevice(dev) != hipSuccess) return;
+      hipLaunchKernelGGL(gz_segment_decode, dim3(1), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, sd, (const uint8_t*)nullptr, 0ull, (const GzSeg*)nullptr, 0u,
+                         (uint16_t*)nullptr, (GzSegOut*)nullptr, 0u);
+      (void)hipGetLastError();
+    });
+  }
+
   // ---- plan ----------------------------------------------------------------------------------------------------------------
   const uint64_t data0 = (uint64_t)h0;
   const uint64_t comp = fsize - data0;
@@ -140,10 +212,32 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   static const uint32_t batch_segs = (uint32_t)std::max(2, env_int("SCFQ_GZ_DEVICE_BATCH_SEGMENTS", 4096));
   // (a file of up to 512 MiB is cut into about 4096 segments — one wave each, the device filled once — of at least 48 KiB; a
   // bigger one into about 8192 of at most 320 KiB: every segment costs 32768 marker symbols and a step of the window chain)
-  const uint64_t target_segs = comp <= (512ull << 20) ? 4096 : 8192;
+  // (r3: at most 128 KiB — 320 KiB segments in two batches were 7 % faster warm, 155 against 166 ms for 10 GB, and held 39 GB instead of
+  // 18: device memory is what a first call pays for when the box has just been used, profiles/r03/gz_segment_size.txt)
+  const uint64_t target_segs = 4096;
   const uint64_t seg_bytes = seg_kb_env > 0 ? ((((uint64_t)std::max(32, seg_kb_env)) << 10) + 4095) & ~4095ull
-                                            : std::min<uint64_t>(320u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull));
-  static const uint64_t ratio = (uint64_t)std::max(2, env_int("SCFQ_GZ_DEVICE_MAX_RATIO", 7));   // output symbols a segment may produce per compressed byte
+                                            : std::min<uint64_t>(128u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull));
+  // Output room of a segment = `ratio_est` symbols per compressed byte it spans + 128 Ki (it runs on to the end of a block),
+  // behind its 32768 markers.  ratio_est comes from the file itself: the host inflates the first 192 KiB of the first member
+  // (a millisecond) and adds a third; a segment that needs more ends with kGzErrOverflow and is decoded again, alone, with four
+  // times the room (the walk below treats it like a gap) — round 2 sized every segment for 7 symbols per byte, held 50 - 70 GB for
+  // a 10 GB file, and sent the whole file to the host when one segment compressed better than that.
+  static const double ratio_env = std::atof(std::getenv("SCFQ_GZ_DEVICE_RATIO") ? std::getenv("SCFQ_GZ_DEVICE_RATIO") : "0");
+  double ratio_est = ratio_env > 0 ? ratio_env : 6.0;
+  if (ratio_env <= 0) {
+    const uint64_t sample_in = std::min<uint64_t>(fsize - data0, 192u << 10);
+    std::vector<uint8_t> sample_out((size_t)kGzWindow + (8u << 20));
+    auto dec = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
+    dec->begin(img + data0, img + data0 + sample_in);
+    uint8_t* o = sample_out.data() + kGzWindow;
+    (void)dec->run(o, sample_out.data() + sample_out.size());      // (ends with "truncated" at the end of the sample: what came out counts)
+    const uint64_t got_out = (uint64_t)(o - (sample_out.data() + kGzWindow)), got_in = std::max<uint64_t>(1, dec->bitpos() / 8);
+    // (long runs — zeros, one record repeated: ratios in the hundreds — are the host decoder's home ground, gigabytes per second,
+    // and the lane-parallel loop's worst case, one symbol per round: such a file is declined here, before anything is queued)
+    if (got_in >= 1024 && (double)got_out / (double)got_in > 24.0) return SCFQ_GZ_DECLINE;
+    static const double est_mul = std::atof(std::getenv("SCFQ_GZ_DEVICE_RATIO_MARGIN") ? std::getenv("SCFQ_GZ_DEVICE_RATIO_MARGIN") : "1.15");
+    if (got_out >= 65536 && got_in >= 4096) ratio_est = std::min(32.0, std::max(3.0, est_mul * (double)got_out / (double)got_in + 0.25));
+  }
   const uint64_t n_plan = std::max<uint64_t>(1, (comp + seg_bytes - 1) / seg_bytes);
   std::vector<uint64_t> bstart{0};                     // planned segments [bstart[k], bstart[k + 1]) make batch k
   {
@@ -160,44 +254,59 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   auto byte0_of = [&](uint32_t k) { return k == 0 ? 0ull : ((data0 + p0_of(k) * seg_bytes) & ~4095ull); };
   auto byte1_of = [&](uint32_t k) { return p1_of(k) == n_plan ? fsize : data0 + p1_of(k) * seg_bytes; };
   auto copy_end_of = [&](uint32_t k) { return std::min<uint64_t>(fsize, byte1_of(k) + margin); };
-  const uint64_t batch_comp_max = std::min<uint64_t>(fsize, (uint64_t)batch_segs * seg_bytes + margin + 8192);
-  const uint32_t spare = 64 + batch_segs / 16;         // room for gap segments of later rounds
+  const uint64_t batch_comp_max = std::min<uint64_t>(fsize, (uint64_t)std::min<uint64_t>(batch_segs, n_plan) * seg_bytes + margin + 8192);
+  const uint32_t spare = 64 + batch_segs / 16;         // gap segments of later rounds
   const uint32_t max_seg = batch_segs + spare;
-  // output room of a segment: `ratio` symbols per compressed byte it spans + 256 Ki (it runs on to the end of a block), behind
-  // its 32768 markers; a slot's pool holds every planned segment of a batch plus `spare` gap segments of up to four segments' span
-  auto seg_cap = [&](uint64_t start_bit, uint64_t stop_bit) { return (((stop_bit - start_bit + 7) / 8) * ratio + 262144 + 7) & ~7ull; };
-  const uint64_t pool_syms = batch_comp_max * ratio + (uint64_t)max_seg * (kGzWindow + 262144 + 8) + (uint64_t)spare * 4 * seg_bytes * ratio;
-  const uint64_t out_max = batch_comp_max * ratio + (uint64_t)max_seg * 262144;     // inflated bytes of one batch
-  // slot meta (device and pinned mirror, same offsets): from | found | segs | outs
-  const uint64_t off_from = 0, off_found = off_from + 8ull * max_seg, off_segs = off_found + 8ull * max_seg,
-                 off_outs = off_segs + sizeof(GzSeg) * max_seg, slot_meta = off_outs + sizeof(GzSegOut) * max_seg + 64;
+  const uint64_t kSegSlack = 98304;       // (zlib's level-6 blocks inflate to ~60 KB, memLevel 9's to ~130 KB: those overflow now and then and are decoded again)
+  auto seg_cap = [&](uint64_t start_bit, uint64_t stop_bit, double mult) {
+    const double c = (double)((stop_bit - start_bit + 7) / 8) * ratio_est * mult + (double)kSegSlack;
+    return (uint64_t)std::min(c, (double)0x3F000000u) & ~7ull;
+  };
+  // Bounds (not allocations): a batch may inflate to 40 bytes per compressed byte — one that needs more (long runs: better served by
+  // the host's decoder anyway) makes the rest of the file the host's.  What is ALLOCATED follows the need, batch by batch.
+  const uint64_t kMaxRatio = 40;
+  const uint64_t res_out = std::min<uint64_t>(160ull << 30, batch_comp_max * kMaxRatio + (uint64_t)max_seg * kSegSlack) + 2 * kStagePad;
+  // slot meta (device and pinned mirror, same offsets): segs | outs; the searches have their own ring of four (from | found): the
+  // search of batch k + 1 is in flight while batch k - 1, of the same parity, is being cut into segments from ITS search's results
+  const uint64_t off_segs = 0, off_outs = off_segs + sizeof(GzSeg) * max_seg, slot_meta = off_outs + sizeof(GzSegOut) * max_seg + 64;
+  const uint64_t off_from = 0, off_found = off_from + 8ull * max_seg, search_meta = (off_found + 8ull * max_seg + 255) & ~255ull;
   // post meta (per parity): chain | first | work entry | work tile | gap from | gap found | group chain | group first | chain's first group
   static const uint32_t group = (uint32_t)std::min(64, std::max(2, env_int("SCFQ_GZ_DEVICE_CHAIN_GROUP", 64)));      // chain entries per window map
-  const uint64_t max_work = out_max / kResolveTile + max_seg + 8;
-  const uint64_t max_groups = max_seg / group + 1026 + 2;                  // (every member chain of a batch ends with a short group)
+  const uint64_t max_work = std::min<uint64_t>(res_out, batch_comp_max * 16 + (uint64_t)max_seg * kSegSlack) / kResolveTile + max_seg + 8;
+  const uint64_t max_groups = max_seg / group + max_seg + 2;               // (every member chain of a batch ends with a short group; a member has a segment)
   const uint64_t offp_chain = 0, offp_first = offp_chain + sizeof(GzChain) * max_seg, offp_we = offp_first + 4ull * (max_seg + 2),
                  offp_wt = offp_we + 4ull * max_work, offp_gfrom = (offp_wt + 4ull * max_work + 7) & ~7ull, offp_gfound = offp_gfrom + 8ull * max_seg,
                  offp_gchain = offp_gfound + 8ull * max_seg, offp_gfirst = offp_gchain + sizeof(GzChain) * max_groups,
                  offp_mfirst = offp_gfirst + 4ull * (max_groups + 2), post_meta = offp_mfirst + 4ull * (max_groups + 2) + 64;
-  const uint64_t crc_tiles_max = (uint64_t)nb * (out_max / kCrcTile + 2) + 4200;      // (one part per member and batch)
-  for (uint32_t b = 0; b < std::min(nb, 3u); ++b)
-    if ((rc = gz_grow(&g.d_comp[b], &g.comp_cap[b], batch_comp_max + comp_pad + 4096))) return rc;
-  for (uint32_t b = 0; b < std::min(nb, 2u); ++b) {
-    GzSlot& sl = g.slot[b];
-    if ((rc = gz_grow(&sl.d_sym, &sl.sym_cap, 2ull * pool_syms)) || (rc = gz_grow(&sl.d_meta, &sl.meta_cap, slot_meta)) ||
-        (rc = gz_grow(&sl.h_meta, &sl.hmeta_cap, slot_meta, true)) || (rc = gz_grow(&g.d_pmeta[b], &g.pmeta_cap[b], post_meta)) ||
-        (rc = gz_grow(&g.h_pmeta[b], &g.hpmeta_cap[b], post_meta, true)))
-      return rc;
+  const uint64_t res_crc = 4 * (16 + (comp * kMaxRatio) / kCrcTile + 2ull * n_plan + 4ull * nb + 8192);      // tiles of the whole file + a part per member and batch
+  for (uint32_t b = 0; b < std::min(nb, 4u); ++b) if ((rc = gz_buf(g, g.comp[b], batch_comp_max + comp_pad + 4096))) return rc;
+  if ((rc = gz_buf(g, g.win, (uint64_t)kGzWindow * max_seg)) || (rc = gz_buf(g, g.crc, res_crc))) return rc;
+  {
+    // the tables of both slots: ONE device and ONE pinned allocation (a pinned allocation costs milliseconds whatever its size)
+    const uint32_t ns = std::min(nb, 2u), nq = std::min(nb, 4u);
+    const uint64_t per = ((slot_meta + post_meta + 255) & ~255ull), crc_room = (res_crc + 255) & ~255ull;
+    const uint64_t t0 = g.tables_cap;
+    if ((rc = gz_grow(&g.d_tables, &g.tables_cap, per * ns + search_meta * nq)) || (rc = gz_grow(&g.h_tables, &g.htables_cap, per * ns + search_meta * nq + crc_room, true))) return rc;
+    for (uint32_t q = 0; q < nq; ++q) { g.d_search[q] = g.d_tables + per * ns + search_meta * q; g.h_search[q] = g.h_tables + per * ns + search_meta * q; }
+    note_dev_bytes((int64_t)g.tables_cap - (int64_t)t0);
+    for (uint32_t b = 0; b < ns; ++b) {
+      g.slot[b].d_meta = g.d_tables + per * b;   g.slot[b].h_meta = g.h_tables + per * b;
+      g.d_pmeta[b] = g.slot[b].d_meta + slot_meta; g.h_pmeta[b] = g.slot[b].h_meta + slot_meta;
+    }
+    g.h_crc = g.h_tables + per * ns + search_meta * nq;
   }
-  if ((rc = gz_grow(&g.d_out, &g.out_cap, out_max + 2 * kStagePad)) || (rc = gz_grow(&g.d_win, &g.win_cap, (uint64_t)kGzWindow * max_seg)) ||
-      (rc = gz_grow(&g.d_wcarry, &g.wcarry_cap, 2ull * kGzWindow)) || (rc = gz_grow(&g.d_maps, &g.maps_cap, 2ull * kGzWindow * (max_groups + 1))) ||
-      (rc = gz_grow(&g.d_gwin, &g.gwin_cap, (uint64_t)kGzWindow * max_groups)) || (rc = gz_grow(&g.d_crc, &g.crc_cap, 4 * (16 + crc_tiles_max))) ||
-      (rc = gz_grow(&g.h_crc, &g.hcrc_cap, 4 * (16 + crc_tiles_max), true)))
-    return rc;
-  uint8_t* const d_out = g.d_out + kStagePad;
+  {
+    const uint64_t w0 = g.wcarry_cap;
+    if ((rc = gz_grow(&g.d_wcarry, &g.wcarry_cap, 2ull * kGzWindow))) return rc;
+    note_dev_bytes((int64_t)g.wcarry_cap - (int64_t)w0);
+  }
+  uint8_t* d_out = nullptr;                            // (set when the first batch's bytes get their room)
   const double alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
-  if (verbose && alloc_ms > 1.0) std::fprintf(stderr, "scfq gzdev: buffers grown in %.1f ms (kept in the context for the next call)\n", alloc_ms);
-  const uint64_t pin_chunk = 64ull << 20;
+  if (verbose) std::fprintf(stderr, "scfq gzdev: plan + tables in %.1f ms: %u batch(es), segments of %llu KiB, %.2f symbols per compressed byte assumed\n", alloc_ms, nb,
+                            (unsigned long long)(seg_bytes >> 10), ratio_est);
+  // the pinned ring the compressed bytes cross in: pieces of 16 MiB (pinning memory costs 160 ms per GB — 21 of a small file's
+  // milliseconds with the host path's 64 MiB pieces); a ring another path of this context has set up already is used as it is
+  const uint64_t pin_chunk = c->stage_cap ? std::min<uint64_t>(c->stage_cap, 64ull << 20) : (16ull << 20);
   rc = ensure_staging(c, pin_chunk, true);
   if (rc) return rc;
 
@@ -223,17 +332,19 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   uint64_t tiles_used = 0;
   std::vector<GzPart> parts;
   std::vector<GzMemberEnd> member_ends;
-  uint32_t n_planned_total = 0, n_decoded_total = 0, n_chain_total = 0, n_gap_rounds = 0;
+  uint32_t n_planned_total = 0, n_decoded_total = 0, n_chain_total = 0, n_gap_rounds = 0, n_overflows = 0;
+  const char* why = nullptr;             // why a batch was handed to the host (kFallbackRest)
+  std::map<uint64_t, double> overflow_mult;      // start bit of a segment that ran out of room -> the multiple of the assumed room it was last given
   double fill_ms = 0, walk_ms = 0, h_evsync_ms = 0, h_memcpy_ms = 0, h_enqueue_ms = 0, h_search_wait_ms = 0, h_dec_wait_ms = 0, h_post_wait_ms = 0;
   uint32_t pin_it = 0;                   // the pinned staging buffers alternate over the whole file
   std::vector<uint32_t> n_seg_of(nb + 1, 0);
   std::vector<uint64_t> pool_used_of(nb + 1, 0);
-  HIPCHK(hipMemsetAsync(g.d_crc, 0, 64, c->compute));          // word 0: the resolve kernels' error status for the whole file
+  HIPCHK(hipMemsetAsync(g.crc.p, 0, 64, c->compute));          // word 0: the resolve kernels' error status for the whole file
 
-  // ---- stage A(k): bytes of batch k to d_comp[k % 3], block-start search ----------------------------------------------------
+  // ---- stage A(k): bytes of batch k to comp[k % 4], block-start search — launched one iteration before its results are waited for ----
   auto stage_a = [&](uint32_t k) -> int {
     const auto tf = clk::now();
-    const int cb = (int)(k % 3);
+    const int cb = (int)(k % 4);
     const uint64_t b0 = byte0_of(k), b1 = copy_end_of(k);
     span_begin(sp_copy, c->copy);
     for (uint64_t off = b0; off < b1; off += pin_chunk, ++pin_it) {
@@ -245,22 +356,21 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
       const uint8_t* src = img + off;
       parallel_pieces(len, [&](uint64_t o, uint64_t l) { std::memcpy(c->h_pin[pb] + o, src + o, l); return 0; });
       auto t2 = clk::now();
-      HIPCHK(hipMemcpyAsync(g.d_comp[cb] + (off - b0), c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
+      HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
       HIPCHK(hipEventRecord(c->ev_copied[pb], c->copy));
       auto t3 = clk::now();
       h_evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
       h_memcpy_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
       h_enqueue_ms += std::chrono::duration<double, std::milli>(t3 - t2).count();
     }
-    HIPCHK(hipMemsetAsync(g.d_comp[cb] + (b1 - b0), 0, comp_pad, c->copy));
+    HIPCHK(hipMemsetAsync(g.comp[cb].p + (b1 - b0), 0, comp_pad, c->copy));
     span_end(sp_copy, c->copy);
     HIPCHK(hipEventRecord(g.ev_copy[cb], c->copy));
     c->timing.h2d_bytes += b1 - b0;
     fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     // search: the planned segments of this batch (the file's very first one starts exactly at the member's first block)
-    GzSlot& sl = g.slot[k & 1];
-    uint64_t* h_from = reinterpret_cast<uint64_t*>(sl.h_meta + off_from);
-    uint64_t* h_found = reinterpret_cast<uint64_t*>(sl.h_meta + off_found);
+    uint64_t* h_from = reinterpret_cast<uint64_t*>(g.h_search[cb] + off_from);
+    uint64_t* h_found = reinterpret_cast<uint64_t*>(g.h_search[cb] + off_found);
     const uint64_t p0 = p0_of(k);
     const uint32_t np = (uint32_t)(p1_of(k) - p0);
     for (uint32_t s = 0; s < np; ++s) { h_from[s] = (data0 + (p0 + s) * seg_bytes) * 8; h_found[s] = ~0ull; }
@@ -268,31 +378,37 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     if (k == 0) h_found[0] = data0 * 8;
     HIPCHK(hipStreamWaitEvent(g.s_search, g.ev_copy[cb], 0));
     if (np > s0) {
-      const uint8_t* vbase = g.d_comp[cb] - b0;          // virtual base: byte i of the file is vbase[i] for i in [b0, b1 + pad)
+      const uint8_t* vbase = g.comp[cb].p - b0;          // virtual base: byte i of the file is vbase[i] for i in [b0, b1 + pad)
       span_begin(sp_search, g.s_search);
-      HIPCHK(hipMemcpyAsync(sl.d_meta + off_from, h_from, 8ull * np, hipMemcpyHostToDevice, g.s_search));
+      HIPCHK(hipMemcpyAsync(g.d_search[cb] + off_from, h_from, 8ull * np, hipMemcpyHostToDevice, g.s_search));
       hipLaunchKernelGGL(gz_sync_search, dim3(np - s0), dim3(kSyncThreads), 0, g.s_search, reinterpret_cast<const uint64_t*>(vbase), b1 * 8,
-                         reinterpret_cast<const uint64_t*>(sl.d_meta + off_from) + s0, np - s0, seg_bytes * 8,
-                         reinterpret_cast<uint64_t*>(sl.d_meta + off_found) + s0);
+                         reinterpret_cast<const uint64_t*>(g.d_search[cb] + off_from) + s0, np - s0, seg_bytes * 8,
+                         reinterpret_cast<uint64_t*>(g.d_search[cb] + off_found) + s0);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(h_found + s0, sl.d_meta + off_found + 8ull * s0, 8ull * (np - s0), hipMemcpyDeviceToHost, g.s_search));
+      HIPCHK(hipMemcpyAsync(h_found + s0, g.d_search[cb] + off_found + 8ull * s0, 8ull * (np - s0), hipMemcpyDeviceToHost, g.s_search));
       span_end(sp_search, g.s_search);
     }
-    { auto t0 = clk::now(); HIPCHK(hipStreamSynchronize(g.s_search)); h_search_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+    HIPCHK(hipEventRecord(g.ev_found[cb], g.s_search));
     n_planned_total += np;
+    return SCFQ_OK;
+  };
+  auto stage_a_wait = [&](uint32_t k) -> int {
+    auto t0 = clk::now();
+    HIPCHK(hipEventSynchronize(g.ev_found[k % 4]));
+    h_search_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
     return SCFQ_OK;
   };
 
   // ---- stage B(k): the segments of batch k (its last one stops at the first start of batch k + 1), decode ---------------------
   auto stage_b = [&](uint32_t k) -> int {
     GzSlot& sl = g.slot[k & 1];
-    const uint64_t* h_found = reinterpret_cast<const uint64_t*>(sl.h_meta + off_found);
+    const uint64_t* h_found = reinterpret_cast<const uint64_t*>(g.h_search[k % 4] + off_found);
     GzSeg* h_segs = reinterpret_cast<GzSeg*>(sl.h_meta + off_segs);
     const uint32_t np = (uint32_t)(p1_of(k) - p0_of(k));
     const uint64_t limit = copy_end_of(k) * 8;
     uint64_t next_first = (k + 1 < nb) ? byte1_of(k) * 8 : end_bit;     // where the last segment stops
     if (k + 1 < nb) {
-      const uint64_t* nf = reinterpret_cast<const uint64_t*>(g.slot[(k + 1) & 1].h_meta + off_found);
+      const uint64_t* nf = reinterpret_cast<const uint64_t*>(g.h_search[(k + 1) % 4] + off_found);
       const uint32_t npn = (uint32_t)(p1_of(k + 1) - p0_of(k + 1));
       for (uint32_t s = 0; s < npn; ++s)
         if (nf[s] != ~0ull) { next_first = nf[s]; break; }
@@ -309,25 +425,26 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
       last_start = st;
       ++n_seg;
     }
+    sl.sym.rewind();
     for (uint32_t q = 0; q < n_seg; ++q) {
-      const uint64_t cap = std::min<uint64_t>(seg_cap(h_segs[q].start_bit, h_segs[q].stop_bit), 0x3F000000u);
-      h_segs[q].sym_off = pool_used;
-      h_segs[q].cap = (uint32_t)cap;     // better compression than `ratio`: overflow status, and the file goes to the host path
+      const uint64_t cap = seg_cap(h_segs[q].start_bit, h_segs[q].stop_bit, 1.0);
+      if (int r = gz_take(sl.sym, kGzWindow + cap, &h_segs[q].sym_off)) return r;
+      h_segs[q].cap = (uint32_t)cap;     // better compression than assumed: overflow status, and the walk has that segment decoded again
       h_segs[q].reserved = 0;
       pool_used += kGzWindow + cap;
     }
-    if (pool_used > pool_syms) return kFallbackToHost;
     n_seg_of[k] = n_seg;
     pool_used_of[k] = pool_used;
     hipStream_t sd = g.s_decode[k & 1];
+    if (warm.th.joinable()) warm.th.join();
     if (k >= 2) HIPCHK(hipStreamWaitEvent(sd, g.ev_post[k & 1], 0));      // the slot's symbols were read by batch k - 2's resolve
-    HIPCHK(hipStreamWaitEvent(sd, g.ev_copy[k % 3], 0));
+    HIPCHK(hipStreamWaitEvent(sd, g.ev_copy[k % 4], 0));
     if (n_seg) {
-      const uint8_t* vbase = g.d_comp[k % 3] - byte0_of(k);
+      const uint8_t* vbase = g.comp[k % 4].p - byte0_of(k);
       span_begin(sp_decode, sd);
       HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs, h_segs, sizeof(GzSeg) * n_seg, hipMemcpyHostToDevice, sd));
       hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, sd,
-                         vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs), n_seg, sl.d_sym,
+                         vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs), n_seg, sl.sym.base(),
                          reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs), inflate_serial_loop());
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(sl.h_meta + off_outs, sl.d_meta + off_outs, sizeof(GzSegOut) * n_seg, hipMemcpyDeviceToHost, sd));
@@ -346,12 +463,15 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     GzSegOut* h_outs = reinterpret_cast<GzSegOut*>(sl.h_meta + off_outs);
     { auto t0 = clk::now(); HIPCHK(hipEventSynchronize(g.ev_dec[pp])); h_dec_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
     if (k >= 2) { auto t0 = clk::now(); HIPCHK(hipEventSynchronize(g.ev_post[pp])); h_post_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }      // h_pmeta[pp] / d_pmeta[pp] were batch k - 2's
+    // (SCFQ_GZ_DEVICE_TEST_REST_AT=k: batch k declares itself out of room — the tests of the hand-over to the host's decoder)
+    static const int test_rest_at = env_int("SCFQ_GZ_DEVICE_TEST_REST_AT", -1);
+    if (test_rest_at >= 0 && k == (uint32_t)test_rest_at) { why = "SCFQ_GZ_DEVICE_TEST_REST_AT"; return gz_decline(__LINE__, kFallbackRest); }
     const auto tw = clk::now();
     uint64_t* h_gfrom = reinterpret_cast<uint64_t*>(g.h_pmeta[pp] + offp_gfrom);
     uint64_t* h_gfound = reinterpret_cast<uint64_t*>(g.h_pmeta[pp] + offp_gfound);
     uint32_t n_seg = n_seg_of[k];
     uint64_t pool_used = pool_used_of[k];
-    const uint8_t* vbase = g.d_comp[k % 3] - byte0_of(k);
+    const uint8_t* vbase = g.comp[k % 4].p - byte0_of(k);
     const bool last_batch = k + 1 == nb;
     const uint64_t territory_end = last_batch ? end_bit : byte1_of(k) * 8, limit = copy_end_of(k) * 8;
     struct Entry { uint32_t seg; uint32_t member; };
@@ -362,10 +482,14 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     std::vector<GzMemberEnd> ends_here;
     for (int round = 0;; ++round) {
       std::map<uint64_t, uint32_t> by_start;
-      for (uint32_t s = 0; s < n_seg; ++s) by_start.emplace(h_segs[s].start_bit, s);      // (the first decode of a start bit wins; later ones are identical)
+      for (uint32_t s = 0; s < n_seg; ++s) {      // the first decode of a start bit wins (later ones are identical) — unless it ran out of room: then the last one does
+        auto ins = by_start.emplace(h_segs[s].start_bit, s);
+        if (!ins.second && h_outs[ins.first->second].status == kGzErrOverflow) ins.first->second = s;
+      }
       chain.clear(); ends_here.clear();
       finished_end = false;
-      std::vector<std::pair<uint64_t, uint64_t>> gaps;
+      struct Gap { uint64_t first, second; double mult; };
+      std::vector<Gap> gaps;
       bool tentative = false, done = false;
       uint64_t p = pos;
       uint32_t mno = member_no;
@@ -377,8 +501,8 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
           // at a false sync and the one before ran over it): decode [p, next known start) in the next round
           auto nx = by_start.upper_bound(p);
           uint64_t stop = nx != by_start.end() ? nx->first : (last_batch ? end_bit : std::min(territory_end + 8 * seg_bytes, limit - 4096));
-          if (stop <= p || stop - p > 64 * 8 * seg_bytes) return kFallbackToHost;     // (one wave would decode a gap that long for seconds)
-          gaps.emplace_back(p, stop);
+          if (stop <= p || stop - p > 64 * 8 * seg_bytes) return SCFQ_GZ_DECLINE;     // (one wave would decode a gap that long for seconds)
+          gaps.push_back(Gap{p, stop, 1.0});
           if (verbose) std::fprintf(stderr, "scfq gzdev:   batch %u: gap at bit %llu (%.1f %% of the file) up to %llu\n", k, (unsigned long long)p,
                                     100.0 * (double)p / (double)end_bit, (unsigned long long)stop);
           tentative = true;
@@ -387,44 +511,63 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
           continue;
         }
         const GzSegOut& r = h_outs[it->second];
+        if (r.status == kGzErrOverflow) {
+          // this stretch compresses better than the room its segment was given: like a gap, it is decoded again in the next
+          // round — cut into pieces, every piece with four times the room per compressed byte (16, 64 times if that is not enough)
+          double& m = overflow_mult[p];
+          m = m > 0 ? m * 4.0 : 4.0;
+          if (m > 300.0) { why = "a segment overflowed 256 times the assumed room"; return gz_decline(__LINE__, kFallbackRest); }
+          auto nx = std::next(it);
+          const uint64_t stop = nx != by_start.end() ? nx->first : (last_batch ? end_bit : std::min(territory_end + 8 * seg_bytes, limit - 4096));
+          if (stop <= p) return SCFQ_GZ_DECLINE;
+          by_start.erase(it);
+          gaps.push_back(Gap{p, stop, m});
+          ++n_overflows;
+          if (verbose) std::fprintf(stderr, "scfq gzdev:   batch %u: segment at bit %llu needs more than %.1f symbols per byte: again with %.0f x the room\n", k,
+                                    (unsigned long long)p, ratio_est * m / 4.0, m);
+          tentative = true;
+          if (nx == by_start.end()) break;
+          p = nx->first;
+          continue;
+        }
         if (r.status != kGzOk && r.status != kGzMemberEnd) {
           if (tentative) break;          // may not even be on the real path: decide after the gaps are decoded
           if (verbose) std::fprintf(stderr, "scfq gzdev: segment at bit %llu ended with status %u: host path\n", (unsigned long long)p, r.status);
-          return kFallbackToHost;
+          return SCFQ_GZ_DECLINE;
         }
-        if (r.end_bit <= p) return kFallbackToHost;
+        if (r.end_bit <= p) return SCFQ_GZ_DECLINE;
         chain.push_back(Entry{it->second, mno});
         if (r.status == kGzMemberEnd) {
           const uint64_t q = (r.end_bit + 7) >> 3;             // the trailer starts on the next byte boundary
-          if (q + 8 > fsize) return kFallbackToHost;           // truncated trailer: gzread's error, from the host path
+          if (q + 8 > fsize) return SCFQ_GZ_DECLINE;           // truncated trailer: gzread's error, from the host path
           GzMemberEnd me;
           me.member = mno;
           me.crc = (uint32_t)img[q] | ((uint32_t)img[q + 1] << 8) | ((uint32_t)img[q + 2] << 16) | ((uint32_t)img[q + 3] << 24);
           me.isize = (uint32_t)img[q + 4] | ((uint32_t)img[q + 5] << 8) | ((uint32_t)img[q + 6] << 16) | ((uint32_t)img[q + 7] << 24);
           ends_here.push_back(me);
           const long h = scfq_gzfast::member_header(img + q + 8, (size_t)(fsize - (q + 8)));
-          if (h < 0) return kFallbackToHost;                   // a damaged further header: the host path decides
+          if (h < 0) return SCFQ_GZ_DECLINE;                   // a damaged further header: the host path decides
           if (h == 0) { finished_end = true; done = true; break; }   // end of file, or trailing garbage (ignored, as gzread does)
           p = (q + 8 + (uint64_t)h) * 8;
-          if (++mno > 1024) return kFallbackToHost;            // (files of very many small members: the host's serial reader)
+          ++mno;      // (any number of members: the parts of a member, its trailer and the window state travel from batch to batch)
         } else {
           p = r.end_bit;
-          if (p + 8 >= end_bit) return kFallbackToHost;        // the data ends inside a member: truncated file
+          if (p + 8 >= end_bit) return SCFQ_GZ_DECLINE;        // the data ends inside a member: truncated file
         }
       }
       if (done && !tentative) { pos_end = p; member_end_no = mno; break; }
       if (gaps.empty() || round >= 4) {
         if (verbose) std::fprintf(stderr, "scfq gzdev: batch %u: chain not closed after %d rounds (%zu gaps): host path\n", k, round, gaps.size());
-        return kFallbackToHost;
+        return SCFQ_GZ_DECLINE;
       }
       // A gap is as long as a planned segment and one wave would take a whole decode phase for it: it is cut into pieces
       // the same way the file was — its exact start, then block starts searched at equal steps inside it
-      std::vector<std::pair<uint64_t, uint64_t>> pieces;       // (start, stop)
+      std::vector<Gap> pieces;       // (start, stop, room multiplier)
       {
         const uint32_t kSub = 8;
         std::vector<uint64_t> from;
         for (auto& gp : gaps) {
-          if (by_start.count(gp.first)) continue;
+          if (by_start.count(gp.first)) continue;          // (decoded in an earlier round after all)
           const uint64_t span = gp.second - gp.first;
           const uint32_t nparts = span >= (uint64_t)kSub * 8 * 4096 ? kSub : 1;
           for (uint32_t j = 1; j < nparts; ++j) from.push_back(gp.first + span * j / nparts);
@@ -449,29 +592,29 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
           std::vector<uint64_t> st{gp.first};
           for (uint32_t j = 1; j < nparts; ++j, ++fk)
             if (fk < found.size() && found[fk] != ~0ull && found[fk] > st.back() && found[fk] < gp.second && !by_start.count(found[fk])) st.push_back(found[fk]);
-          for (size_t q = 0; q < st.size(); ++q) pieces.emplace_back(st[q], q + 1 < st.size() ? st[q + 1] : gp.second);
+          for (size_t q = 0; q < st.size(); ++q) pieces.push_back(Gap{st[q], q + 1 < st.size() ? st[q + 1] : gp.second, gp.mult});
         }
       }
-      if (n_seg + pieces.size() > max_seg) return kFallbackToHost;
+      if (n_seg + pieces.size() > max_seg) { why = "more gap segments than a batch has room for"; return gz_decline(__LINE__, kFallbackRest); }
       const uint32_t first = n_seg;
       for (auto& gp : pieces) {
         GzSeg& sg = h_segs[n_seg];
         sg.start_bit = gp.first;
         sg.stop_bit = gp.second;
-        const uint64_t cap = std::min<uint64_t>(seg_cap(gp.first, gp.second), 0x3F000000u);
-        if (pool_used + kGzWindow + cap > pool_syms) return kFallbackToHost;
-        sg.sym_off = pool_used;
+        const uint64_t cap = seg_cap(gp.first, gp.second, gp.mult);
+        if (pool_used + kGzWindow + cap > 2 * res_out) { why = "a batch's symbols outgrow every bound"; return gz_decline(__LINE__, kFallbackRest); }
+        if (int r = gz_take(sl.sym, kGzWindow + cap, &sg.sym_off)) return r;      // (a new chunk if need be: the decode of the next batch, in the other slot, is not disturbed)
         sg.cap = (uint32_t)cap;
         sg.reserved = 0;
         pool_used += kGzWindow + cap;
         ++n_seg;
       }
-      if (n_seg == first) return kFallbackToHost;
+      if (n_seg == first) return SCFQ_GZ_DECLINE;
       if (verbose) std::fprintf(stderr, "scfq gzdev:   batch %u round %d: %u gap segments\n", k, round + 1, n_seg - first);
       ++n_gap_rounds;
       HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs + sizeof(GzSeg) * first, h_segs + first, sizeof(GzSeg) * (n_seg - first), hipMemcpyHostToDevice, c->compute));
       hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg - first + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, c->compute,
-                         vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs) + first, n_seg - first, sl.d_sym,
+                         vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs) + first, n_seg - first, sl.sym.base(),
                          reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs) + first, inflate_serial_loop());
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(h_outs + first, sl.d_meta + off_outs + sizeof(GzSegOut) * first, sizeof(GzSegOut) * (n_seg - first), hipMemcpyDeviceToHost, c->compute));
@@ -511,19 +654,38 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
         parts_here.back().len += h_outs[s].n_sym;
         v = (uint32_t)std::min<uint64_t>(kGzWindow, (uint64_t)v + h_outs[s].n_sym);
         const uint32_t nt = (h_outs[s].n_sym + kResolveTile - 1) / kResolveTile;
-        if (n_work + nt > max_work) return kFallbackToHost;
+        if (n_work + nt > max_work) { why = "more resolve tiles than a batch's tables hold"; return gz_decline(__LINE__, kFallbackRest); }
         for (uint32_t t = 0; t < nt; ++t) { h_we[n_work] = q; h_wt[n_work] = t; ++n_work; }
       }
       h_first[n_chains] = n_chain;
       if (n_chain) valid_end = (!finished_end && chain[n_chain - 1].member == member_end_no) ? v : 0u;
     }
-    if (batch_out > out_max) return kFallbackToHost;
+    if (batch_out + 2 * kStagePad > res_out) { why = "a batch inflates to more than the reserved range"; return gz_decline(__LINE__, kFallbackRest); }
+    {
+      // (every test that can send this batch elsewhere comes before the first launch that writes the batch's bytes)
+      uint64_t nt_all = 0;
+      for (const PartHere& ph : parts_here) nt_all += (ph.len + kCrcTile - 1) / kCrcTile;
+      if (4 * (16 + tiles_used + nt_all) > res_crc) { why = "more CRC tiles than the reserved range holds"; return gz_decline(__LINE__, kFallbackRest); }
+    }
     walk_ms += std::chrono::duration<double, std::milli>(clk::now() - tw).count();
     if (n_chain) {
+      // room for what this batch turned out to need.  A bigger buffer than the last batch's is a NEW buffer (the old one, which the
+      // last batch's scan may still be reading, is freed when the call ends): that batch's last byte — this batch's look-behind —
+      // moves over with a one-byte copy
+      uint8_t* const old_out = d_out;
+      bool parked = false;
+      if (int r = gz_buf(g, g.out, std::max<uint64_t>(batch_out, (uint64_t)((double)(copy_end_of(k) - byte0_of(k)) * ratio_est * 0.8)) + 2 * kStagePad)) return r;
+      d_out = g.out.p + kStagePad;
+      if (have_prev_out && old_out != d_out) {
+        HIPCHK(hipMemcpyAsync(d_out - 1, old_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToDevice, c->compute));
+        parked = true;
+      }
+      uint16_t* const d_sym = sl.sym.base();
+      uint8_t* const d_win = g.win.p;
       const bool carry_in = chain[0].member == member_no && valid > 0;                                     // the first chain goes on inside a member begun earlier
       const bool carry_out = !finished_end && chain[n_chain - 1].member == member_end_no;               // the last chain's member goes on in the next batch
       // the byte in front of this batch's output is the last byte of the batch before it: parked below the buffer before that is overwritten
-      if (have_prev_out) HIPCHK(hipMemcpyAsync(d_out - 1, d_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToDevice, c->compute));
+      if (have_prev_out && !parked) HIPCHK(hipMemcpyAsync(d_out - 1, d_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToDevice, c->compute));
       HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_chain, g.h_pmeta[pp] + offp_chain, sizeof(GzChain) * n_chain, hipMemcpyHostToDevice, c->compute));
       HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_first, g.h_pmeta[pp] + offp_first, 4ull * (n_chains + 1), hipMemcpyHostToDevice, c->compute));
       if (n_work) {
@@ -537,7 +699,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
       if (n_chain <= n_chains + group) {
         // short chains: one walk per member
         hipLaunchKernelGGL(gz_window_chain, dim3(n_chains), dim3(1024), 0, c->compute, d_chain, reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_first),
-                           sl.d_sym, g.d_win, w_in, w_out, (const uint8_t*)nullptr);
+                           d_sym, d_win, w_in, w_out, (const uint8_t*)nullptr);
       } else {
         // groups of `group` entries inside every member's chain: maps, windows in front of the groups, windows in front of the entries
         GzChain* h_gchain = reinterpret_cast<GzChain*>(g.h_pmeta[pp] + offp_gchain);
@@ -547,7 +709,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
         for (uint32_t ch = 0; ch < n_chains; ++ch) {
           h_mfirst[ch] = n_groups;
           for (uint32_t q = h_first[ch]; q < h_first[ch + 1]; q += group) {
-            if (n_groups >= max_groups) return kFallbackToHost;
+            if (n_groups >= max_groups) return SCFQ_GZ_DECLINE;      // (cannot happen: max_groups covers a group per member and per 64 entries)
             h_gfirst[n_groups] = q;
             h_gchain[n_groups] = GzChain{};
             h_gchain[n_groups].sym_off = (uint64_t)n_groups * kGzWindow;       // (map g lies one window further: the form of a segment's symbols)
@@ -557,16 +719,19 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
         }
         h_mfirst[n_chains] = n_groups;
         h_gfirst[n_groups] = n_chain;
+        // (a bigger map buffer than the last batch's is a new one: that batch's window kernels are behind this batch's on the same stream)
+        if (int r = gz_buf(g, g.maps, 2ull * kGzWindow * (n_groups + 1))) return r;
+        if (int r = gz_buf(g, g.gwin, (uint64_t)kGzWindow * n_groups)) return r;
         HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gchain, h_gchain, sizeof(GzChain) * n_groups, hipMemcpyHostToDevice, c->compute));
         HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gfirst, h_gfirst, 4ull * (n_groups + 1), hipMemcpyHostToDevice, c->compute));
         HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_mfirst, h_mfirst, 4ull * (n_chains + 1), hipMemcpyHostToDevice, c->compute));
         const uint32_t* d_gfirst = reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_gfirst);
-        hipLaunchKernelGGL(gz_window_maps, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, sl.d_sym, reinterpret_cast<uint16_t*>(g.d_maps));
+        hipLaunchKernelGGL(gz_window_maps, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, d_sym, reinterpret_cast<uint16_t*>(g.maps.p));
         hipLaunchKernelGGL(gz_window_chain, dim3(n_chains), dim3(1024), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_gchain),
-                           reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_mfirst), reinterpret_cast<const uint16_t*>(g.d_maps), g.d_gwin, w_in, w_out,
+                           reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_mfirst), reinterpret_cast<const uint16_t*>(g.maps.p), g.gwin.p, w_in, w_out,
                            (const uint8_t*)nullptr);
-        hipLaunchKernelGGL(gz_window_chain, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, sl.d_sym, g.d_win, (const uint8_t*)nullptr,
-                           (uint8_t*)nullptr, (const uint8_t*)g.d_gwin);
+        hipLaunchKernelGGL(gz_window_chain, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, d_sym, d_win, (const uint8_t*)nullptr,
+                           (uint8_t*)nullptr, (const uint8_t*)g.gwin.p);
       }
       HIPCHK(hipGetLastError());
       span_end(sp_chain, c->compute);
@@ -574,18 +739,17 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
       if (n_work) {
         span_begin(sp_resolve, c->compute);
         hipLaunchKernelGGL(gz_resolve, dim3((unsigned)n_work), dim3(256), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_chain),
-                           reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_we), reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_wt), sl.d_sym,
-                           g.d_win, d_out, reinterpret_cast<uint32_t*>(g.d_crc));
+                           reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_we), reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_wt), d_sym,
+                           d_win, d_out, reinterpret_cast<uint32_t*>(g.crc.p));
         HIPCHK(hipGetLastError());
         span_end(sp_resolve, c->compute);
       }
       span_begin(sp_crc, c->compute);
       for (const PartHere& ph : parts_here) {
         const uint64_t nt = (ph.len + kCrcTile - 1) / kCrcTile;
-        if (tiles_used + nt > crc_tiles_max) return kFallbackToHost;
         if (nt) {
           hipLaunchKernelGGL(gz_crc32_tiles, dim3((unsigned)nt), dim3(256), 0, c->compute, d_out + ph.off, ph.len, nt * kCrcTile - ph.len,
-                             reinterpret_cast<uint32_t*>(g.d_crc) + 16 + tiles_used);
+                             reinterpret_cast<uint32_t*>(g.crc.p) + 16 + tiles_used);
           HIPCHK(hipGetLastError());
         }
         parts.push_back(GzPart{ph.member, ph.len, tiles_used, nt});
@@ -611,42 +775,94 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     return SCFQ_OK;
   };
 
+  // ---- every member's ISIZE and CRC-32 (members that ended so far; what is left over is the prefix of the member `pos` lies in) --
+  size_t parts_checked = 0, ends_checked = 0;
+  uint32_t prefix_raw = 0;
+  uint64_t prefix_len = 0;
+  auto check_members = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(g.h_crc, g.crc.p, 4 * (16 + tiles_used), hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    const uint32_t* hc = reinterpret_cast<const uint32_t*>(g.h_crc);
+    if (hc[0]) return SCFQ_GZ_DECLINE;                 // a reference before a member's start
+    const uint32_t x_tile = gz_xpow8n(kCrcTile);
+    auto fold_part = [&](const GzPart& pt, uint32_t* raw, uint64_t* len) {
+      uint32_t r = 0;
+      for (uint64_t t = 0; t < pt.n_tiles; ++t) r = gz_mulmod(x_tile, r) ^ hc[16 + pt.tile_at + t];
+      *raw = gz_mulmod(gz_xpow8n(pt.len), *raw) ^ r;
+      *len += pt.len;
+    };
+    for (; ends_checked < member_ends.size(); ++ends_checked) {
+      const GzMemberEnd& me = member_ends[ends_checked];
+      uint32_t raw = 0;
+      uint64_t len = 0;       // (64 bits: ISIZE is the length modulo 2^32, a member may be longer)
+      for (; parts_checked < parts.size() && parts[parts_checked].member == me.member; ++parts_checked) fold_part(parts[parts_checked], &raw, &len);
+      const uint32_t crc = raw ^ gz_mulmod(gz_xpow8n(len), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+      if ((uint32_t)(len & 0xFFFFFFFFull) != me.isize || crc != me.crc) {
+        if (verbose) std::fprintf(stderr, "scfq gzdev: member %u: %llu bytes, CRC-32 %08x; its trailer says %u, %08x: host path\n", me.member,
+                                  (unsigned long long)len, crc, me.isize, me.crc);
+        return SCFQ_GZ_DECLINE;
+      }
+    }
+    prefix_raw = 0; prefix_len = 0;
+    for (size_t q = parts_checked; q < parts.size(); ++q) {
+      if (parts[q].member != member_no) return SCFQ_GZ_DECLINE;
+      fold_part(parts[q], &prefix_raw, &prefix_len);
+    }
+    return SCFQ_OK;
+  };
+
   // ---- the pipeline -----------------------------------------------------------------------------------------------------------
-  for (uint32_t it = 0; it < nb + 2; ++it) {
-    if (it < nb && (rc = stage_a(it))) return rc;
-    if (it >= 1 && it - 1 < nb && (rc = stage_b(it - 1))) return rc;
+  int fail = SCFQ_OK;
+  for (uint32_t it = 0; it < nb + 2 && !fail; ++it) {
+    auto timed = [&](int which, int r) { return r; };
+    (void)timed;
+    // copy + search run ONE batch ahead of where their results are needed: the search of batch it + 1 is queued before the host waits
+    // for the search of batch it (launched an iteration ago), so that wait is short even when the decode waves of two batches fill
+    // the device and a search workgroup only gets the slots they leave
+    { const auto t0 = clk::now();
+      if (it == 0) fail = stage_a(0);
+      if (!fail && it + 1 < nb) fail = stage_a(it + 1);
+      if (!fail && it < nb) fail = stage_a_wait(it);
+      stage_ms[0] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
+    { const auto t0 = clk::now(); if (it >= 1 && it - 1 < nb) fail = stage_b(it - 1); stage_ms[1] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
     if (it >= 2) {
-      if ((rc = stage_c(it - 2))) return rc;
+      { const auto t0 = clk::now(); fail = stage_c(it - 2); stage_ms[2] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+      if (fail) break;
       if (finished) break;              // (trailing garbage may leave batches behind the last member: nothing in them counts)
     }
   }
-  if (!finished) return kFallbackToHost;               // the data ended inside a member
-
-  // ---- every member's ISIZE and CRC-32 ------------------------------------------------------------------------------------------
-  HIPCHK(hipMemcpyAsync(g.h_crc, g.d_crc, 4 * (16 + tiles_used), hipMemcpyDeviceToHost, c->compute));
-  HIPCHK(hipStreamSynchronize(c->compute));
-  {
-    const uint32_t* hc = reinterpret_cast<const uint32_t*>(g.h_crc);
-    if (hc[0]) return kFallbackToHost;                 // a reference before a member's start
-    const uint32_t x_tile = gz_xpow8n(kCrcTile);
-    size_t pi = 0;
-    for (const GzMemberEnd& me : member_ends) {
-      uint32_t raw = 0;
-      uint64_t len = 0;
-      for (; pi < parts.size() && parts[pi].member == me.member; ++pi) {
-        uint32_t r = 0;
-        for (uint64_t t = 0; t < parts[pi].n_tiles; ++t) r = gz_mulmod(x_tile, r) ^ hc[16 + parts[pi].tile_at + t];
-        raw = gz_mulmod(gz_xpow8n(parts[pi].len), raw) ^ r;
-        len += parts[pi].len;
-      }
-      const uint32_t crc = raw ^ gz_mulmod(gz_xpow8n(len), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
-      if ((uint32_t)len != me.isize || crc != me.crc) {
-        if (verbose) std::fprintf(stderr, "scfq gzdev: member %u: %llu bytes, CRC-32 %08x; its trailer says %u, %08x: host path\n", me.member,
-                                  (unsigned long long)len, crc, me.isize, me.crc);
-        return kFallbackToHost;
-      }
-    }
-    if (pi != parts.size()) return kFallbackToHost;
+  if (fail < 0) return fail;
+  if (!fail && !finished) return SCFQ_GZ_DECLINE;      // the data ended inside a member
+  bool resumed = false;
+  if (fail) {
+    // A batch the device path cannot take for want of room (kFallbackRest: nothing suspect about the data).  What the batches before
+    // it folded STAYS: the host's decoder carries on from the exact bit the chain has reached, with the window in front of it and
+    // the CRC-32 / length of the member so far — instead of round 2's restart of the whole file on the host.  (Before the first
+    // batch is through, and for anything that smells of damaged data, the whole file is still the host's: its readers are
+    // gzread byte for byte, error text included.)
+    static const bool resume_on = env_int("SCFQ_GZ_DEVICE_RESUME", 1) != 0;
+    if (fail != kFallbackRest || total_out == 0 || !resume_on) return SCFQ_GZ_DECLINE;
+    for (hipStream_t st : {c->copy, g.s_search, g.s_decode[0], g.s_decode[1], c->compute}) HIPCHK(hipStreamSynchronize(st));
+    if ((rc = check_members())) return rc;
+    std::vector<uint8_t> window(kGzWindow, 0);
+    if (valid) HIPCHK(hipMemcpy(window.data(), g.d_wcarry + (uint64_t)wcarry * kGzWindow, kGzWindow, hipMemcpyDeviceToHost));
+    int prev = -1;
+    if (have_prev_out) { uint8_t pb = 0; HIPCHK(hipMemcpy(&pb, d_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToHost)); prev = pb; }
+    const uint32_t crc_prefix = prefix_raw ^ gz_mulmod(gz_xpow8n(prefix_len), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+    if (verbose) std::fprintf(stderr, "scfq gzdev: %s: %llu bytes are through, the host's decoder takes the file from bit %llu (%.1f %%)\n", why ? why : "a batch without room",
+                              (unsigned long long)total_out, (unsigned long long)pos, 100.0 * (double)pos / (double)end_bit);
+    struct RestSource : Source {
+      scfq_gzfast::Resume rs;
+      int64_t fill(uint8_t* dst, uint64_t cap) override { const int64_t r = rs.next_chunk(dst, cap); return r < 0 ? (int64_t)SCFQ_EGZ : r; }
+    } rest;
+    rest.rs.open(img, (size_t)fsize, pos, window.data(), valid, crc_prefix, prefix_len);
+    rc = ingest(c, rest, prev, flags, 64ull << 20, timing);
+    if (rc) return rc;
+    resumed = true;
+  } else if ((rc = check_members())) {
+    return rc;
+  } else if (parts_checked != parts.size()) {
+    return SCFQ_GZ_DECLINE;
   }
   c->timing.host_fill_ms += fill_ms;
   c->timing.ingest_wall_ms += std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
@@ -663,9 +879,12 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "scan", sum(sp_scan));
     std::fprintf(stderr, "scfq gzdev: host: pinned-buffer waits %.1f, memcpy %.1f, copy enqueue %.1f, search waits %.1f, decode waits %.1f, post waits %.1f ms\n", h_evsync_ms,
                  h_memcpy_ms, h_enqueue_ms, h_search_wait_ms, h_dec_wait_ms, h_post_wait_ms);
+    std::fprintf(stderr, "scfq gzdev: host time in stage A (copy, search) %.1f, B (plan, decode launch) %.1f, C (walk, windows, bytes, scan) %.1f ms; of all that inside device allocations %.1f ms\n",
+                 stage_ms[0], stage_ms[1], stage_ms[2], gz_alloc_ms());
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "wall", std::chrono::duration<double, std::milli>(clk::now() - t_begin).count());
-    std::fprintf(stderr, "scfq gzdev: %u batch(es), %u segments planned, %u decoded (%u gap rounds), %u on the chain, %zu member(s), %llu bytes inflated\n", nb,
-                 n_planned_total, n_decoded_total, n_gap_rounds, n_chain_total, member_ends.size(), (unsigned long long)total_out);
+    std::fprintf(stderr, "scfq gzdev: %u batch(es), %u segments planned, %u decoded (%u gap rounds, %u segments given more room), %u on the chain, %zu member(s), %llu bytes inflated%s\n", nb,
+                 n_planned_total, n_decoded_total, n_gap_rounds, n_overflows, n_chain_total, member_ends.size(), (unsigned long long)total_out, resumed ? " on the device, the rest on the host" : "");
+    std::fprintf(stderr, "scfq gzdev: device memory high water %.2f GB (this path holds %.2f GB now)\n", (double)g_dev_high.load() / 1e9, (double)g.held() / 1e9);
   }
   return SCFQ_OK;
 }
@@ -681,5 +900,6 @@ int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags,
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
   for (int b = 0; b < 2; ++b) if (g.s_decode[b]) (void)hipStreamSynchronize(g.s_decode[b]);
   if (c->compute) (void)hipStreamSynchronize(c->compute);
+  gz_free_retired(&g);
   return rc;
 }

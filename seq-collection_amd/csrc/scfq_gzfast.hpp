@@ -222,4 +222,80 @@ class Stream {
   uint32_t crc_ = 0, isize_ = 0;
 };
 
+// The REST of a gzip stream from a position in the middle of a member: the device inflate path (scfq_gzdev.hpp) hands over
+// here when a batch is more than it can take — what its earlier batches folded stays, the host carries on from the exact bit
+// the device's chain had reached, with the 32 KiB of history in front of it and the CRC-32 / length of the member so far.
+// Same bytes and the same accept / reject decisions as Stream (and zlib's gzread): the current member's trailer is checked
+// against prefix + rest, further members follow, trailing garbage is ignored.  One thread, the serial decoder: this is the
+// rare path.
+class Resume {
+ public:
+  // img[0 .. n): the whole file.  bit: a block header inside a member, or the first block of a member (then valid = 0, the
+  // prefix is empty).  window: 32 KiB whose last `valid` bytes are the member's output in front of `bit`.
+  // crc_prefix / len_prefix: zlib crc32 and length of the member's output in front of `bit`.
+  void open(const uint8_t* img, size_t n, uint64_t bit, const uint8_t* window, uint32_t valid, uint32_t crc_prefix, uint64_t len_prefix) {
+    img_ = img; n_ = n;
+    window_.assign(window, window + kWindow);
+    dec_.reset(new scfq_inflate::Decoder());
+    dec_->begin_at_bit(img, img + n, bit);
+    dec_->total_out = valid;
+    crc_ = crc_prefix;
+    len_ = len_prefix;
+  }
+  // up to cap bytes of the inflated stream into dst; 0 at the end, -1 on a corrupt stream
+  int64_t next_chunk(uint8_t* dst, uint64_t cap) {
+    if (finished_) return failed_ ? -1 : 0;
+    if (buf_.size() < kWindow + cap + 512) buf_.resize(kWindow + (size_t)cap + 512);
+    std::memcpy(buf_.data(), window_.data(), kWindow);
+    uint8_t* const base = buf_.data() + kWindow;
+    uint8_t* out = base;
+    uint8_t* const out_end = base + cap;
+    size_t from = 0;
+    bool bad = false, last = false;
+    const uint8_t* const end = img_ + n_;
+    for (;;) {
+      const int r = dec_->run(out, out_end);
+      if (r == scfq_inflate::kNeedOutput) break;
+      if (r < 0) { bad = true; break; }
+      const uint8_t* t = dec_->end_of_stream();
+      if (t > end || end - t < 8) { bad = true; break; }
+      const size_t off = (size_t)(out - base);
+      crc_ = scfq_crc::crc32(crc_, base + from, off - from);
+      len_ += off - from;
+      from = off;
+      const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+      const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+      if (crc != crc_ || isize != (uint32_t)len_) { bad = true; break; }
+      crc_ = 0; len_ = 0;
+      t += 8;
+      const long nh = member_header(t, (size_t)(end - t));
+      if (nh == 0) { last = true; break; }
+      if (nh < 0) { bad = true; break; }
+      dec_->begin(t + nh, end);
+    }
+    const size_t n_out = (size_t)(out - base);
+    if (n_out > cap) { failed_ = finished_ = true; return -1; }
+    crc_ = scfq_crc::crc32(crc_, base + from, n_out - from);
+    len_ += n_out - from;
+    std::memcpy(dst, base, n_out);
+    if (n_out >= kWindow) std::memcpy(window_.data(), out - kWindow, kWindow);
+    else {
+      std::memmove(window_.data(), window_.data() + n_out, kWindow - n_out);
+      std::memcpy(window_.data() + kWindow - n_out, base, n_out);
+    }
+    if (bad) { failed_ = finished_ = true; return -1; }
+    if (last) finished_ = true;
+    return (int64_t)n_out;
+  }
+
+ private:
+  const uint8_t* img_ = nullptr;
+  size_t n_ = 0;
+  std::vector<uint8_t> window_, buf_;
+  std::unique_ptr<scfq_inflate::Decoder> dec_;
+  uint32_t crc_ = 0;
+  uint64_t len_ = 0;
+  bool finished_ = false, failed_ = false;
+};
+
 }  // namespace scfq_gzfast

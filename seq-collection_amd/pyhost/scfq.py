@@ -31,7 +31,7 @@ HIST_WORDS = 4 * 256
 EXPORTS = [
     "scfq_count_file", "scfq_count_buffer", "scfq_partial_buffer", "scfq_partial_identity",
     "scfq_partial_combine", "scfq_partial_finalize", "scfq_format_tsv", "scfq_strerror",
-    "scfq_last_error_detail", "scfq_last_timing", "scfq_device_count", "scfq_shutdown",
+    "scfq_last_error_detail", "scfq_last_timing", "scfq_device_bytes_now", "scfq_device_bytes_high_water", "scfq_device_count", "scfq_shutdown",
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
     "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
     "scfq_index_lines", "scfq_dedup_buffer", "scfq_dedup_file", "scfq_dedup_error_detail", "scfq_stage_file",
@@ -157,6 +157,8 @@ def lib():
         L.scfq_comm_init_all.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, pvp]
         L.scfq_comm_world.argtypes = [vp]
         L.scfq_comm_rank.argtypes = [vp]
+        L.scfq_device_bytes_now.restype = ctypes.c_uint64
+        L.scfq_device_bytes_high_water.restype = ctypes.c_uint64
         L.scfq_comm_is_broken.argtypes = [vp]
         L.scfq_prepare.argtypes = [ctypes.POINTER(Opts)]
         L.scfq_comm_transport.argtypes = [vp]

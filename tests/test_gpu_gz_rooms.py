@@ -1,0 +1,184 @@
+"""Device gzip path (csrc/scfq_gzdev.hpp), the memory side of it: a segment's output room comes from an estimate, so a segment that
+compresses better is decoded again with more room (never the whole file on the host); a batch that has no room at all hands the
+REST of the file to the host's decoder and keeps what the batches before it folded; any number of members; members and files
+beyond 4 GiB of inflated bytes (ISIZE is a length modulo 2^32).  Rows must be the oracle's / the generator's tallies.
+Reference: src/fq_count.nim:30-34, gzip_stream.nim:16-17 (zlib gzread)."""
+import os
+import struct
+import subprocess
+import sys
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from conftest import PKG
+from test_ingest_sources import fastq_bytes
+
+pytestmark = pytest.mark.gpu
+
+SC = os.path.join(PKG, "sc")
+DEV_ENV = {"SCFQ_GZ_DEVICE_MIN_MB": "0", "SCFQ_GZ_DEVICE_SEGMENT_KB": "32", "SCFQ_VERBOSE": "1"}
+BATCH_ENV = dict(DEV_ENV, SCFQ_GZ_DEVICE_BATCH_SEGMENTS="8", SCFQ_GZ_DEVICE_CHAIN_GROUP="3")
+
+
+def run(path, **env):
+    return subprocess.run([SC, "fq-count", str(path)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+
+
+def member(data, level=6):
+    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    return co.compress(data) + co.flush()
+
+
+def test_segment_that_needs_more_room_is_decoded_again(gpu, oracle, tmp_path):
+    data = fastq_bytes(6_000_000, seed=77)
+    f = tmp_path / "tight.fq.gz"
+    f.write_bytes(member(data))
+    want = oracle.tsv(oracle.count(np.frombuffer(data, dtype=np.uint8))) + "\n"
+    # room for 2 symbols per compressed byte (+ 128 Ki) where the data needs 4.4: every segment of 128 KiB overflows once and is decoded
+    # again with 4 x the room; with 0.4 per byte twice (4 x, 16 x)
+    big = dict(SCFQ_GZ_DEVICE_SEGMENT_KB="128")
+    for env in (dict(DEV_ENV, SCFQ_GZ_DEVICE_RATIO="2", **big), dict(BATCH_ENV, SCFQ_GZ_DEVICE_RATIO="2", **big), dict(DEV_ENV, SCFQ_GZ_DEVICE_RATIO="0.4", **big)):
+        r = run(f, **env)
+        assert r.returncode == 0 and r.stdout == want, r.stderr[-3000:]
+        assert "on the chain" in r.stderr and "the rest on the host" not in r.stderr, r.stderr[-3000:]
+        given = [l for l in r.stderr.splitlines() if "segments given more room" in l]
+        assert given and " 0 segments given more room" not in given[-1], r.stderr[-2000:]
+    # the estimate taken from the file itself leaves every segment room enough
+    r = run(f, **DEV_ENV)
+    assert r.returncode == 0 and r.stdout == want and " 0 segments given more room" in r.stderr, r.stderr[-2000:]
+
+
+def test_batch_without_room_hands_the_rest_to_the_host(gpu, oracle, tmp_path):
+    data = fastq_bytes(7_000_000, seed=78)
+    cuts = [0, 2_000_003, 2_000_003 + 41, 5_100_000, len(data)]
+    one = tmp_path / "one_member.fq.gz"
+    one.write_bytes(member(data))
+    four = tmp_path / "four_members.fq.gz"
+    four.write_bytes(b"".join(member(data[a:b]) for a, b in zip(cuts[:-1], cuts[1:])) + b"trailing garbage")
+    want = oracle.tsv(oracle.count(np.frombuffer(data, dtype=np.uint8))) + "\n"
+    for f in (one, four):
+        for at in (1, 3, 5):
+            r = run(f, **dict(BATCH_ENV, SCFQ_GZ_DEVICE_TEST_REST_AT=str(at)))
+            assert r.returncode == 0 and r.stdout == want, (f.name, at, r.stderr[-3000:])
+            assert "the rest on the host" in r.stderr, (f.name, at, r.stderr[-3000:])
+        # batch 0 without room: nothing is through yet, the whole file is the host's
+        r = run(f, **dict(BATCH_ENV, SCFQ_GZ_DEVICE_TEST_REST_AT="0"))
+        assert r.returncode == 0 and r.stdout == want and "on the chain" not in r.stderr, r.stderr[-2000:]
+    # a damaged tail behind the hand-over is still gzread's error, same text as the host path
+    bad = bytearray(one.read_bytes())
+    bad[-3] ^= 0x10
+    g = tmp_path / "bad_isize.fq.gz"
+    g.write_bytes(bytes(bad))
+    host = run(g, SCFQ_GZ_DEVICE="0")
+    dev = run(g, **dict(BATCH_ENV, SCFQ_GZ_DEVICE_TEST_REST_AT="5"))
+    strip = lambda s: "\n".join(l for l in s.splitlines() if not l.startswith("scfq"))     # noqa: E731
+    assert host.returncode != 0 and (dev.returncode, dev.stdout, strip(dev.stderr)) == (host.returncode, host.stdout, strip(host.stderr)), dev.stderr[-2000:]
+
+
+def test_more_than_1024_members(gpu, scfq, tmp_path):
+    plan = scfq.synth_plan(0, 20260105, 170_000_000)
+    data, info = scfq.synth_host(0, 20260105, plan.records)
+    n = 1300
+    cuts = [data.size * k // n for k in range(n + 1)]         # members end at arbitrary bytes
+    with ThreadPoolExecutor(8) as ex:
+        blobs = list(ex.map(lambda ab: member(data[ab[0]:ab[1]].tobytes(), 1), zip(cuts[:-1], cuts[1:])))
+    f = tmp_path / "members.fq.gz"
+    f.write_bytes(b"".join(blobs))
+    r = run(f, SCFQ_GZ_DEVICE_MIN_MB="0", SCFQ_VERBOSE="1", SCFQ_GZ_DEVICE_SEGMENT_KB="32")
+    assert r.returncode == 0 and r.stdout == "%d\t%s\t%d\t%d\t%d\n" % (plan.records, r.stdout.split("\t")[1], info.gc_bases, info.n_bases, info.bases), r.stderr[-3000:]
+    assert "%d member(s)" % n in r.stderr and "on the chain" in r.stderr, r.stderr[-3000:]
+
+
+def _pigz_like(path, raw, level=1, step=64 << 20, threads=16):
+    """one gzip member written the way pigz does: raw deflate of pieces joined by sync flushes, CRC-32 and ISIZE (mod 2^32) of the whole"""
+    cuts = list(range(0, raw.size, step))
+
+    def piece(i):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        chunk = raw[cuts[i]:cuts[i] + step].tobytes()
+        return co.compress(chunk) + co.flush(zlib.Z_FINISH if i == len(cuts) - 1 else zlib.Z_SYNC_FLUSH), zlib.crc32(chunk), len(chunk)
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(piece, range(len(cuts))))
+    crc = 0
+    for _, c, ln in parts:
+        crc = _crc32_combine(crc, c, ln)
+    with open(path, "wb") as f:
+        f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+        for b, _, _ in parts:
+            f.write(b)
+        f.write(struct.pack("<II", crc & 0xFFFFFFFF, raw.size & 0xFFFFFFFF))
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (not exported by the Python module): crc of A || B from crc(A), crc(B), |B|"""
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+    if len2 <= 0:
+        return crc1
+    odd = [0xEDB88320] + [1 << n for n in range(31)]
+    even = square(odd)
+    odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
+def test_crc32_combine_helper():
+    a, b = os.urandom(1000), os.urandom(77777)
+    assert _crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+
+
+def test_member_beyond_4_gib(gpu, scfq, tmp_path):
+    """4.6 GB in ONE member (ISIZE wraps) through the device gzip path, and the same bytes as BGZF through the device BGZF path:
+    counters == the generator's tallies (src/fq_count.nim:38-45 on bytes gzread would yield)"""
+    plan = scfq.synth_plan(0, 20260104, int(4.6e9))
+    assert plan.bytes > (1 << 32) + (200 << 20)
+    data, info = scfq.synth_host(0, 20260104, plan.records)
+    want = "%d\t" % plan.records, "\t%d\t%d\t%d\n" % (info.gc_bases, info.n_bases, info.bases)
+    f = tmp_path / "big_member.fq.gz"
+    _pigz_like(str(f), data)
+    r = subprocess.run([SC, "fq-count", str(f)], capture_output=True, text=True, env=dict(os.environ, SCFQ_VERBOSE="1"), timeout=900)
+    assert r.returncode == 0 and r.stdout.startswith(want[0]) and r.stdout.endswith(want[1]), r.stderr[-3000:]
+    assert "on the chain" in r.stderr and "the rest on the host" not in r.stderr and "%d bytes inflated" % plan.bytes in r.stderr, r.stderr[-2000:]
+    os.remove(f)
+
+    def block(b):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        payload = co.compress(b) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(payload) + 8 - 1) + payload +
+                struct.pack("<II", zlib.crc32(b) & 0xFFFFFFFF, len(b)))
+
+    def span(i):
+        a = data[i:i + (32 << 20)]
+        return b"".join(block(a[o:o + 65280].tobytes()) for o in range(0, a.size, 65280))
+    g = tmp_path / "big_bgzf.fq.gz"
+    with ThreadPoolExecutor(16) as ex, open(g, "wb") as out:
+        for s in ex.map(span, range(0, data.size, 32 << 20)):
+            out.write(s)
+        out.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    r = subprocess.run([SC, "fq-count", "--stats", str(g)], capture_output=True, text=True, env=dict(os.environ, SCFQ_VERBOSE="1"), timeout=900)
+    assert r.returncode == 0 and r.stdout.startswith(want[0]) and r.stdout.endswith(want[1]), r.stderr[-3000:]
+    assert '"input_bytes": %d' % plan.bytes in r.stderr and int(r.stderr.split('"h2d_bytes": ')[1].split(",")[0].rstrip("}")) < plan.bytes // 2, r.stderr[-2000:]
