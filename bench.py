@@ -6,9 +6,12 @@ ranks) over one HBM-resident batch of synthetic FASTQ.  N=1 workload = BASELINE.
 synthetic 10 GB uncompressed 150 bp Illumina FASTQ (seed 20260101).  N>1 workload =
 BASELINE.json configs[2]: every rank holds its own 25 GB byte range (200 GB / 8) of one N x 25 GB record
 stream (seed 20260102), cut at ARBITRARY byte offsets (not record aligned), scans it, and the ranks
-exchange their 32-word partials with one RCCL all-gather issued by the C library itself (scfq_comm_*,
+exchange their 32-word partials with one RCCL all-gather issued by the C library itself (scfq_comm_*: its own rendezvous,
 librccl; the combine is ordered / non-commutative, so a sum-allreduce of counters would be wrong)
--> "scaling": "weak".  torch.distributed only provides the contract's barrier and the max over ranks.
+-> "scaling": "weak".  torch.distributed only provides the contract's barrier and the max over ranks (control plane: gloo by
+default, so that the library's RCCL communicator is the only one a rank creates).  At N=1 the line also carries a non-headline
+`ingest` object: a gzip member and a BGZF file of the same stream, written here, counted by a fresh `sc fq-count` process (cold)
+and by the second call in this process (warm) — BASELINE configs[3] end to end, compressed bytes over PCIe, inflate on the device.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -70,6 +73,82 @@ def cpu_all_cores(L, host, nbytes, threads):
     return time.perf_counter() - t0, acc
 
 
+def ingest_rows(scfq, nbytes):
+    """Non-headline: BASELINE configs[3] end to end — a gzip member and a BGZF file of the same synthetic stream, written here,
+    counted (a) by a fresh `sc fq-count` process, which is how the reference is used (one call per process, sc.nim:114-116): wall
+    time of the whole process, context and buffers included, and (b) by the second call in this process (buffers in place).
+    Compressed bytes cross PCIe and are inflated on the device.  Counters must equal the generator's tallies."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    plan = scfq.synth_plan(0, SEED, nbytes)
+    data, info = scfq.synth_host(0, SEED, plan.records)
+    want = (plan.records, info.gc_bases, info.n_bases, info.bases)
+    tmp = tempfile.mkdtemp(prefix="scfq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    rows = {"inflated_bytes": int(data.size), "what": "cold = wall of a fresh `sc fq-count FILE` process; warm = second call in one process; "
+            "GB/s of inflated bytes; counters == generator tallies"}
+    try:
+        step = 64 << 20
+        cuts = list(range(0, data.size, step))
+
+        def piece(i):
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            chunk = data[cuts[i]:cuts[i] + step].tobytes()
+            return co.compress(chunk) + co.flush(zlib.Z_FINISH if i == len(cuts) - 1 else zlib.Z_SYNC_FLUSH)
+
+        def block(b):
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            payload = co.compress(b) + co.flush()
+            return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(payload) + 8 - 1) + payload +
+                    struct.pack("<II", zlib.crc32(b) & 0xFFFFFFFF, len(b)))
+
+        def span(i):
+            a = data[i:i + (32 << 20)]
+            return b"".join(block(a[o:o + 65280].tobytes()) for o in range(0, a.size, 65280))
+        gz = os.path.join(tmp, "member.fq.gz")
+        bg = os.path.join(tmp, "bgzf.fq.gz")
+        with ThreadPoolExecutor(16) as ex:
+            parts = list(ex.map(piece, range(len(cuts))))
+            spans = list(ex.map(span, range(0, data.size, 32 << 20)))
+        crc = 0
+        for c0 in cuts:
+            crc = zlib.crc32(data[c0:c0 + step], crc)
+        with open(gz, "wb") as f:
+            f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+            for b in parts:
+                f.write(b)
+            f.write(struct.pack("<II", crc & 0xFFFFFFFF, data.size & 0xFFFFFFFF))
+        with open(bg, "wb") as f:
+            for s_ in spans:
+                f.write(s_)
+            f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+        del parts, spans
+        sc = os.path.join(ROOT, "seq-collection_amd", "sc")
+        for name, path, how in (("gzip_member", gz, "one gzip member, zlib level 6, 64 MiB pieces joined by sync flushes (as pigz writes it)"),
+                                ("bgzf", bg, "BGZF (bgzip layout, 65280-byte blocks, level 6)")):
+            t = time.perf_counter()
+            r = subprocess.run([sc, "fq-count", path], capture_output=True, text=True)
+            cold = time.perf_counter() - t
+            f_ = r.stdout.strip().split("\t")
+            assert r.returncode == 0 and (int(f_[0]), int(f_[2]), int(f_[3]), int(f_[4])) == want, ("cold row", r.stdout, r.stderr[-500:], want)
+            walls = []
+            for _ in range(2):
+                t = time.perf_counter()
+                c = scfq.count_file(path)
+                walls.append(time.perf_counter() - t)
+                assert (c.reads, c.gc_bases, c.n_bases, c.bases) == want, ("in-process row", name)
+            rows[name] = {"layout": how, "compressed_bytes": os.path.getsize(path), "cold_process_wall_s": round(cold, 4), "cold_GBps": round(data.size / cold / 1e9, 2),
+                          "first_call_wall_s": round(walls[0], 4), "warm_wall_s": round(walls[1], 4), "warm_GBps": round(data.size / walls[1] / 1e9, 2),
+                          "counters_match_generator": True}
+        rows["device_bytes_high_water"] = int(scfq.lib().scfq_device_bytes_high_water())
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,10 +161,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra SCFQ_* flags (1 = qual hist, 2 = struct check)")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic (ablation builds): skip the counter checks")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--backend", default="gloo",
+                    help="torch.distributed backend of the CONTROL plane (the contract's barrier and the max over ranks): gloo by default — the "
+                         "data path's collective is the C library's own RCCL communicator, and a second RCCL communicator per rank (torch's) "
+                         "would only be one more thing that can fail while eight ranks come up; nccl is accepted")
     ap.add_argument("--exchange", choices=["lib", "torch"], default="lib",
-                    help="lib = the C library's own communicator (scfq_comm_*, librccl; default with the nccl backend); "
-                         "torch = the Python mirror over torch.distributed (always used with gloo)")
+                    help="lib = the C library's own communicator (scfq_comm_*: RCCL ncclAllGather inside libsc_fqcount_hip; default); "
+                         "torch = the Python mirror over torch.distributed (--backend says over what)")
+    ap.add_argument("--transport", choices=["rccl", "tcp"], default="rccl",
+                    help="transport of the library communicator: rccl (default) or tcp (rehearsals with several ranks on ONE device, which RCCL refuses)")
+    ap.add_argument("--ingest-bytes", type=float, default=2e9,
+                    help="N=1 only, after the timed region: inflated size of the gzip member / BGZF file of the non-headline `ingest` object (0 = skip)")
     ap.add_argument("--exchange-timeout-s", type=float, default=120.0, help="deadline of one exchange: a stuck collective ends the run non-zero")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo backend); the number is not a scaling result")
@@ -154,16 +240,24 @@ def main():
         rank-ordered fold) — its worker thread runs the collective while this thread is inside the C call that scans the next
         step, so submit() never blocks and wait() normally finds the result ready"""
         def __init__(self):
-            # rank 0 creates the RCCL unique id, the ranks fetch it from torch.distributed's store (no collective involved)
+            # The RCCL unique id travels through the LIBRARY's own rendezvous (scfq_comm_init_rendezvous: rank 0 listens, the ranks
+            # connect); torch.distributed only tells the ranks which port rank 0 found free (a public collective on the control plane)
+            port = [0]
+            if rank == 0:
+                import socket
+                s_ = socket.socket()
+                s_.bind(("127.0.0.1", 0))
+                port[0] = s_.getsockname()[1]
+                s_.close()
             if world > 1:
-                store = dist.distributed_c10d._get_default_store()
-                if rank == 0:
-                    store.set("scfq_comm_uid", scfq.Comm.unique_id())
-                uid = bytes(store.get("scfq_comm_uid"))
+                dist.broadcast_object_list(port, src=0)
+            transport = scfq.SCFQ_COMM_TCP if args.transport == "tcp" else scfq.SCFQ_COMM_RCCL
+            self.comm = scfq.Comm.init_rendezvous(os.environ.get("MASTER_ADDR", "127.0.0.1"), port[0], world, rank, device=local_rank,
+                                                  transport=transport, timeout_ms=tmo_ms)
+            if transport == scfq.SCFQ_COMM_TCP:
+                self.what = "all-gather of 32 x u64 partials over the library's TCP transport (scfq_comm_*, rehearsal: several ranks on one device) + rank-ordered fold"
             else:
-                uid = scfq.Comm.unique_id()
-            self.comm = scfq.Comm.init_rank(uid, world, rank, local_rank, timeout_ms=tmo_ms)
-            self.what = "%s ncclAllGather of 32 x u64 partials inside libsc_fqcount_hip (scfq_comm_*) + rank-ordered fold" % self.comm.transport
+                self.what = "%s ncclAllGather of 32 x u64 partials inside libsc_fqcount_hip (scfq_comm_*) + rank-ordered fold" % self.comm.transport
 
         def submit(self, partial):
             self.comm.start(partial, timeout_ms=tmo_ms)
@@ -219,7 +313,7 @@ def main():
     exchanger = None
     exchange_note = None
     if exchange:
-        use_lib = args.exchange == "lib" and args.backend == "nccl"
+        use_lib = args.exchange == "lib"
         if use_lib:
             # every rank must end up on the same path: a rank whose library communicator failed takes all ranks to the mirror
             ok, err = 1, ""
@@ -412,6 +506,8 @@ def main():
         assert (acc[2], acc[6], acc[10]) == (oc.gc_bases, oc.n_bases, oc.bases)
         out["cpu_all_cores"] = {"value": round(oc.bases / all_s / 1e9, 3), "unit": "Gbases/s", "threads": threads,
                                 "note": "optimised CPU restatement: byte-range shards + the same ordered fold, byte-serial scan per shard"}
+    if rank == 0 and world == 1 and args.ingest_bytes > 0 and kind == 0 and args.flags == 0:
+        out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes))
     if rank == 0:
         print(json.dumps(out))
     if exchange:

@@ -205,8 +205,13 @@ int scfq_prepare(const scfq_opts* opts);
 
 /* fq_count of ONE file by all ranks of a communicator: rank r scans bytes [size*r/world, size*(r+1)/world) of `path` — cut at
  * arbitrary byte offsets, one byte of look-behind — on the current device (or opts->device_ids[0]), the partials are
- * exchanged, every rank receives the counters of the whole file. Gzip input has no byte-range shards: rank 0 inflates and
- * scans all of it, the other ranks contribute the identity. Collective: every rank must call it. */
+ * exchanged, every rank receives the counters of the whole file.
+ * ".gz" input: a BGZF (bgzip) file shards where its members are — rank r takes the members that start in its byte range (the
+ * first cut at or after size*r/world where eight members follow one another; the byte in front of a rank's first inflated byte
+ * comes from the member before the cut, inflated on the host), inflates them on its device and scans them; the ranks agree on
+ * that with one extra all-gather of a word, and fall back together when any of them saw something else in its range. Every other
+ * gzip layout (a deflate stream has no shards): rank 0 inflates and scans all of it, the other ranks contribute the identity.
+ * Collective: every rank must call it. */
 int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* comm, scfq_counts* out);
 
 /* ---- K5: line index (record-boundary detection) ---------------------------------------------

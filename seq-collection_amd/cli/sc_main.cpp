@@ -396,6 +396,7 @@ int main(int argc, char** argv) {
     for (const auto& f : files) {
       const FileResult r = fq_count_compute(f, basename, absolute, opts, stats, comm);
       if (r.exit_code || shard_rank == 0) fq_count_emit(r);       // every rank quits with the reference's message on an error
+      else if (!r.extra.empty()) std::fputs(r.extra.c_str(), stderr);      // (the additions' stderr lines, e.g. --stats of this rank's share)
     }
     scfq_comm_destroy(comm);
     scfq_shutdown();

@@ -736,7 +736,9 @@ static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, int launch = 3)
   return (uint32_t)full;
 }
 
-int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing) {
+// first_prev: the byte in front of the first inflated byte (0..255), or -1 when the members start the input (a rank of a sharded
+// BGZF file starts in the middle of the inflated stream: scfq_count_file_sharded)
+int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1) {
   int rc = ensure_bgzf_device_buffers(c, fsize);
   if (rc) return rc;
   const uint64_t chunk = c->inf_cap, comp_chunk = c->comp_cap;
@@ -797,7 +799,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
       }
     }
     if (ob) {
-      rc = scan_async(c, base, ob, prev_base ? -2 : -1, flags & ~SCFQ_PREV_IN_MEMORY, timing);
+      rc = scan_async(c, base, ob, prev_base ? -2 : first_prev, flags & ~SCFQ_PREV_IN_MEMORY, timing);
       if (rc) return rc;
       prev_base = base;
       prev_n = ob;
@@ -1130,6 +1132,56 @@ static int count_file_partial(const char* path, const scfq_opts* opts, scfq_part
   return SCFQ_OK;
 }
 
+}  // extern "C"
+namespace {
+// BGZF shards.  A BGZF file is cut where its members are: the first position at or after `from` where eight members follow one
+// another (or a shorter run that ends exactly with the file) — every rank finds the SAME positions with this rule, from the bytes
+// alone.  n when there is none.
+uint64_t bgzf_boundary(const uint8_t* img, uint64_t n, uint64_t from) {
+  for (uint64_t p = from; p + 18 <= n;) {
+    const void* hit = std::memchr(img + p, 0x1f, (size_t)(n - 17 - p));
+    if (!hit) break;
+    p = (uint64_t)(static_cast<const uint8_t*>(hit) - img);
+    uint64_t q = p;
+    int k = 0;
+    while (k < 8 && q < n) {
+      uint32_t hl = 0;
+      const uint32_t bs = scfq_bgzf::block_size(img + q, n - q, &hl);
+      if (!bs || q + bs > n || scfq_bgzf::rd32(img + q + bs - 4) > (1u << 16)) break;
+      q += bs;
+      ++k;
+    }
+    if (k == 8 || (k > 0 && q == n)) return p;
+    ++p;
+  }
+  return n;
+}
+// Where rank r's members start (r > 0) and the byte in front of its first inflated byte: the boundary rule gives a member; the rank's
+// range starts BEHIND the first non-empty member from there, which the rank inflates on the host (one member of at most 64 KiB)
+// for its last byte.  Both neighbours compute the same cut.  false: a member that does not inflate (the file is damaged).
+bool bgzf_cut(const uint8_t* img, uint64_t n, uint64_t from, uint64_t* cut, int* prev) {
+  uint64_t p = bgzf_boundary(img, n, from);
+  *prev = -1;
+  while (p < n) {
+    uint32_t hl = 0;
+    const uint32_t bs = scfq_bgzf::block_size(img + p, n - p, &hl);
+    if (!bs || p + bs > n) { *cut = n; return false; }
+    const uint32_t isize = scfq_bgzf::rd32(img + p + bs - 4);
+    if (isize == 0) { p += bs; continue; }               // (an empty member — the end-of-file marker — has no last byte)
+    if (isize > (1u << 16)) { *cut = n; return false; }
+    std::vector<scfq_bgzf::Block> one{{p, bs, hl, isize, scfq_bgzf::rd32(img + p + bs - 8), 0}};
+    std::vector<uint8_t> out(isize);
+    if (scfq_bgzf::inflate_blocks(img, one, 0, 1, out.data())) { *cut = n; return false; }
+    *prev = out[isize - 1];
+    *cut = p + bs;
+    return true;
+  }
+  *cut = n;
+  return true;
+}
+}  // namespace
+extern "C" {
+
 // fq_count of one file by all ranks of a communicator (include/sc_fqcount.h): byte-range shard -> K1/K2 -> exchange -> fold
 int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* comm, scfq_counts* out) {
   if (!path || !comm || !out || out->struct_size != sizeof(scfq_counts)) return SCFQ_EARG;
@@ -1147,12 +1199,66 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
   const bool is_gz = plen >= 3 && std::memcmp(path + plen - 3, ".gz", 3) == 0;      // src/fq_count.nim:31
   int local = SCFQ_OK;          // a rank that fails still takes part in the exchange (with the identity) so nobody hangs
   if (is_gz) {
-    if (rank == 0) {
-      // a deflate stream has no byte-range shards: rank 0 inflates and scans all of it
+    // BGZF (bgzip) input shards where its members are: rank r takes the members that start in its byte range, inflates them on its
+    // device and scans them; the partials fold as for a plain file.  The ranks first AGREE (one all-gather of a word) that every one
+    // of them found its cuts and saw nothing but BGZF members of at most 64 KiB in its range — otherwise, and for every other gzip
+    // layout (one deflate stream has no shards), rank 0 inflates and scans all of it and the others contribute the identity.
+    static const bool shard_bgzf = env_int("SCFQ_SHARD_BGZF", 1) != 0;
+    const int fd = shard_bgzf && world > 1 ? open(path, O_RDONLY) : -1;
+    struct stat sb;
+    const uint8_t* img = nullptr;
+    uint64_t size = 0, b_lo = 0, b_hi = 0;
+    int prev = -1;
+    uint64_t mine_ok = 0;
+    if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && bgzf_device_enabled() && !std::getenv("SCFQ_NO_BGZF") && scfq_bgzf::probe(fd)) {
+      void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m != MAP_FAILED) {
+        img = static_cast<const uint8_t*>(m);
+        size = (uint64_t)sb.st_size;
+        bool ok = true;
+        int prev_hi = -1;
+        if (rank > 0) ok = bgzf_cut(img, size, size / (uint64_t)world * (uint64_t)rank, &b_lo, &prev);
+        if (rank + 1 < world) ok = bgzf_cut(img, size, size / (uint64_t)world * (uint64_t)(rank + 1), &b_hi, &prev_hi) && ok;
+        else b_hi = size;
+        if (b_hi < b_lo) b_hi = b_lo;
+        ok = ok && (b_lo == b_hi || bgzf_is_pure(img + b_lo, b_hi - b_lo));
+        mine_ok = ok ? 1 : 0;
+      }
+    }
+    std::vector<uint64_t> oks((size_t)world, 0);
+    bool sharded = false;
+    if (world > 1 && shard_bgzf) {
+      // (every rank takes part in this all-gather whatever it found: a rank that cannot even open the file says 0)
+      rc = scfq_comm_allgather_u64(comm, &mine_ok, 1, oks.data(), 0);
+      if (rc) { if (img) munmap(const_cast<uint8_t*>(img), (size_t)size); if (fd >= 0) close(fd); std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return rc; }
+      sharded = true;
+      for (int r = 0; r < world; ++r) sharded = sharded && oks[(size_t)r] == 1;
+    }
+    if (sharded) {
+      if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) local = SCFQ_EHIP;
+      if (!local && b_hi > b_lo) {
+        Ctx* c = nullptr;
+        SessionLock sl;
+        local = get_ctx(&c, sl);
+        if (!local) local = begin_session(c, rank == 0);
+        if (!local) {
+          local = ingest_bgzf_device(c, img + b_lo, b_hi - b_lo, o.flags, opt_chunk(&o), timing, prev);
+          if (local == kFallbackToHost || local == kNotPureBgzf) {
+            // no room for the device path's buffers (kNotPureBgzf cannot happen: the range was walked): the host's block-parallel
+            // inflate over the same members
+            local = begin_session(c, rank == 0);
+            if (!local) { BgzfSource src(fd, b_hi); src.pos = b_lo; local = ingest(c, src, prev, o.flags, opt_chunk(&o), timing); }
+          }
+        }
+        if (!local) local = end_session(c, want_hist, &mine, want_hist ? hist.data() : nullptr);
+      }
+    } else if (rank == 0) {
       scfq_opts o1 = o;
       o1.n_devices = std::min(o.n_devices, 1);
       local = count_file_partial(path, &o1, &mine, want_hist ? hist.data() : nullptr);
     }
+    if (img) munmap(const_cast<uint8_t*>(img), (size_t)size);
+    if (fd >= 0) close(fd);
   } else {
     const int fd = open(path, O_RDONLY);
     struct stat sb;

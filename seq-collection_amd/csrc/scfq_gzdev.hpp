@@ -212,11 +212,14 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   static const uint32_t batch_segs = (uint32_t)std::max(2, env_int("SCFQ_GZ_DEVICE_BATCH_SEGMENTS", 4096));
   // (a file of up to 512 MiB is cut into about 4096 segments — one wave each, the device filled once — of at least 48 KiB; a
   // bigger one into about 8192 of at most 320 KiB: every segment costs 32768 marker symbols and a step of the window chain)
-  // (r3: at most 128 KiB — 320 KiB segments in two batches were 7 % faster warm, 155 against 166 ms for 10 GB, and held 39 GB instead of
-  // 18: device memory is what a first call pays for when the box has just been used, profiles/r03/gz_segment_size.txt)
+  // (r3: at most 64 KiB.  Bigger segments are a little faster once the buffers exist — 10 GB: 155 ms with 292 KiB segments in two
+  // batches, 166 ms with 128 KiB, 177 ms with 64 KiB — and hold 39 / 18 / 10 GB of device memory for it.  That memory is what a
+  // PROCESS pays for: the driver wipes what a process frees at ~20 GB/s after it exits and the next process's allocations wait for
+  // it, so `for f in *.gz; do sc fq-count $f; done` spends 1.7 / 0.7 / 0.3 s per file waiting: profiles/r03/gz_segment_size.txt,
+  // gz_cold.jsonl)
   const uint64_t target_segs = 4096;
   const uint64_t seg_bytes = seg_kb_env > 0 ? ((((uint64_t)std::max(32, seg_kb_env)) << 10) + 4095) & ~4095ull
-                                            : std::min<uint64_t>(128u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull));
+                                            : std::min<uint64_t>(64u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull));
   // Output room of a segment = `ratio_est` symbols per compressed byte it spans + 128 Ki (it runs on to the end of a block),
   // behind its 32768 markers.  ratio_est comes from the file itself: the host inflates the first 192 KiB of the first member
   // (a millisecond) and adds a third; a segment that needs more ends with kGzErrOverflow and is decoded again, alone, with four

@@ -104,6 +104,45 @@ def test_cli_one_process_per_rank_real_kernels(gpu, scfq, oracle, tmp_path):
     assert outs[1][0] == oracle.tsv(oc) + "\tcrlf.fq\n"                 # rank 0: the reference's row
 
 
+def test_bgzf_input_shards_across_ranks(gpu, scfq, oracle, tmp_path):
+    """a BGZF file is cut where its members are: 2 and 3 `sc fq-count --shard-rank` processes (TCP transport, one device), CRLF
+    records so that the byte in front of a rank's first inflated byte matters, structure check on (its line-start accounting
+    needs that byte too); every rank inflates and scans its own members (h2d_bytes > 0), rank 0 prints the oracle's row"""
+    from test_ingest_sources import bgzf_file
+    rec = b"@r x\r\nACGTNNGCGC\r\n+\r\nIIII#III@+\r\n@r2\nGGCCN\n+r2\n!!!!!\n"
+    data = rec * 150_001 + b"@tail\nACGT"
+    f = tmp_path / "crlf.fq.gz"
+    f.write_bytes(bgzf_file(data))
+    oc = oracle.count(np.frombuffer(data, dtype=np.uint8))
+    sc = os.path.join(PKG, "sc")
+    for world in (2, 3):
+        port = _free_port()
+        procs = [subprocess.Popen([sc, "fq-count", "--shard-rank=%d" % r, "--shard-world=%d" % world, "--rendezvous=127.0.0.1:%d" % port,
+                                   "--transport=tcp", "--devices=0", "--stats", "--struct-check", str(f)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in reversed(range(world))]
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert [p.returncode for p in procs] == [0] * world, outs
+        assert outs[-1][0] == oracle.tsv(oc) + "\n"                          # rank 0: the reference's row
+        assert "bad_at=%d\tbad_plus=%d" % (oc.bad_at, oc.bad_plus) in outs[-1][1]
+        shares = []
+        for so, se in outs:
+            st = [json.loads(ln) for ln in se.splitlines() if ln.startswith("{")]
+            assert st and st[-1]["h2d_bytes"] > 0 and st[-1]["scan_launches"] > 0, se      # every rank moved compressed bytes and scanned
+            shares.append(st[-1]["h2d_bytes"])
+        assert max(shares) < 0.75 * sum(shares)                              # nobody did (nearly) all of it
+    # SCFQ_SHARD_BGZF=0 and a non-BGZF .gz: rank 0 alone, same row
+    import gzip
+    g = tmp_path / "plain.fq.gz"
+    g.write_bytes(gzip.compress(data, 6))
+    for path, env in ((f, {"SCFQ_SHARD_BGZF": "0"}), (g, {})):
+        port = _free_port()
+        procs = [subprocess.Popen([sc, "fq-count", "--shard-rank=%d" % r, "--shard-world=2", "--rendezvous=127.0.0.1:%d" % port,
+                                   "--transport=tcp", "--devices=0", str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, **env)) for r in (1, 0)]
+        outs = [p.communicate(timeout=300) for p in procs]
+        assert [p.returncode for p in procs] == [0, 0] and outs[1][0] == oracle.tsv(oc) + "\n", outs
+
+
 def _bench(args, nproc=0, timeout=600):
     env = dict(os.environ)
     if nproc:
@@ -140,10 +179,39 @@ def test_bench_full_size_shard_of_the_scaling_run(gpu):
 
 
 def test_bench_two_ranks_launched_like_the_driver(gpu):
-    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (gloo on one device: RCCL cannot put two ranks on
-    one GPU): two shards of one record stream cut at an arbitrary byte, exchange, counters == generator tallies"""
-    j = _bench(["--gpus", "2", "--backend", "gloo", "--same-device", "--bytes-per-gpu", "2.5e8", "--steps", "4", "--warmup", "2"], nproc=2)
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on one device: two shards of one record stream cut at
+    an arbitrary byte, the LIBRARY's communicator (its own rendezvous; TCP transport, because RCCL cannot put two ranks on one
+    GPU), counters == generator tallies; and the torch.distributed mirror on the same path"""
+    j = _bench(["--gpus", "2", "--same-device", "--transport", "tcp", "--bytes-per-gpu", "2.5e8", "--steps", "4", "--warmup", "2"], nproc=2)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak"
     assert j["counters"]["matches_generator_tally"] is True
     assert "configs[2]" in j["config"]["workload"] and j["config"]["seed"] == 20260102
     assert j["counters"]["bases"] > 2 * 2.5e8 / 2.5          # both shards are in the folded result
+    assert "scfq_comm" in j["config"]["exchange"] and "exchange_note" not in j["config"]
+    j2 = _bench(["--gpus", "2", "--same-device", "--exchange", "torch", "--bytes-per-gpu", "2.5e8", "--steps", "4", "--warmup", "2"], nproc=2)
+    assert j2["counters"] == j["counters"] and "torch.distributed" in j2["config"]["exchange"]
+
+
+def test_bench_configs2_shape_at_full_shard_size(gpu):
+    """BASELINE configs[2] at its real shard size: 25 GB per rank of ONE record stream (seed 20260102) cut at arbitrary bytes, five
+    ranks on this one device (125 GB of its 288 GB; the GPU box allows six processes on the card and pytest is one of them — the
+    8-rank, 200 GB form needs the 8-GPU node), launched as the driver launches the scaling run; every rank scans its own shard with
+    the real kernels, the partials cross the library's communicator (own rendezvous, TCP transport: RCCL refuses several ranks on
+    one device), counters of all 347 M records == the generator's tallies"""
+    j = _bench(["--gpus", "5", "--same-device", "--transport", "tcp", "--steps", "3", "--warmup", "1"], nproc=5, timeout=900)
+    assert j["n_gpus"] == 5 and j["scaling"] == "weak"
+    assert j["counters"]["matches_generator_tally"] is True
+    assert j["config"]["bytes_per_gpu"] >= 25_000_000_000 - 1000 and "configs[2]" in j["config"]["workload"] and j["config"]["seed"] == 20260102
+    assert j["counters"]["reads"] > 5 * 69_000_000 and j["counters"]["bases"] > 5 * 25e9 / 2.5
+    assert "scfq_comm" in j["config"]["exchange"]
+
+
+def test_bench_ingest_object(gpu):
+    """the non-headline `ingest` object of the default N=1 line: a gzip member and a BGZF file written in setup, a cold process and
+    the warm call, counters == generator tallies (here at a fifth of the default size)"""
+    j = _bench(["--gpus", "1", "--bytes-per-gpu", "3e8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--ingest-bytes", "4e8"])
+    ing = j["ingest"]
+    for k in ("gzip_member", "bgzf"):
+        assert ing[k]["counters_match_generator"] is True and ing[k]["compressed_bytes"] < ing["inflated_bytes"] // 2
+        assert 0 < ing[k]["warm_wall_s"] <= ing[k]["cold_process_wall_s"]
+    assert ing["device_bytes_high_water"] > 0
