@@ -193,16 +193,17 @@ def test_bench_two_ranks_launched_like_the_driver(gpu):
 
 
 def test_bench_configs2_shape_at_full_shard_size(gpu):
-    """BASELINE configs[2] at its real shard size: 25 GB per rank of ONE record stream (seed 20260102) cut at arbitrary bytes, five
-    ranks on this one device (125 GB of its 288 GB; the GPU box allows six processes on the card and pytest is one of them — the
-    8-rank, 200 GB form needs the 8-GPU node), launched as the driver launches the scaling run; every rank scans its own shard with
-    the real kernels, the partials cross the library's communicator (own rendezvous, TCP transport: RCCL refuses several ranks on
-    one device), counters of all 347 M records == the generator's tallies"""
-    j = _bench(["--gpus", "5", "--same-device", "--transport", "tcp", "--steps", "3", "--warmup", "1"], nproc=5, timeout=900)
-    assert j["n_gpus"] == 5 and j["scaling"] == "weak"
+    """BASELINE configs[2] at its real shard size: 25 GB per rank of ONE record stream (seed 20260102) cut at arbitrary bytes, four
+    ranks on this one device (100 GB of its 288 GB; the GPU box allows six processes on the card, and pytest and the launcher are
+    two of them — with five ranks its process guard killed the run; the 8-rank, 200 GB form needs the 8-GPU node), launched as the
+    driver launches the scaling run; every rank scans its own shard with the real kernels, the partials cross the library's
+    communicator (own rendezvous, TCP transport: RCCL refuses several ranks on one device), counters of all 278 M records == the
+    generator's tallies"""
+    j = _bench(["--gpus", "4", "--same-device", "--transport", "tcp", "--steps", "3", "--warmup", "1"], nproc=4, timeout=900)
+    assert j["n_gpus"] == 4 and j["scaling"] == "weak"
     assert j["counters"]["matches_generator_tally"] is True
     assert j["config"]["bytes_per_gpu"] >= 25_000_000_000 - 1000 and "configs[2]" in j["config"]["workload"] and j["config"]["seed"] == 20260102
-    assert j["counters"]["reads"] > 5 * 69_000_000 and j["counters"]["bases"] > 5 * 25e9 / 2.5
+    assert j["counters"]["reads"] > 4 * 69_000_000 and j["counters"]["bases"] > 4 * 25e9 / 2.5
     assert "scfq_comm" in j["config"]["exchange"]
 
 
