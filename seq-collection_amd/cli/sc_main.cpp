@@ -117,7 +117,7 @@ static void help_fq_count(FILE* f) {   // docs/fq-count.md:5-19
       "      --struct-check         Report header lines not starting '@' / separator lines not starting '+' on stderr\n"
       "      --qual-hist            Print the quality-byte histogram on stderr\n"
       "      --stats                Print bytes / device milliseconds / GB/s as JSON on stderr\n"
-      "      --jobs=N               Keep up to N files in flight (rows still come out in argument order)\n"
+      "      --jobs=N               Keep up to N files in flight (default: 2; rows still come out in argument order)\n"
       "      --shard-rank=R --shard-world=W --rendezvous=HOST:PORT [--transport=rccl|tcp]\n"
       "                             One process per GPU: this process scans byte range R of W of every file on its device\n"
       "                             (--devices=ID, default R), the partials are exchanged (RCCL all-gather), rank 0 prints\n"
@@ -318,7 +318,7 @@ int main(int argc, char** argv) {
   if (params.size() == 1) { help_fq_count(stdout); return 0; }   // sc.nim:288-290: len <= 1 -> "-h"
 
   bool header = false, basename = false, absolute = false, stats = false;
-  int jobs = 1;
+  int jobs = 0;      // 0: not given
   int shard_rank = -1, shard_world = 0, transport = SCFQ_COMM_RCCL;
   std::string rendezvous;
   std::vector<std::string> files;
@@ -409,6 +409,10 @@ int main(int argc, char** argv) {
   // points descriptor 1 at descriptor 2 — RCCL prints a banner on stdout — and a row printed in that window would be lost to
   // stderr); a failure here is reported by the first counting call
   if (devices.size() > 1 && !files.empty()) (void)scfq_prepare(&opts);
+  // sc.nim:114-116 takes the files one after the other.  Here two are in flight unless --jobs says otherwise (a file's
+  // pipeline — read or copy, inflate, scan — leaves the device idle most of the time; file k + 1's ingest runs under file k's
+  // kernels): rows still come out in argv order and the first failing file ends the run where the sequential loop would have.
+  if (jobs == 0) jobs = devices.size() > 1 ? 1 : (int)std::min<size_t>(2, std::max<size_t>(1, files.size()));
   if (jobs <= 1 || files.size() <= 1) {
     for (const auto& f : files) fq_count_emit(fq_count_compute(f, basename, absolute, opts, stats));   // sc.nim:114-116
   } else {

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -107,12 +108,22 @@ struct GzDevBuffers {
   }
 };
 
-// The buffers of the device gzip path are per DEVICE, not per context, and one file at a time goes through them: a file is
-// inflated at tens of GB/s with the whole device, so sessions that arrive together (`sc fq-count --jobs=8 *.fq.gz`) queue here
-// instead of each growing its own tens of GB of buffers and sharing the CUs among eight sets of decode waves.  (What eight
-// jobs over eight 64 MB files cost against one — 0.85 against 0.4-0.5 s — is the set-up of eight contexts, pinned staging
-// buffers above all, not the inflate: the figure is the same with and without this queue.)
-struct GzShared { std::mutex mu; GzDevBuffers buf; };
+// The device gzip path has a small POOL of engines per device (buffers, streams, events: GzDevBuffers), SCFQ_GZ_DEVICE_ENGINES = 4 of
+// them at most, made as sessions need them.  Round 2 had one: a small file's pipeline is a chain — copy, block-start search, decode,
+// walk, windows, bytes, scan — that leaves the device idle most of the time, so `sc fq-count --jobs=N *.fq.gz` (and the default
+// loop, which keeps up to four files in flight) only paid for N contexts and then queued.  With buffers sized by what a file needs
+// (scfq_gzdev.hpp) an engine for a 64 MB file holds about a GB, and file k + 1's copy and search run under file k's decode.
+// Files of more than 1 GiB compressed take the device one at a time (`big`): their decode fills it anyway, and four of them would
+// hold four times the memory.
+struct GzShared {
+  std::mutex mu;                       // guards the pool's bookkeeping
+  std::condition_variable cv;
+  static constexpr int kMax = 8;
+  GzDevBuffers buf[kMax];
+  bool busy[kMax] = {false, false, false, false, false, false, false, false};
+  int n_busy = 0;
+  bool big_running = false;
+};
 inline GzShared& gz_shared(int dev) { static GzShared g[64]; return g[dev & 63]; }
 
 struct Ctx {
@@ -151,7 +162,9 @@ struct Ctx {
   uint8_t* d_comp[2] = {nullptr, nullptr};
   scfq_dinflate::Block* d_blk[2] = {nullptr, nullptr};
   scfq_dinflate::Block* h_blk[2] = {nullptr, nullptr};
-  uint8_t* h_comp[2] = {nullptr, nullptr};
+  bool bgzf_warmed = false;                        // bgzf_inflate's first (empty) launch has set the device's scratch up
+  hipEvent_t ev_piece[2] = {nullptr, nullptr};     // pieces of compressed bytes crossing the pinned ring (device inflate paths)
+  unsigned piece_it = 0;
   uint8_t* d_inf[2] = {nullptr, nullptr};      // inflated chunks (kStagePad + inf_cap each)
   uint32_t* d_dstatus = nullptr;
   uint64_t comp_cap = 0, inf_cap = 0;
@@ -183,29 +196,40 @@ thread_local uint64_t g_hist_stats[2] = {0, 0};   // ranges of the last session 
 
 int new_ctx(int dev, std::unique_ptr<Ctx>* out);
 
+std::map<int, int> g_ctx_creating;      // (under g_mu) contexts of a device being created right now
+
 int get_ctx(Ctx** out, SessionLock& sl) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   static const int max_ctx = std::max(1, std::min(64, env_int("SCFQ_MAX_SESSIONS", 16)));
   Ctx* wait_on = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     auto& pool = g_ctx[dev];
     for (auto& c : pool) {
       std::unique_lock<std::mutex> try_lk(c->mu, std::try_to_lock);
       if (try_lk.owns_lock()) { sl.lk = std::move(try_lk); *out = c.get(); return SCFQ_OK; }
     }
-    if ((int)pool.size() < max_ctx) {
+    if ((int)pool.size() + g_ctx_creating[dev] < max_ctx) {
+      // a new context is made OUTSIDE the registry's lock (its streams and pinned words take tens of milliseconds): the sessions of
+      // `--jobs=N` set their contexts up side by side, not one after the other
+      ++g_ctx_creating[dev];
+      lk.unlock();
       std::unique_ptr<Ctx> c;
-      int rc = new_ctx(dev, &c);
+      const int rc = new_ctx(dev, &c);
+      lk.lock();
+      --g_ctx_creating[dev];
       if (rc) return rc;
       sl.lk = std::unique_lock<std::mutex>(c->mu);
       *out = c.get();
-      pool.push_back(std::move(c));
+      g_ctx[dev].push_back(std::move(c));
       return SCFQ_OK;
     }
+    if (pool.empty()) {      // (every allowed context is still being created by another thread: wait for the first to appear)
+      while (g_ctx[dev].empty()) { lk.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); lk.lock(); }
+    }
     static unsigned rr = 0;
-    wait_on = pool[rr++ % pool.size()].get();
+    wait_on = g_ctx[dev][rr++ % g_ctx[dev].size()].get();
   }
   sl.lk = std::unique_lock<std::mutex>(wait_on->mu);   // every context busy: queue behind one of them
   *out = wait_on;
@@ -588,6 +612,27 @@ int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_part
 
 #include "scfq_sources.hpp"   // Source, MemSource, FdSource, GzSource, FastGzSource, BgzfSource, open_gz_source
 
+// `n` bytes of host (pageable: a mapped file) memory to device memory through the context's pinned ring, in pieces: a piece
+// crosses PCIe while the next one is copied into the other pinned buffer, so the bytes are on the device one piece after the last
+// of them reached pinned memory — and the ring is 2 x 16 MiB, not two buffers of the size of a chunk (pinning memory costs
+// 160 ms per GB: 170 of the 310 ms of a cold `sc fq-count` over a 2 GB BGZF file went into two pinned buffers of 0.5 GB).
+int copy_through_ring(Ctx* c, uint8_t* dst_device, const uint8_t* src_host, uint64_t n) {
+  int rc = ensure_staging(c, c->stage_cap ? c->stage_cap : (16ull << 20), true);
+  if (rc) return rc;
+  const uint64_t piece = std::min<uint64_t>(c->stage_cap, 64ull << 20);
+  for (int b = 0; b < 2; ++b) if (!c->ev_piece[b]) HIPCHK(hipEventCreateWithFlags(&c->ev_piece[b], hipEventDisableTiming));
+  for (uint64_t o = 0; o < n; o += piece, ++c->piece_it) {
+    const int pb = (int)(c->piece_it & 1);
+    const uint64_t len = std::min(piece, n - o);
+    if (c->piece_it >= 2) HIPCHK(hipEventSynchronize(c->ev_piece[pb]));
+    parallel_pieces(len, [&](uint64_t q, uint64_t l) { std::memcpy(c->h_pin[pb] + q, src_host + o + q, l); return 0; });
+    HIPCHK(hipMemcpyAsync(dst_device + o, c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
+    HIPCHK(hipEventRecord(c->ev_piece[pb], c->copy));
+  }
+  return SCFQ_OK;
+}
+
+
 // Chunked ingest with copy/compute overlap: the host thread fills pinned buffer b (pread / inflate)
 // while the copy stream moves buffer b^1 to HBM and the compute stream scans the chunk before it.
 int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, bool timing) {
@@ -678,14 +723,12 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
     for (int b = 0; b < 2; ++b) {
       if (c->d_comp[b]) HIPCHK(hipFree(c->d_comp[b]));
       if (c->d_inf[b]) HIPCHK(hipFree(c->d_inf[b]));
-      if (c->h_comp[b]) HIPCHK(hipHostFree(c->h_comp[b]));
-      c->d_comp[b] = nullptr; c->d_inf[b] = nullptr; c->h_comp[b] = nullptr;
+      c->d_comp[b] = nullptr; c->d_inf[b] = nullptr;
     }
     c->comp_cap = c->inf_cap = 0;
     bool ok = true;
     for (int b = 0; b < 2 && ok; ++b) {
-      ok = hipMalloc(&c->d_comp[b], want_comp + 64) == hipSuccess && hipMalloc(&c->d_inf[b], want_inf + kStagePad) == hipSuccess &&
-           hipHostMalloc(&c->h_comp[b], want_comp, hipHostMallocDefault) == hipSuccess;
+      ok = hipMalloc(&c->d_comp[b], want_comp + 64) == hipSuccess && hipMalloc(&c->d_inf[b], want_inf + kStagePad) == hipSuccess;
       if (ok && !c->d_blk[b]) ok = hipMalloc(&c->d_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block)) == hipSuccess;
       if (ok && !c->h_blk[b]) ok = hipHostMalloc(&c->h_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block), hipHostMallocDefault) == hipSuccess;
     }
@@ -697,8 +740,7 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
       for (int b = 0; b < 2; ++b) {
         if (c->d_comp[b]) (void)hipFree(c->d_comp[b]);
         if (c->d_inf[b]) (void)hipFree(c->d_inf[b]);
-        if (c->h_comp[b]) (void)hipHostFree(c->h_comp[b]);
-        c->d_comp[b] = nullptr; c->d_inf[b] = nullptr; c->h_comp[b] = nullptr;
+        c->d_comp[b] = nullptr; c->d_inf[b] = nullptr;
       }
       return kFallbackToHost;
     }
@@ -739,6 +781,20 @@ static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, int launch = 3)
 // first_prev: the byte in front of the first inflated byte (0..255), or -1 when the members start the input (a rank of a sharded
 // BGZF file starts in the middle of the inflated stream: scfq_count_file_sharded)
 int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1) {
+  // (bgzf_inflate keeps 72 bytes of scratch per lane and the runtime sets the device's scratch up inside the first launch of such
+  // a kernel — 35 - 50 ms on the launching thread: an empty launch on a helper thread, under the buffers' allocation and the first copy)
+  struct Warm { std::thread th; ~Warm() { if (th.joinable()) th.join(); } } warm;
+  if (!c->bgzf_warmed) {
+    c->bgzf_warmed = true;
+    hipStream_t st = c->compute;
+    const int dev = c->dev;
+    warm.th = std::thread([st, dev] {
+      if (hipSetDevice(dev) != hipSuccess) return;
+      hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3(1), dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, st,
+                         (const uint8_t*)nullptr, (const scfq_dinflate::Block*)nullptr, 0u, (uint8_t*)nullptr, (uint32_t*)nullptr, 0u);
+      (void)hipGetLastError();
+    });
+  }
   int rc = ensure_bgzf_device_buffers(c, fsize);
   if (rc) return rc;
   const uint64_t chunk = c->inf_cap, comp_chunk = c->comp_cap;
@@ -773,13 +829,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
       while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
       HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
     }
-    // pinned buffer and PCIe in pieces of 64 MiB: a piece crosses while the next is filled, so the chunk is on the device one
-    // piece after its last byte reached pinned memory
-    for (uint64_t o = 0; o < (uint64_t)used; o += 64ull << 20) {
-      const uint64_t len = std::min<uint64_t>(64ull << 20, (uint64_t)used - o);
-      parallel_pieces(len, [&](uint64_t q, uint64_t l) { std::memcpy(c->h_comp[b] + o + q, src + o + q, l); return 0; });
-      HIPCHK(hipMemcpyAsync(c->d_comp[b] + o, c->h_comp[b] + o, (size_t)len, hipMemcpyHostToDevice, c->copy));
-    }
+    if ((rc = copy_through_ring(c, c->d_comp[b], src, (uint64_t)used))) return rc;
     fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
     if (timing) { HIPCHK(hipEventRecord(c->cp_pool[c->cp_used + 1], c->copy)); c->cp_used += 2; }
@@ -787,6 +837,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
     HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));
     uint8_t* base = c->d_inf[b] + kStagePad;
     if (prev_base) HIPCHK(hipMemcpyAsync(base - 1, prev_base + prev_n - 1, 1, hipMemcpyDeviceToDevice, c->compute));
+    if (warm.th.joinable()) warm.th.join();
     if (nb) {
       hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
                          dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
@@ -1345,10 +1396,10 @@ int scfq_shutdown(void) {
       if (c->d_inf[b]) (void)hipFree(c->d_inf[b]);
       if (c->d_blk[b]) (void)hipFree(c->d_blk[b]);
       if (c->h_blk[b]) (void)hipHostFree(c->h_blk[b]);
-      if (c->h_comp[b]) (void)hipHostFree(c->h_comp[b]);
+      if (c->ev_piece[b]) (void)hipEventDestroy(c->ev_piece[b]);
     }
     if (c->d_dstatus) (void)hipFree(c->d_dstatus);
-    { GzShared& gs = gz_shared(c->dev); std::lock_guard<std::mutex> lk(gs.mu); gz_free(&gs.buf); }
+    { GzShared& gs = gz_shared(c->dev); std::lock_guard<std::mutex> lk(gs.mu); for (int e = 0; e < GzShared::kMax; ++e) gz_free(&gs.buf[e]); }
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1416,9 +1467,8 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
               if (used < 0) return SCFQ_EGZ;
               if (used == 0) break;
               const uint8_t* src = img + pos;
-              parallel_pieces((uint64_t)used, [&](uint64_t o, uint64_t len) { std::memcpy(c->h_comp[b] + o, src + o, len); return 0; });
               if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));
-              HIPCHK(hipMemcpyAsync(c->d_comp[b], c->h_comp[b], (size_t)used, hipMemcpyHostToDevice, c->copy));
+              if ((rc = copy_through_ring(c, c->d_comp[b], src, (uint64_t)used))) return rc;
               HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
               HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
               HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));

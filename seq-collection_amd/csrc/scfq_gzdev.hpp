@@ -126,7 +126,7 @@ struct GzPart {            // the bytes of one member inside one batch: a run of
 };
 struct GzMemberEnd { uint32_t member; uint32_t crc, isize; };
 
-int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing) {
+int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing) {
   using namespace scfq_dinflate;
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
@@ -135,69 +135,14 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   static const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
   const long h0 = scfq_gzfast::member_header(img, (size_t)fsize);
   if (h0 <= 0 || fsize < 64) return SCFQ_GZ_DECLINE;
-  GzDevBuffers& g = gz_shared(c->dev).buf;             // (the caller holds its mutex)
   int rc;
-  if (!g.s_search) {
-    // the search's workgroups are small and short, and the decode of the next batch cannot be cut into segments before they are
-    // through: their stream has priority over the decode streams, whose waves run for tens of milliseconds
-    int least = 0, greatest = 0;
-    static const int hi = env_int("SCFQ_GZ_DEVICE_SEARCH_PRIORITY", 1);
-    if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) HIPCHK(hipStreamCreateWithPriority(&g.s_search, hipStreamNonBlocking, greatest));
-    else HIPCHK(hipStreamCreateWithFlags(&g.s_search, hipStreamNonBlocking));
-  }
   for (int b = 0; b < 4; ++b) {
     if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
     if (!g.ev_found[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_found[b], hipEventDisableTiming));
   }
   for (int b = 0; b < 2; ++b) {
-    if (!g.s_decode[b]) {
-      // The decode kernels fill the device with waves that run for tens of milliseconds, and whatever else the pipeline launches
-      // meanwhile (copies, search, window chain, resolve, CRC, scan) has to get in between.  SCFQ_GZ_DEVICE_RESERVE_CUS=n keeps
-      // the decode streams off n CUs (a CU mask); measured, that costs the decode more than it gives the rest: off by default.
-      static const int reserve = std::max(0, env_int("SCFQ_GZ_DEVICE_RESERVE_CUS", 0));
-      hipError_t e = hipErrorNotSupported;
-      if (reserve > 0 && c->n_cu > 2 * reserve) {
-        std::vector<uint32_t> mask((size_t)(c->n_cu + 31) / 32, 0u);
-        // (mask bit 32 x + j is CU j of XCD x, and workgroups go round the XCDs in turn: the same number of CUs is left out in every XCD,
-        // or the XCD that lost most sets the pace — measured: 16 CUs taken from one XCD made the decode 1.6 x slower)
-        static const int layout = env_int("SCFQ_GZ_DEVICE_MASK_LAYOUT", 1);
-        const int per = c->n_cu / 8, r = (reserve + 7) / 8;
-        for (int i = 0; i < c->n_cu; ++i) {
-          const bool keep = (layout == 1 && c->n_cu % 8 == 0) ? (i % per) < per - r : i < c->n_cu - reserve;
-          if (keep) mask[(size_t)i >> 5] |= 1u << (i & 31);
-        }
-        e = hipExtStreamCreateWithCUMask(&g.s_decode[b], (uint32_t)mask.size(), mask.data());
-        if (e != hipSuccess) { (void)hipGetLastError(); g.s_decode[b] = nullptr; }
-      }
-      if (e != hipSuccess) {
-        static const int low = env_int("SCFQ_GZ_DEVICE_DECODE_LOW_PRIORITY", 0);
-        int least = 0, greatest = 0;
-        if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) HIPCHK(hipStreamCreateWithPriority(&g.s_decode[b], hipStreamNonBlocking, least));
-        else HIPCHK(hipStreamCreateWithFlags(&g.s_decode[b], hipStreamNonBlocking));
-      }
-    }
     if (!g.ev_dec[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_dec[b], hipEventDisableTiming));
     if (!g.ev_post[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_post[b], hipEventDisableTiming));
-  }
-
-  // The decode kernel keeps 72 bytes of scratch per lane (its symbol loop is a real function call), and the runtime sets the
-  // device's scratch up inside the FIRST launch of such a kernel: 35 - 50 ms of a process's first call, spent on the host thread.
-  // An empty launch on a helper thread takes that off the critical path: it runs under the plan, the pinned ring's allocation and
-  // the first batch's copy.
-  struct Warm {
-    std::thread th;
-    ~Warm() { if (th.joinable()) th.join(); }
-  } warm;
-  if (!g.decode_warmed) {
-    g.decode_warmed = true;
-    hipStream_t sd = g.s_decode[0];
-    const int dev = c->dev;
-    warm.th = std::thread([sd, dev] {
-      if (hipSetDevice(dev) != hipSuccess) return;
-      hipLaunchKernelGGL(gz_segment_decode, dim3(1), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, sd, (const uint8_t*)nullptr, 0ull, (const GzSeg*)nullptr, 0u,
-                         (uint16_t*)nullptr, (GzSegOut*)nullptr, 0u);
-      (void)hipGetLastError();
-    });
   }
 
   // ---- plan ----------------------------------------------------------------------------------------------------------------
@@ -219,7 +164,8 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   // gz_cold.jsonl)
   const uint64_t target_segs = 4096;
   const uint64_t seg_bytes = seg_kb_env > 0 ? ((((uint64_t)std::max(32, seg_kb_env)) << 10) + 4095) & ~4095ull
-                                            : std::min<uint64_t>(64u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull));
+                                            : comp <= (512ull << 20) ? std::min<uint64_t>(128u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull))
+                                                                     : (64u << 10);      // (up to 512 MiB: one batch of ~4096 segments, the device filled once, <= 9 GB held)
   // Output room of a segment = `ratio_est` symbols per compressed byte it spans + 128 Ki (it runs on to the end of a block),
   // behind its 32768 markers.  ratio_est comes from the file itself: the host inflates the first 192 KiB of the first member
   // (a millisecond) and adds a third; a segment that needs more ends with kGzErrOverflow and is decoded again, alone, with four
@@ -248,6 +194,71 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     for (uint64_t at = 0; at < n_plan;) { at = std::min<uint64_t>(n_plan, at + per); bstart.push_back(at); }
   }
   const uint32_t nb = (uint32_t)bstart.size() - 1;
+  // ---- streams.  A file of ONE batch is a chain — copy, search, decode, walk, windows, bytes, scan — and runs on the context's two
+  // streams (copy + search on one, decode and everything behind it on the other): creating a stream costs 10 - 15 ms, and an
+  // engine's three were half of what a small file's first call paid.  Files of several batches get the engine's own streams: the
+  // search of batch k + 1, the decodes of two batches and the post-processing of a third overlap.
+  hipStream_t s_search = c->copy, s_dec[2] = {c->compute, c->compute};
+  if (nb > 1) {
+    if (!g.s_search) {
+      // the search's workgroups are small and short, and the decode of the next batch cannot be cut into segments before they are
+      // through: their stream has priority over the decode streams, whose waves run for tens of milliseconds
+      int least = 0, greatest = 0;
+      static const int hi = env_int("SCFQ_GZ_DEVICE_SEARCH_PRIORITY", 1);
+      if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) HIPCHK(hipStreamCreateWithPriority(&g.s_search, hipStreamNonBlocking, greatest));
+      else HIPCHK(hipStreamCreateWithFlags(&g.s_search, hipStreamNonBlocking));
+    }
+    for (int b = 0; b < 2; ++b) {
+      if (!g.s_decode[b]) {
+        // The decode kernels fill the device with waves that run for tens of milliseconds, and whatever else the pipeline launches
+        // meanwhile (copies, search, window chain, resolve, CRC, scan) has to get in between.  SCFQ_GZ_DEVICE_RESERVE_CUS=n keeps
+        // the decode streams off n CUs (a CU mask); measured, that costs the decode more than it gives the rest: off by default.
+        static const int reserve = std::max(0, env_int("SCFQ_GZ_DEVICE_RESERVE_CUS", 0));
+        hipError_t e = hipErrorNotSupported;
+        if (reserve > 0 && c->n_cu > 2 * reserve) {
+          std::vector<uint32_t> mask((size_t)(c->n_cu + 31) / 32, 0u);
+          // (mask bit 32 x + j is CU j of XCD x, and workgroups go round the XCDs in turn: the same number of CUs is left out in every XCD,
+          // or the XCD that lost most sets the pace — measured: 16 CUs taken from one XCD made the decode 1.6 x slower)
+          static const int layout = env_int("SCFQ_GZ_DEVICE_MASK_LAYOUT", 1);
+          const int per = c->n_cu / 8, r = (reserve + 7) / 8;
+          for (int i = 0; i < c->n_cu; ++i) {
+            const bool keep = (layout == 1 && c->n_cu % 8 == 0) ? (i % per) < per - r : i < c->n_cu - reserve;
+            if (keep) mask[(size_t)i >> 5] |= 1u << (i & 31);
+          }
+          e = hipExtStreamCreateWithCUMask(&g.s_decode[b], (uint32_t)mask.size(), mask.data());
+          if (e != hipSuccess) { (void)hipGetLastError(); g.s_decode[b] = nullptr; }
+        }
+        if (e != hipSuccess) {
+          static const int low = env_int("SCFQ_GZ_DEVICE_DECODE_LOW_PRIORITY", 0);
+          int least = 0, greatest = 0;
+          if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) HIPCHK(hipStreamCreateWithPriority(&g.s_decode[b], hipStreamNonBlocking, least));
+          else HIPCHK(hipStreamCreateWithFlags(&g.s_decode[b], hipStreamNonBlocking));
+        }
+      }
+      s_dec[b] = g.s_decode[b];
+    }
+    s_search = g.s_search;
+  }
+
+  // The decode kernel keeps 72 bytes of scratch per lane (its symbol loop is a real function call), and the runtime sets the
+  // device's scratch up inside the FIRST launch of such a kernel: 35 - 50 ms of a process's first call, spent on the host thread.
+  // An empty launch on a helper thread takes that off the critical path: it runs under the tables' and the pinned ring's allocation
+  // and the first batch's copy.
+  struct Warm {
+    std::thread th;
+    ~Warm() { if (th.joinable()) th.join(); }
+  } warm;
+  if (!g.decode_warmed) {
+    g.decode_warmed = true;
+    hipStream_t sd = s_dec[0];
+    const int dev = c->dev;
+    warm.th = std::thread([sd, dev] {
+      if (hipSetDevice(dev) != hipSuccess) return;
+      hipLaunchKernelGGL(gz_segment_decode, dim3(1), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, sd, (const uint8_t*)nullptr, 0ull, (const GzSeg*)nullptr, 0u,
+                         (uint16_t*)nullptr, (GzSegOut*)nullptr, 0u);
+      (void)hipGetLastError();
+    });
+  }
   const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
   const uint64_t comp_pad = 256;
   const uint64_t end_bit = fsize * 8;
@@ -379,19 +390,19 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     for (uint32_t s = 0; s < np; ++s) { h_from[s] = (data0 + (p0 + s) * seg_bytes) * 8; h_found[s] = ~0ull; }
     const uint32_t s0 = (k == 0) ? 1u : 0u;
     if (k == 0) h_found[0] = data0 * 8;
-    HIPCHK(hipStreamWaitEvent(g.s_search, g.ev_copy[cb], 0));
+    HIPCHK(hipStreamWaitEvent(s_search, g.ev_copy[cb], 0));
     if (np > s0) {
       const uint8_t* vbase = g.comp[cb].p - b0;          // virtual base: byte i of the file is vbase[i] for i in [b0, b1 + pad)
-      span_begin(sp_search, g.s_search);
-      HIPCHK(hipMemcpyAsync(g.d_search[cb] + off_from, h_from, 8ull * np, hipMemcpyHostToDevice, g.s_search));
-      hipLaunchKernelGGL(gz_sync_search, dim3(np - s0), dim3(kSyncThreads), 0, g.s_search, reinterpret_cast<const uint64_t*>(vbase), b1 * 8,
+      span_begin(sp_search, s_search);
+      HIPCHK(hipMemcpyAsync(g.d_search[cb] + off_from, h_from, 8ull * np, hipMemcpyHostToDevice, s_search));
+      hipLaunchKernelGGL(gz_sync_search, dim3(np - s0), dim3(kSyncThreads), 0, s_search, reinterpret_cast<const uint64_t*>(vbase), b1 * 8,
                          reinterpret_cast<const uint64_t*>(g.d_search[cb] + off_from) + s0, np - s0, seg_bytes * 8,
                          reinterpret_cast<uint64_t*>(g.d_search[cb] + off_found) + s0);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(h_found + s0, g.d_search[cb] + off_found + 8ull * s0, 8ull * (np - s0), hipMemcpyDeviceToHost, g.s_search));
-      span_end(sp_search, g.s_search);
+      HIPCHK(hipMemcpyAsync(h_found + s0, g.d_search[cb] + off_found + 8ull * s0, 8ull * (np - s0), hipMemcpyDeviceToHost, s_search));
+      span_end(sp_search, s_search);
     }
-    HIPCHK(hipEventRecord(g.ev_found[cb], g.s_search));
+    HIPCHK(hipEventRecord(g.ev_found[cb], s_search));
     n_planned_total += np;
     return SCFQ_OK;
   };
@@ -438,7 +449,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     }
     n_seg_of[k] = n_seg;
     pool_used_of[k] = pool_used;
-    hipStream_t sd = g.s_decode[k & 1];
+    hipStream_t sd = s_dec[k & 1];
     if (warm.th.joinable()) warm.th.join();
     if (k >= 2) HIPCHK(hipStreamWaitEvent(sd, g.ev_post[k & 1], 0));      // the slot's symbols were read by batch k - 2's resolve
     HIPCHK(hipStreamWaitEvent(sd, g.ev_copy[k % 4], 0));
@@ -845,7 +856,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
     // gzread byte for byte, error text included.)
     static const bool resume_on = env_int("SCFQ_GZ_DEVICE_RESUME", 1) != 0;
     if (fail != kFallbackRest || total_out == 0 || !resume_on) return SCFQ_GZ_DECLINE;
-    for (hipStream_t st : {c->copy, g.s_search, g.s_decode[0], g.s_decode[1], c->compute}) HIPCHK(hipStreamSynchronize(st));
+    for (hipStream_t st : {c->copy, s_search, s_dec[0], s_dec[1], c->compute}) HIPCHK(hipStreamSynchronize(st));
     if ((rc = check_members())) return rc;
     std::vector<uint8_t> window(kGzWindow, 0);
     if (valid) HIPCHK(hipMemcpy(window.data(), g.d_wcarry + (uint64_t)wcarry * kGzWindow, kGzWindow, hipMemcpyDeviceToHost));
@@ -870,7 +881,7 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   c->timing.host_fill_ms += fill_ms;
   c->timing.ingest_wall_ms += std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
   if (verbose) {
-    for (hipStream_t st : {c->copy, g.s_search, g.s_decode[0], g.s_decode[1]}) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {c->copy, s_search, s_dec[0], s_dec[1]}) (void)hipStreamSynchronize(st);
     auto sum = [](const std::vector<Span>& v) { double t = 0; for (const Span& s : v) { float ms = 0; if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) t += ms; } return t; };
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "copy to HBM", sum(sp_copy));
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "block-start search", sum(sp_search));
@@ -892,17 +903,35 @@ int ingest_gz_device_batches(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_
   return SCFQ_OK;
 }
 
-// One file at a time per device (gz_shared); every stream of the path is idle when this returns, whatever the outcome — the
-// scan of the last batch included, which reads the shared output buffer: the buffers belong to the next caller.
+// An engine of the device's pool for the length of the call (GzShared, scfq_api.hip); every stream of the path is idle when this
+// returns, whatever the outcome — the scan of the last batch included, which reads the engine's output buffer: the buffers belong to
+// the next caller.
 int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing) {
   GzShared& gs = gz_shared(c->dev);
-  std::lock_guard<std::mutex> lk(gs.mu);
-  const int rc = ingest_gz_device_batches(c, img, fsize, flags, timing);
-  GzDevBuffers& g = gs.buf;
+  static const int n_engines = std::min((int)GzShared::kMax, std::max(1, env_int("SCFQ_GZ_DEVICE_ENGINES", 4)));
+  const bool big = fsize > (1ull << 30);
+  int e = -1;
+  {
+    std::unique_lock<std::mutex> lk(gs.mu);
+    gs.cv.wait(lk, [&] { return !gs.big_running && (big ? gs.n_busy == 0 : gs.n_busy < n_engines); });
+    for (int k = 0; k < n_engines; ++k) if (!gs.busy[k]) { e = k; break; }
+    gs.busy[e] = true;
+    ++gs.n_busy;
+    gs.big_running = big;
+  }
+  GzDevBuffers& g = gs.buf[e];
+  const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing);
   if (c->copy) (void)hipStreamSynchronize(c->copy);
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
   for (int b = 0; b < 2; ++b) if (g.s_decode[b]) (void)hipStreamSynchronize(g.s_decode[b]);
   if (c->compute) (void)hipStreamSynchronize(c->compute);
   gz_free_retired(&g);
+  {
+    std::lock_guard<std::mutex> lk(gs.mu);
+    gs.busy[e] = false;
+    --gs.n_busy;
+    if (big) gs.big_running = false;
+  }
+  gs.cv.notify_all();
   return rc;
 }
