@@ -96,7 +96,7 @@ struct GzDevBuffers {
   uint8_t* h_crc = nullptr;
   std::vector<void*> retired;                             // buffers replaced by bigger ones during a call: freed when it ends
   bool decode_warmed = false;                             // the decode kernel's first (empty) launch has set the device's scratch up
-  hipStream_t s_search = nullptr, s_decode[2] = {nullptr, nullptr};
+  hipStream_t s_search = nullptr, s_gap = nullptr, s_decode[2] = {nullptr, nullptr};
   hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr}, ev_found[4] = {nullptr, nullptr, nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
   uint8_t* d_search[4] = {nullptr, nullptr, nullptr, nullptr};       // from | found of a batch's block-start search (slices of the tables)
   uint8_t* h_search[4] = {nullptr, nullptr, nullptr, nullptr};

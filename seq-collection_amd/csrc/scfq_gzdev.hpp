@@ -98,7 +98,8 @@ inline void gz_free(GzDevBuffers* g) {
   g->d_wcarry = nullptr;
   g->wcarry_cap = 0;
   if (g->s_search) (void)hipStreamDestroy(g->s_search);
-  g->s_search = nullptr;
+  if (g->s_gap) (void)hipStreamDestroy(g->s_gap);
+  g->s_search = g->s_gap = nullptr;
 }
 
 // x^(8 n) mod P and products in the reflected representation (as the kernels: bit 31 = x^0)
@@ -574,6 +575,18 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
         if (verbose) std::fprintf(stderr, "scfq gzdev: batch %u: chain not closed after %d rounds (%zu gaps): host path\n", k, round, gaps.size());
         return SCFQ_GZ_DECLINE;
       }
+      // (a gap round — a search, a handful of segments decoded, the host waiting for both — runs on its own high-priority stream when the
+      // file has several batches: queued on the compute stream it stood behind the previous batch's window kernels, which wait for the
+      // LDS of a CU that two decode workgroups still hold: 9 ms per round instead of 2 - 3)
+      hipStream_t s_gap = c->compute;
+      if (nb > 1) {
+        if (!g.s_gap) {
+          int least = 0, greatest = 0;
+          if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) HIPCHK(hipStreamCreateWithPriority(&g.s_gap, hipStreamNonBlocking, greatest));
+          else HIPCHK(hipStreamCreateWithFlags(&g.s_gap, hipStreamNonBlocking));
+        }
+        s_gap = g.s_gap;
+      }
       // A gap is as long as a planned segment and one wave would take a whole decode phase for it: it is cut into pieces
       // the same way the file was — its exact start, then block starts searched at equal steps inside it
       std::vector<Gap> pieces;       // (start, stop, room multiplier)
@@ -589,13 +602,13 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
         std::vector<uint64_t> found(from.size(), ~0ull);
         if (!from.empty() && from.size() <= max_seg) {
           std::memcpy(h_gfrom, from.data(), 8 * from.size());
-          HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gfrom, h_gfrom, 8 * from.size(), hipMemcpyHostToDevice, c->compute));
-          hipLaunchKernelGGL(gz_sync_search, dim3((unsigned)from.size()), dim3(kSyncThreads), 0, c->compute, reinterpret_cast<const uint64_t*>(vbase), limit,
+          HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gfrom, h_gfrom, 8 * from.size(), hipMemcpyHostToDevice, s_gap));
+          hipLaunchKernelGGL(gz_sync_search, dim3((unsigned)from.size()), dim3(kSyncThreads), 0, s_gap, reinterpret_cast<const uint64_t*>(vbase), limit,
                              reinterpret_cast<const uint64_t*>(g.d_pmeta[pp] + offp_gfrom), (uint32_t)from.size(), seg_bytes * 8,
                              reinterpret_cast<uint64_t*>(g.d_pmeta[pp] + offp_gfound));
           HIPCHK(hipGetLastError());
-          HIPCHK(hipMemcpyAsync(h_gfound, g.d_pmeta[pp] + offp_gfound, 8 * from.size(), hipMemcpyDeviceToHost, c->compute));
-          HIPCHK(hipStreamSynchronize(c->compute));
+          HIPCHK(hipMemcpyAsync(h_gfound, g.d_pmeta[pp] + offp_gfound, 8 * from.size(), hipMemcpyDeviceToHost, s_gap));
+          HIPCHK(hipStreamSynchronize(s_gap));
           for (size_t q = 0; q < from.size(); ++q) found[q] = h_gfound[q];
         }
         size_t fk = 0;
@@ -626,13 +639,13 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       if (n_seg == first) return SCFQ_GZ_DECLINE;
       if (verbose) std::fprintf(stderr, "scfq gzdev:   batch %u round %d: %u gap segments\n", k, round + 1, n_seg - first);
       ++n_gap_rounds;
-      HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs + sizeof(GzSeg) * first, h_segs + first, sizeof(GzSeg) * (n_seg - first), hipMemcpyHostToDevice, c->compute));
-      hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg - first + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, c->compute,
+      HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs + sizeof(GzSeg) * first, h_segs + first, sizeof(GzSeg) * (n_seg - first), hipMemcpyHostToDevice, s_gap));
+      hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg - first + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, s_gap,
                          vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs) + first, n_seg - first, sl.sym.base(),
                          reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs) + first, inflate_serial_loop());
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(h_outs + first, sl.d_meta + off_outs + sizeof(GzSegOut) * first, sizeof(GzSegOut) * (n_seg - first), hipMemcpyDeviceToHost, c->compute));
-      HIPCHK(hipStreamSynchronize(c->compute));
+      HIPCHK(hipMemcpyAsync(h_outs + first, sl.d_meta + off_outs + sizeof(GzSegOut) * first, sizeof(GzSegOut) * (n_seg - first), hipMemcpyDeviceToHost, s_gap));
+      HIPCHK(hipStreamSynchronize(s_gap));
       n_decoded_total += n_seg - first;
     }
     n_seg_of[k] = n_seg;
@@ -923,6 +936,7 @@ int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags,
   const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing);
   if (c->copy) (void)hipStreamSynchronize(c->copy);
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
+  if (g.s_gap) (void)hipStreamSynchronize(g.s_gap);
   for (int b = 0; b < 2; ++b) if (g.s_decode[b]) (void)hipStreamSynchronize(g.s_decode[b]);
   if (c->compute) (void)hipStreamSynchronize(c->compute);
   gz_free_retired(&g);
