@@ -72,6 +72,6 @@ for mode, env in modes:
         reps = re.split(r"scfq rep \d+\n", r.stderr)
         k = rows.index(min(rows, key=lambda j: j["wall_s"])) + 1
         best["phases_ms"] = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"scfq gzdev: ([a-zA-Z|\- ]+?)\s+([0-9.]+) ms", reps[k])}
-        best["summary"] = [l for l in reps[k].splitlines() if "on the chain" in l or "round" in l or "host:" in l]
+        best["summary"] = [l for l in reps[k].splitlines() if "on the chain" in l or "round" in l or "host:" in l or "copier thread" in l or "high water" in l]
     print(json.dumps(best), flush=True)
 os.remove(plain); os.remove(plain + ".gz")

@@ -579,6 +579,11 @@ __device__ __forceinline__ void hot_match(const uint32_t* xa, const uint32_t* xb
       ".Lhm_tab%=:\n\t"
       SCFQ_HOT_STANZAS
       "\n.Lhm_end%=:\n\t"
+      // the jump lands at .Lhm_tab + v * stanza: if a stanza's encoding ever changes size (another v_bitop3 encoding, a relaxed
+      // branch, padding) this stops the build instead of jumping into the middle of an instruction
+      ".if (.Lhm_end%= - .Lhm_tab%=) != 256 * %c[stanza]\n\t"
+      ".error \"hot_match: the 256 stanzas of hot_dispatch.inc are not SCFQ_HOT_STANZA_BYTES each\"\n\t"
+      ".endif\n\t"
       "v_bitop3_b32 %[ma], %[ma], %[t0], %[t2] bitop3:0x80\n\t"
       "v_bitop3_b32 %[mb], %[mb], %[t1], %[t3] bitop3:0x80"
       : [ma] "=&v"(ma), [mb] "=&v"(mb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [st] "=&s"(st)

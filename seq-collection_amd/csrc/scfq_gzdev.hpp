@@ -165,7 +165,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // gz_cold.jsonl)
   const uint64_t target_segs = 4096;
   const uint64_t seg_bytes = seg_kb_env > 0 ? ((((uint64_t)std::max(32, seg_kb_env)) << 10) + 4095) & ~4095ull
-                                            : comp <= (512ull << 20) ? std::min<uint64_t>(128u << 10, std::max<uint64_t>(48u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull))
+                                            : comp <= (512ull << 20) ? std::min<uint64_t>(128u << 10, std::max<uint64_t>(16u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull))
                                                                      : (64u << 10);      // (up to 512 MiB: one batch of ~4096 segments, the device filled once, <= 9 GB held)
   // Output room of a segment = `ratio_est` symbols per compressed byte it spans + 128 Ki (it runs on to the end of a block),
   // behind its 32768 markers.  ratio_est comes from the file itself: the host inflates the first 192 KiB of the first member
@@ -350,18 +350,39 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   uint32_t n_planned_total = 0, n_decoded_total = 0, n_chain_total = 0, n_gap_rounds = 0, n_overflows = 0;
   const char* why = nullptr;             // why a batch was handed to the host (kFallbackRest)
   std::map<uint64_t, double> overflow_mult;      // start bit of a segment that ran out of room -> the multiple of the assumed room it was last given
-  double fill_ms = 0, walk_ms = 0, h_evsync_ms = 0, h_memcpy_ms = 0, h_enqueue_ms = 0, h_search_wait_ms = 0, h_dec_wait_ms = 0, h_post_wait_ms = 0;
+  double fill_ms = 0, walk_ms = 0, h_copier_wait_ms = 0, h_search_wait_ms = 0, h_dec_wait_ms = 0, h_post_wait_ms = 0;
   uint32_t pin_it = 0;                   // the pinned staging buffers alternate over the whole file
   std::vector<uint32_t> n_seg_of(nb + 1, 0);
   std::vector<uint64_t> pool_used_of(nb + 1, 0);
   HIPCHK(hipMemsetAsync(g.crc.p, 0, 64, c->compute));          // word 0: the resolve kernels' error status for the whole file
 
-  // ---- stage A(k): bytes of batch k to comp[k % 4], block-start search — launched one iteration before its results are waited for ----
-  auto stage_a = [&](uint32_t k) -> int {
+  // ---- the COPIER: a thread of its own moves the compressed bytes — file mapping -> pinned ring -> comp[k % 4] — batch after batch,
+  // up to four batches ahead of the walk.  On the orchestrating thread (round 2, and this round until the last day) the copies
+  // were 100 of the 166 ms that thread was busy for a 10 GB file, and the thread was the pipeline's bottleneck: it waited 25 ms
+  // for decodes, the decodes waited for it.  ev_copy[k % 4] is recorded behind a batch's last piece; `enq` counts the batches whose
+  // copies are queued, `allowed` the batches whose buffer is free again (batch k + 4 re-uses batch k's once that has been walked).
+  struct Copier {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t enq = 0, allowed = 4;
+    bool stop = false;
+    int rc = SCFQ_OK;
+    std::string err;
+    double evsync_ms = 0, memcpy_ms = 0, enqueue_ms = 0, fill_ms = 0;
+    uint64_t bytes = 0;
+    std::vector<Span> spans;
+    ~Copier() {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv.notify_all();
+      if (th.joinable()) th.join();
+    }
+  } cp;
+  auto copy_batch = [&](uint32_t k) -> int {       // (runs on the copier thread)
     const auto tf = clk::now();
     const int cb = (int)(k % 4);
     const uint64_t b0 = byte0_of(k), b1 = copy_end_of(k);
-    span_begin(sp_copy, c->copy);
+    if (verbose) { Span sp; (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b); (void)hipEventRecord(sp.a, c->copy); cp.spans.push_back(sp); }
     for (uint64_t off = b0; off < b1; off += pin_chunk, ++pin_it) {
       const int pb = (int)(pin_it & 1);
       const uint64_t len = std::min(pin_chunk, b1 - off);
@@ -374,15 +395,54 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
       HIPCHK(hipEventRecord(c->ev_copied[pb], c->copy));
       auto t3 = clk::now();
-      h_evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
-      h_memcpy_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
-      h_enqueue_ms += std::chrono::duration<double, std::milli>(t3 - t2).count();
+      cp.evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+      cp.memcpy_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
+      cp.enqueue_ms += std::chrono::duration<double, std::milli>(t3 - t2).count();
     }
     HIPCHK(hipMemsetAsync(g.comp[cb].p + (b1 - b0), 0, comp_pad, c->copy));
-    span_end(sp_copy, c->copy);
+    if (verbose) (void)hipEventRecord(cp.spans.back().b, c->copy);
     HIPCHK(hipEventRecord(g.ev_copy[cb], c->copy));
-    c->timing.h2d_bytes += b1 - b0;
-    fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
+    cp.bytes += b1 - b0;
+    cp.fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
+    return SCFQ_OK;
+  };
+  cp.th = std::thread([&] {
+    if (hipSetDevice(c->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(cp.mu); cp.rc = SCFQ_EHIP; cp.err = "hipSetDevice on the copier thread"; cp.cv.notify_all(); return; }
+    for (uint32_t k = 0; k < nb; ++k) {
+      {
+        std::unique_lock<std::mutex> lk(cp.mu);
+        cp.cv.wait(lk, [&] { return cp.stop || k < cp.allowed; });
+        if (cp.stop) return;
+      }
+      const int r = copy_batch(k);
+      {
+        std::lock_guard<std::mutex> lk(cp.mu);
+        if (r) { cp.rc = r; cp.err = g_err; }
+        cp.enq = k + 1;
+      }
+      cp.cv.notify_all();
+      if (r) return;
+    }
+  });
+  struct CopierJoin {      // (declared behind everything the copier thread touches: runs first on every way out of this function)
+    Copier& cp;
+    void now() { { std::lock_guard<std::mutex> lk(cp.mu); cp.stop = true; } cp.cv.notify_all(); if (cp.th.joinable()) cp.th.join(); }
+    ~CopierJoin() { now(); }
+  } copier_join{cp};
+  // the walk of batch k is through: batch k + 4 may take its buffer
+  auto release_comp = [&](uint32_t k) { { std::lock_guard<std::mutex> lk(cp.mu); cp.allowed = std::max(cp.allowed, k + 5); } cp.cv.notify_all(); };
+
+  // ---- stage A(k): the block-start search of batch k, queued behind its copy — launched one iteration before its results are waited for ----
+  auto stage_a = [&](uint32_t k) -> int {
+    const int cb = (int)(k % 4);
+    const uint64_t b0 = byte0_of(k), b1 = copy_end_of(k);
+    {
+      auto t0 = clk::now();
+      std::unique_lock<std::mutex> lk(cp.mu);
+      cp.cv.wait(lk, [&] { return cp.enq > k || cp.rc != SCFQ_OK; });
+      h_copier_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+      if (cp.rc != SCFQ_OK) { std::snprintf(g_err, sizeof g_err, "%s", cp.err.c_str()); return cp.rc; }
+    }
     // search: the planned segments of this batch (the file's very first one starts exactly at the member's first block)
     uint64_t* h_from = reinterpret_cast<uint64_t*>(g.h_search[cb] + off_from);
     uint64_t* h_found = reinterpret_cast<uint64_t*>(g.h_search[cb] + off_found);
@@ -799,6 +859,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     member_no = member_end_no;
     valid = valid_end;
     finished = finished_end;
+    release_comp(k);
     return SCFQ_OK;
   };
 
@@ -858,6 +919,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       if (finished) break;              // (trailing garbage may leave batches behind the last member: nothing in them counts)
     }
   }
+  copier_join.now();                                    // (batches behind the end of the last member are not copied any more; the ring is free for a hand-over)
   if (fail < 0) return fail;
   if (!fail && !finished) return SCFQ_GZ_DECLINE;      // the data ended inside a member
   bool resumed = false;
@@ -891,6 +953,10 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   } else if (parts_checked != parts.size()) {
     return SCFQ_GZ_DECLINE;
   }
+  fill_ms += cp.fill_ms;
+  c->timing.h2d_bytes += cp.bytes;
+  for (const Span& sp : cp.spans) sp_copy.push_back(sp);
+  cp.spans.clear();
   c->timing.host_fill_ms += fill_ms;
   c->timing.ingest_wall_ms += std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
   if (verbose) {
@@ -904,8 +970,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "resolve", sum(sp_resolve));
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "crc tiles", sum(sp_crc));
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "scan", sum(sp_scan));
-    std::fprintf(stderr, "scfq gzdev: host: pinned-buffer waits %.1f, memcpy %.1f, copy enqueue %.1f, search waits %.1f, decode waits %.1f, post waits %.1f ms\n", h_evsync_ms,
-                 h_memcpy_ms, h_enqueue_ms, h_search_wait_ms, h_dec_wait_ms, h_post_wait_ms);
+    std::fprintf(stderr, "scfq gzdev: copier thread: pinned-buffer waits %.1f, memcpy %.1f, copy enqueue %.1f ms; orchestrating thread: copier waits %.1f, search waits %.1f, decode waits %.1f, post waits %.1f ms\n",
+                 cp.evsync_ms, cp.memcpy_ms, cp.enqueue_ms, h_copier_wait_ms, h_search_wait_ms, h_dec_wait_ms, h_post_wait_ms);
     std::fprintf(stderr, "scfq gzdev: host time in stage A (copy, search) %.1f, B (plan, decode launch) %.1f, C (walk, windows, bytes, scan) %.1f ms; of all that inside device allocations %.1f ms\n",
                  stage_ms[0], stage_ms[1], stage_ms[2], gz_alloc_ms());
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "wall", std::chrono::duration<double, std::milli>(clk::now() - t_begin).count());
