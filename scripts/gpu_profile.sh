@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BARGS="--steps ${PROF_STEPS:-20} --warmup 3 --no-cpu-baseline $@"
+BARGS="--steps ${PROF_STEPS:-20} --warmup 3 --no-cpu-baseline --ingest-bytes 0 $@"
 # 1) kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $R/bench.py $BARGS > $OUT/trace_bench.json 2> $OUT/trace.err
 # 2) PMC passes (counters only; each group in its own run)

@@ -22,6 +22,8 @@ gzip6)
 prof)
   bash scripts/gpu_profile.sh $TAG > gpurun_out/$TAG/profile_summary.txt 2>&1
   grep -E "fq_scan_tiles|FETCH|WRITE" gpurun_out/$TAG/profile_summary.txt | head -20 ;;
+jobs)
+  python scripts/measure_jobs.py /tmp > gpurun_out/$TAG/jobs_8_files.jsonl 2> gpurun_out/$TAG/jobs.err; cut -c1-330 gpurun_out/$TAG/jobs_8_files.jsonl ;;
 aux)
   python scripts/measure_ingest.py 2e9 /tmp > gpurun_out/$TAG/ingest.jsonl 2>gpurun_out/$TAG/ingest.err
   python scripts/measure_bgzf_device.py 4e9 > gpurun_out/$TAG/bgzf_device.jsonl 2>gpurun_out/$TAG/bgzf.err
