@@ -74,8 +74,13 @@ __device__ __forceinline__ bool sync_kraft(WP words, uint64_t bit) {
 // code with an end-of-block code and a distance code zlib accepts.  Everything lives in registers (counts and the symbols
 // sorted by code length are packed into 64-bit words), and a candidate is dropped the moment one of its codes is
 // over-subscribed: random bits get there within a few dozen lengths, so the survivors of the quick tests cost little.
+// lit_mask: bit j set = the file is known to hold no byte in [32 j, 32 j + 32) (from the host's sample of its first 192 KiB): a
+// candidate whose literal/length code gives one of those literals a code is not a block of this file.  A header made of chance bits
+// hands out code lengths all over the alphabet — for a text file (no byte >= 128: half the literals) this takes the false syncs from
+// one in 4000 searches to practically none, and with them the extra decode round each of them cost (5 - 9 ms).  A true block that
+// does use such a byte is simply not found here: the walk decodes it as a gap, results do not depend on the mask.
 template <typename WP>
-__device__ inline bool sync_deep(WP words, uint64_t bit, uint64_t end_bit) {
+__device__ inline bool sync_deep(WP words, uint64_t bit, uint64_t end_bit, uint32_t lit_mask) {
   const uint64_t w = bits64_at(words, bit);
   const uint32_t hlit = (uint32_t)((w >> 3) & 31u) + 257u, hdist = (uint32_t)((w >> 8) & 31u) + 1u, hclen = (uint32_t)((w >> 13) & 15u) + 4u;
   const uint64_t w2 = bits64_at(words, bit + 17);
@@ -127,6 +132,12 @@ __device__ inline bool sync_deep(WP words, uint64_t bit, uint64_t end_bit) {
       kraft_d += in_d * (32768u >> val);
       if (kraft_l > 32768u || kraft_d > 32768u) return false;          // over-subscribed: no need to read on
       if (k <= 256u && 256u < k + rep) len256 = val;
+      if (lit_mask && k < 256u) {
+        // literals [k, min(k + rep, 256)) get a code: none of them may lie in a masked 32-value class
+        const uint32_t hi = (k + rep < 256u ? k + rep : 256u) - 1u, c0 = k >> 5, c1 = hi >> 5;
+        const uint32_t span = (c1 >= 31u ? 0xFFFFFFFFu : ((2u << c1) - 1u)) & ~((1u << c0) - 1u);
+        if (lit_mask & span) return false;
+      }
       if (in_d) { n_d += in_d; max_d = val > max_d ? val : max_d; }
     }
     k += rep;
@@ -142,7 +153,7 @@ __device__ inline bool sync_deep(WP words, uint64_t bit, uint64_t end_bit) {
 // quick test and each code length of the deep one was a memory round trip (6.2 ms for 4096 searches over 0.5 GB).
 constexpr uint32_t kSyncStageWords = 600;       // 512 words of positions + 1 (the chunk starts inside a word) + 4600 bits of header + spare
 __global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* __restrict__ words, uint64_t end_bit, const uint64_t* __restrict__ from,
-                                                              uint32_t n_seg, uint64_t max_bits, uint64_t* __restrict__ found) {
+                                                              uint32_t n_seg, uint64_t max_bits, uint64_t* __restrict__ found, uint32_t lit_mask) {
   __shared__ uint32_t list[kSyncListCap];
   __shared__ uint32_t n_list, best;
   __shared__ uint64_t stage[kSyncStageWords];
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* _
     // (a list that overflowed lost some LATER candidates of this chunk at worst out of order: every kept one is still
     // tested, the minimum over them is taken, and a missed earlier true block only makes this segment a gap for the host)
     for (uint32_t t = threadIdx.x; t < n; t += kSyncThreads)
-      if (sync_deep(sw, c0 + list[t] - bit0, rel_end)) atomicMin(&best, list[t]);
+      if (sync_deep(sw, c0 + list[t] - bit0, rel_end, lit_mask)) atomicMin(&best, list[t]);
     __syncthreads();
     if (best != 0xFFFFFFFFu) { result = c0 + best; break; }       // block-uniform
     __syncthreads();

@@ -174,7 +174,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // a 10 GB file, and sent the whole file to the host when one segment compressed better than that.
   static const double ratio_env = std::atof(std::getenv("SCFQ_GZ_DEVICE_RATIO") ? std::getenv("SCFQ_GZ_DEVICE_RATIO") : "0");
   double ratio_est = ratio_env > 0 ? ratio_env : 6.0;
-  if (ratio_env <= 0) {
+  uint32_t lit_mask = 0;                 // 32-value classes of bytes the file's first 192 KiB (inflated: a MB or so) do not hold: the search's plausibility test
+  {
     const uint64_t sample_in = std::min<uint64_t>(fsize - data0, 192u << 10);
     std::vector<uint8_t> sample_out((size_t)kGzWindow + (8u << 20));
     auto dec = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
@@ -184,15 +185,28 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     const uint64_t got_out = (uint64_t)(o - (sample_out.data() + kGzWindow)), got_in = std::max<uint64_t>(1, dec->bitpos() / 8);
     // (long runs — zeros, one record repeated: ratios in the hundreds — are the host decoder's home ground, gigabytes per second,
     // and the lane-parallel loop's worst case, one symbol per round: such a file is declined here, before anything is queued)
-    if (got_in >= 1024 && (double)got_out / (double)got_in > 24.0) return SCFQ_GZ_DECLINE;
+    if (ratio_env <= 0 && got_in >= 1024 && (double)got_out / (double)got_in > 24.0) return SCFQ_GZ_DECLINE;
     static const double est_mul = std::atof(std::getenv("SCFQ_GZ_DEVICE_RATIO_MARGIN") ? std::getenv("SCFQ_GZ_DEVICE_RATIO_MARGIN") : "1.15");
-    if (got_out >= 65536 && got_in >= 4096) ratio_est = std::min(32.0, std::max(3.0, est_mul * (double)got_out / (double)got_in + 0.25));
+    if (ratio_env <= 0 && got_out >= 65536 && got_in >= 4096) ratio_est = std::min(32.0, std::max(3.0, est_mul * (double)got_out / (double)got_in + 0.25));
+    static const bool use_mask = env_int("SCFQ_GZ_DEVICE_LITERAL_MASK", 1) != 0;
+    if (use_mask && got_out >= 65536) {
+      // (only the upper half of the alphabet is ever ruled out: FASTQ is ASCII by definition, while which letters or digits a file
+      // uses may well change after its first megabyte — lowercase soft-masked bases, another quality range)
+      uint32_t seen = 0;
+      const uint8_t* so = sample_out.data() + kGzWindow;
+      for (uint64_t q = 0; q < got_out; ++q) seen |= 1u << (so[q] >> 5);
+      lit_mask = (seen & 0xF0u) ? 0u : 0xF0u;
+    }
   }
   const uint64_t n_plan = std::max<uint64_t>(1, (comp + seg_bytes - 1) / seg_bytes);
   std::vector<uint64_t> bstart{0};                     // planned segments [bstart[k], bstart[k + 1]) make batch k
   {
     const uint64_t n_batches = (n_plan + batch_segs - 1) / batch_segs, per = (n_plan + n_batches - 1) / n_batches;
     for (uint64_t at = 0; at < n_plan;) { at = std::min<uint64_t>(n_plan, at + per); bstart.push_back(at); }
+    // (SCFQ_GZ_DEVICE_FIRST_BATCH_DIV=4: the first batch cut in two, a quarter and the rest, so that the device starts sooner — measured
+    // r3: 160.6 ms against 156.4 for the 10 GB file, the decode is what the call waits for: off)
+    static const int first_div = std::max(1, env_int("SCFQ_GZ_DEVICE_FIRST_BATCH_DIV", 1));
+    if (n_batches >= 3 && first_div > 1 && bstart[1] / first_div >= 64) bstart.insert(bstart.begin() + 1, bstart[1] / first_div);
   }
   const uint32_t nb = (uint32_t)bstart.size() - 1;
   // ---- streams.  A file of ONE batch is a chain — copy, search, decode, walk, windows, bytes, scan — and runs on the context's two
@@ -317,13 +331,20 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   }
   uint8_t* d_out = nullptr;                            // (set when the first batch's bytes get their room)
   const double alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
-  if (verbose) std::fprintf(stderr, "scfq gzdev: plan + tables in %.1f ms: %u batch(es), segments of %llu KiB, %.2f symbols per compressed byte assumed\n", alloc_ms, nb,
-                            (unsigned long long)(seg_bytes >> 10), ratio_est);
+  if (verbose) std::fprintf(stderr, "scfq gzdev: plan + tables in %.1f ms: %u batch(es), segments of %llu KiB, %.2f symbols per compressed byte assumed, literal classes the search rules out 0x%02x\n", alloc_ms, nb,
+                            (unsigned long long)(seg_bytes >> 10), ratio_est, lit_mask);
   // the pinned ring the compressed bytes cross in: pieces of 16 MiB (pinning memory costs 160 ms per GB — 21 of a small file's
   // milliseconds with the host path's 64 MiB pieces); a ring another path of this context has set up already is used as it is
-  const uint64_t pin_chunk = c->stage_cap ? std::min<uint64_t>(c->stage_cap, 64ull << 20) : (16ull << 20);
-  rc = ensure_staging(c, pin_chunk, true);
+  // Bigger files, bigger pieces — 64 MiB beyond 256 MiB compressed, 128 MiB beyond 1 GiB (SCFQ_GZ_DEVICE_RING_MB overrides both): with the
+  // decode waves of two batches on the device a piece crosses PCIe at 26 - 30 GB/s instead of 55, every piece costs the copier a
+  // round of eight memcpy threads, and the orchestrating thread waited for the copier 94 / 75 / 39 ms of a 10 GB file's 187 / 169 /
+  // 156 ms with pieces of 16 / 64 / 128 MiB (profiles/r03/gz_device_variants.txt); pinning 2 x 128 MiB costs a process 40 ms.
+  static const int ring_env = env_int("SCFQ_GZ_DEVICE_RING_MB", 0);
+  const uint64_t want_piece = ring_env > 0 ? ((uint64_t)std::min(256, std::max(4, ring_env)) << 20)
+                                           : comp > (1ull << 30) ? (128ull << 20) : comp > (256ull << 20) ? (64ull << 20) : (16ull << 20);
+  rc = ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
   if (rc) return rc;
+  const uint64_t pin_chunk = want_piece;
 
   // ---- measurement aid (SCFQ_VERBOSE): device time of the stages, summed over the batches ---------------------------------------
   struct Span { hipEvent_t a = nullptr, b = nullptr; };
@@ -458,7 +479,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       HIPCHK(hipMemcpyAsync(g.d_search[cb] + off_from, h_from, 8ull * np, hipMemcpyHostToDevice, s_search));
       hipLaunchKernelGGL(gz_sync_search, dim3(np - s0), dim3(kSyncThreads), 0, s_search, reinterpret_cast<const uint64_t*>(vbase), b1 * 8,
                          reinterpret_cast<const uint64_t*>(g.d_search[cb] + off_from) + s0, np - s0, seg_bytes * 8,
-                         reinterpret_cast<uint64_t*>(g.d_search[cb] + off_found) + s0);
+                         reinterpret_cast<uint64_t*>(g.d_search[cb] + off_found) + s0, lit_mask);
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(h_found + s0, g.d_search[cb] + off_found + 8ull * s0, 8ull * (np - s0), hipMemcpyDeviceToHost, s_search));
       span_end(sp_search, s_search);
@@ -665,7 +686,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
           HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gfrom, h_gfrom, 8 * from.size(), hipMemcpyHostToDevice, s_gap));
           hipLaunchKernelGGL(gz_sync_search, dim3((unsigned)from.size()), dim3(kSyncThreads), 0, s_gap, reinterpret_cast<const uint64_t*>(vbase), limit,
                              reinterpret_cast<const uint64_t*>(g.d_pmeta[pp] + offp_gfrom), (uint32_t)from.size(), seg_bytes * 8,
-                             reinterpret_cast<uint64_t*>(g.d_pmeta[pp] + offp_gfound));
+                             reinterpret_cast<uint64_t*>(g.d_pmeta[pp] + offp_gfound), lit_mask);
           HIPCHK(hipGetLastError());
           HIPCHK(hipMemcpyAsync(h_gfound, g.d_pmeta[pp] + offp_gfound, 8 * from.size(), hipMemcpyDeviceToHost, s_gap));
           HIPCHK(hipStreamSynchronize(s_gap));

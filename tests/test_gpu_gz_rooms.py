@@ -51,6 +51,25 @@ def test_segment_that_needs_more_room_is_decoded_again(gpu, oracle, tmp_path):
     assert r.returncode == 0 and r.stdout == want and " 0 segments given more room" in r.stderr, r.stderr[-2000:]
 
 
+def test_bytes_the_sample_did_not_show(gpu, oracle, tmp_path):
+    """the block-start search rules out blocks whose literal code covers bytes >= 128 when the file's first 192 KiB (compressed) hold
+    none: a file that turns binary later only loses the search there (those blocks are decoded as gaps, or the file goes to the
+    host) — the row is the oracle's either way, with and without the rule"""
+    rng = np.random.default_rng(81)
+    text = fastq_bytes(5_000_000, seed=80)
+    data = text + rng.integers(128, 256, 400_000, dtype=np.uint8).tobytes() + b"\n" + text[:2_000_000]
+    f = tmp_path / "turns_binary.fq.gz"
+    f.write_bytes(member(data))
+    want = oracle.tsv(oracle.count(np.frombuffer(data, dtype=np.uint8))) + "\n"
+    for env in (DEV_ENV, BATCH_ENV, dict(DEV_ENV, SCFQ_GZ_DEVICE_LITERAL_MASK="0")):
+        r = run(f, **env)
+        assert r.returncode == 0 and r.stdout == want, r.stderr[-3000:]
+    r = run(f, **DEV_ENV)
+    assert "rules out 0xf0" in r.stderr, r.stderr[-2000:]
+    r = run(f, **dict(DEV_ENV, SCFQ_GZ_DEVICE_LITERAL_MASK="0"))
+    assert "rules out 0x00" in r.stderr, r.stderr[-2000:]
+
+
 def test_batch_without_room_hands_the_rest_to_the_host(gpu, oracle, tmp_path):
     data = fastq_bytes(7_000_000, seed=78)
     cuts = [0, 2_000_003, 2_000_003 + 41, 5_100_000, len(data)]
