@@ -160,19 +160,19 @@ def _bench(args, nproc=0, timeout=600):
 
 def test_bench_exchange_path_single_rank_rccl(gpu):
     """bench.py's N>1 code (library communicator, exchanges two steps in flight, drain) with one RCCL rank"""
-    j = _bench(["--gpus", "1", "--exchange-at-1", "--bytes-per-gpu", "3e8", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    j = _bench(["--gpus", "1", "--exchange-at-1", "--bytes-per-gpu", "3e8", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--ingest-bytes", "0"])
     assert j["counters"]["matches_generator_tally"] is True
     assert j["config"]["exchange"].startswith("RCCL 2.") and "scfq_comm" in j["config"]["exchange"]
     assert "exchange_note" not in j["config"]
     # and the torch.distributed mirror on the same path
-    j2 = _bench(["--gpus", "1", "--exchange-at-1", "--exchange", "torch", "--bytes-per-gpu", "3e8", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    j2 = _bench(["--gpus", "1", "--exchange-at-1", "--exchange", "torch", "--bytes-per-gpu", "3e8", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--ingest-bytes", "0"])
     assert j2["counters"] == j["counters"] and "torch.distributed" in j2["config"]["exchange"]
 
 
 def test_bench_full_size_shard_of_the_scaling_run(gpu):
     """one rank's share of BASELINE configs[2] — 25 GB, 69.5 M records — generated, scanned and exchanged exactly as in the 8-GPU
     run (at this size the generator's one-wave-per-record launch once exceeded 2^32 threads and silently wrote 3 % of the shard)"""
-    j = _bench(["--gpus", "1", "--exchange-at-1", "--bytes-per-gpu", "25e9", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], timeout=900)
+    j = _bench(["--gpus", "1", "--exchange-at-1", "--bytes-per-gpu", "25e9", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--ingest-bytes", "0"], timeout=900)
     assert j["counters"]["matches_generator_tally"] is True
     assert j["config"]["bytes_per_gpu"] >= 25_000_000_000 and j["counters"]["reads"] > 69_000_000
     assert j["roofline"]["frac"] > 0.5
