@@ -82,11 +82,11 @@ struct GzSlot {            // one batch being decoded: symbols + its segment tab
 // 1.5 - 2.6 s of every first call in round 2).
 struct GzDevBuffers {
   DevBuf comp[4];                                                                           // compressed bytes of the four batches in flight (copy + search one ahead of the decode)
-  GzSlot slot[2];
+  GzSlot slot[3];                                                                           // symbols of the batches being decoded / resolved (SCFQ_GZ_DEVICE_SLOTS)
   uint8_t* d_tables = nullptr;  uint64_t tables_cap = 0;        // every table of both slots: one device allocation ...
   uint8_t* h_tables = nullptr;  uint64_t htables_cap = 0;       // ... and one pinned one (+ the tile CRCs' mirror)
-  uint8_t* d_pmeta[2] = {nullptr, nullptr};                     // chain, work lists, gap searches of a batch
-  uint8_t* h_pmeta[2] = {nullptr, nullptr};
+  uint8_t* d_pmeta[3] = {nullptr, nullptr, nullptr};            // chain, work lists, gap searches of a batch
+  uint8_t* h_pmeta[3] = {nullptr, nullptr, nullptr};
   DevBuf out;                                             // inflated bytes of one batch (kStagePad in front)
   DevBuf win;                                             // the window in front of every chain entry of one batch
   uint8_t* d_wcarry = nullptr; uint64_t wcarry_cap = 0;  // the window that crosses a batch border (two, alternating)
@@ -97,13 +97,13 @@ struct GzDevBuffers {
   std::vector<void*> retired;                             // buffers replaced by bigger ones during a call: freed when it ends
   bool decode_warmed = false;                             // the decode kernel's first (empty) launch has set the device's scratch up
   hipStream_t s_search = nullptr, s_gap = nullptr, s_decode[2] = {nullptr, nullptr};
-  hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr}, ev_found[4] = {nullptr, nullptr, nullptr, nullptr}, ev_dec[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
+  hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr}, ev_found[4] = {nullptr, nullptr, nullptr, nullptr}, ev_dec[3] = {nullptr, nullptr, nullptr}, ev_post[3] = {nullptr, nullptr, nullptr};
   uint8_t* d_search[4] = {nullptr, nullptr, nullptr, nullptr};       // from | found of a batch's block-start search (slices of the tables)
   uint8_t* h_search[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t held() const {
     uint64_t t = out.cap + win.cap + maps.cap + gwin.cap + crc.cap + wcarry_cap + tables_cap;
     for (int b = 0; b < 4; ++b) t += comp[b].cap;
-    for (int b = 0; b < 2; ++b) t += slot[b].sym.bytes();
+    for (int b = 0; b < 3; ++b) t += slot[b].sym.bytes();
     return t;
   }
 };

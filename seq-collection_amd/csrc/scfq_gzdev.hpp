@@ -78,14 +78,16 @@ inline void gz_free(GzDevBuffers* g) {
     g->ev_copy[b] = g->ev_found[b] = nullptr;
     g->d_search[b] = g->h_search[b] = nullptr;
   }
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < 3; ++b) {
     g->slot[b].sym.release();
     g->slot[b].d_meta = g->slot[b].h_meta = nullptr;
     g->d_pmeta[b] = g->h_pmeta[b] = nullptr;
     if (g->ev_dec[b]) (void)hipEventDestroy(g->ev_dec[b]);
     if (g->ev_post[b]) (void)hipEventDestroy(g->ev_post[b]);
-    if (g->s_decode[b]) (void)hipStreamDestroy(g->s_decode[b]);
     g->ev_dec[b] = g->ev_post[b] = nullptr;
+  }
+  for (int b = 0; b < 2; ++b) {
+    if (g->s_decode[b]) (void)hipStreamDestroy(g->s_decode[b]);
     g->s_decode[b] = nullptr;
   }
   if (g->d_tables) (void)hipFree(g->d_tables);
@@ -141,10 +143,16 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
     if (!g.ev_found[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_found[b], hipEventDisableTiming));
   }
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < 3; ++b) {
     if (!g.ev_dec[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_dec[b], hipEventDisableTiming));
     if (!g.ev_post[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_post[b], hipEventDisableTiming));
   }
+  // Two sets of symbols (SCFQ_GZ_DEVICE_SLOTS=3: three).  With two, the decode of batch k + 1 waits for the resolve of batch k - 1, whose
+  // window kernels need 76 KiB of LDS on a CU that decode workgroups still hold (7 - 10 ms): the decode kernels run one after the other
+  // (profiles/r03/gz_timeline.txt).  A third set lets batch k + 1 start behind batch k at once — measured: 157.6 ms against 157.3 for the
+  // 10 GB file with 15.8 instead of 11.5 GB held: the decode kernels overlap, their sum grows from 140 to 185 ms, the call does not get
+  // shorter.  The device is busy either way.
+  static const uint32_t n_slots = env_int("SCFQ_GZ_DEVICE_SLOTS", 2) == 3 ? 3u : 2u;
 
   // ---- plan ----------------------------------------------------------------------------------------------------------------
   const uint64_t data0 = (uint64_t)h0;
@@ -312,7 +320,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   if ((rc = gz_buf(g, g.win, (uint64_t)kGzWindow * max_seg)) || (rc = gz_buf(g, g.crc, res_crc))) return rc;
   {
     // the tables of both slots: ONE device and ONE pinned allocation (a pinned allocation costs milliseconds whatever its size)
-    const uint32_t ns = std::min(nb, 2u), nq = std::min(nb, 4u);
+    const uint32_t ns = std::min(nb, n_slots), nq = std::min(nb, 4u);
     const uint64_t per = ((slot_meta + post_meta + 255) & ~255ull), crc_room = (res_crc + 255) & ~255ull;
     const uint64_t t0 = g.tables_cap;
     if ((rc = gz_grow(&g.d_tables, &g.tables_cap, per * ns + search_meta * nq)) || (rc = gz_grow(&g.h_tables, &g.htables_cap, per * ns + search_meta * nq + crc_room, true))) return rc;
@@ -497,7 +505,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
 
   // ---- stage B(k): the segments of batch k (its last one stops at the first start of batch k + 1), decode ---------------------
   auto stage_b = [&](uint32_t k) -> int {
-    GzSlot& sl = g.slot[k & 1];
+    GzSlot& sl = g.slot[k % n_slots];
     const uint64_t* h_found = reinterpret_cast<const uint64_t*>(g.h_search[k % 4] + off_found);
     GzSeg* h_segs = reinterpret_cast<GzSeg*>(sl.h_meta + off_segs);
     const uint32_t np = (uint32_t)(p1_of(k) - p0_of(k));
@@ -533,7 +541,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     pool_used_of[k] = pool_used;
     hipStream_t sd = s_dec[k & 1];
     if (warm.th.joinable()) warm.th.join();
-    if (k >= 2) HIPCHK(hipStreamWaitEvent(sd, g.ev_post[k & 1], 0));      // the slot's symbols were read by batch k - 2's resolve
+    if (k >= n_slots) HIPCHK(hipStreamWaitEvent(sd, g.ev_post[k % n_slots], 0));      // the slot's symbols were read by the resolve of the batch that had it before
     HIPCHK(hipStreamWaitEvent(sd, g.ev_copy[k % 4], 0));
     if (n_seg) {
       const uint8_t* vbase = g.comp[k % 4].p - byte0_of(k);
@@ -546,19 +554,19 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       HIPCHK(hipMemcpyAsync(sl.h_meta + off_outs, sl.d_meta + off_outs, sizeof(GzSegOut) * n_seg, hipMemcpyDeviceToHost, sd));
       span_end(sp_decode, sd);
     }
-    HIPCHK(hipEventRecord(g.ev_dec[k & 1], sd));
+    HIPCHK(hipEventRecord(g.ev_dec[k % n_slots], sd));
     n_decoded_total += n_seg;
     return SCFQ_OK;
   };
 
   // ---- stage C(k): walk, windows, bytes, CRC tiles, scan -----------------------------------------------------------------------
   auto stage_c = [&](uint32_t k) -> int {
-    GzSlot& sl = g.slot[k & 1];
-    const int pp = (int)(k & 1);
+    GzSlot& sl = g.slot[k % n_slots];
+    const int pp = (int)(k % n_slots);
     GzSeg* h_segs = reinterpret_cast<GzSeg*>(sl.h_meta + off_segs);
     GzSegOut* h_outs = reinterpret_cast<GzSegOut*>(sl.h_meta + off_outs);
     { auto t0 = clk::now(); HIPCHK(hipEventSynchronize(g.ev_dec[pp])); h_dec_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
-    if (k >= 2) { auto t0 = clk::now(); HIPCHK(hipEventSynchronize(g.ev_post[pp])); h_post_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }      // h_pmeta[pp] / d_pmeta[pp] were batch k - 2's
+    if (k >= n_slots) { auto t0 = clk::now(); HIPCHK(hipEventSynchronize(g.ev_post[pp])); h_post_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }      // h_pmeta[pp] / d_pmeta[pp] were batch k - 2's
     // (SCFQ_GZ_DEVICE_TEST_REST_AT=k: batch k declares itself out of room — the tests of the hand-over to the host's decoder)
     static const int test_rest_at = env_int("SCFQ_GZ_DEVICE_TEST_REST_AT", -1);
     if (test_rest_at >= 0 && k == (uint32_t)test_rest_at) { why = "SCFQ_GZ_DEVICE_TEST_REST_AT"; return gz_decline(__LINE__, kFallbackRest); }
