@@ -95,26 +95,8 @@ os.environ["SCFQ_NO_BGZF"] = "1"
 t = time.time(); c = scfq.count_file(bgz, flags=scfq.SCFQ_TIMING); dt = time.time() - t
 check(c)
 row("same BGZF file through serial gzread (SCFQ_NO_BGZF=1)", inflated_bytes=data.size, wall_s=round(dt, 3), inflated_GBps=round(data.size / dt / 1e9, 3))
-# many files: sequential (the reference's loop, sc.nim:115-116) vs --jobs=8 (8 sessions sharing the GPU)
-import subprocess
-sc = os.path.join(ROOT, "seq-collection_amd", "sc")
+# (many files by --jobs: scripts/measure_jobs.py — the settings in shuffled order, a second apart: processes that follow one another
+# closely wait for the driver's wipe of what the one before freed, which hit whichever setting came later in a fixed order)
 many = []
-for i in range(8):
-    p = os.path.join(tmp, "scfq_many_%d.fq.gz" % i)
-    with open(p, "wb") as f:
-        for k in range(4): f.write(blobs_gz[(4 * i + k) % len(blobs_gz)])
-    many.append(p)
-want_rows = None
-for jobs in (1, 2, 4, 8, 0):
-    arg = ["--jobs=%d" % jobs] if jobs else []
-    best = None
-    for rep in range(3):
-        t = time.time(); r = subprocess.run([sc, "fq-count"] + arg + many, capture_output=True, text=True); dt = time.time() - t
-        assert r.returncode == 0 and len(r.stdout.splitlines()) == 8, r.stderr
-        if want_rows is None: want_rows = r.stdout
-        assert r.stdout == want_rows, "rows differ from --jobs=1 (argv order, sc.nim:115-116)"
-        best = dt if best is None else min(best, dt)
-    row("8 gzip files (256 MiB inflated each), sc fq-count %s (process start included, best of 3)" % (arg[0] if arg else "(default: two files in flight)"),
-        wall_s=round(best, 3), inflated_GBps=round(8 * 4 * (64 << 20) / best / 1e9, 3))
 for p in [plain, gz1, gzm, bgz] + many:
     os.remove(p)
