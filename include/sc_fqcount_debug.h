@@ -22,6 +22,10 @@ int  scfq_debug_partial_simple(const void* device_ptr, uint64_t n, int prev_byte
 /* Diagnostic only: the byte stream scfq_count_file() would scan for `path` (plain pread, BGZF block-parallel
  * inflate, or serial gzread), produced on the host without any device. Returns bytes written or a negative code. */
 int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk_bytes);
+/* host only: the same bytes with the first member read in two halves — the serial decoder up to the first block boundary at or after
+ * `after_bytes` of output, then the decoder that takes a stream over in the middle of a member (exact bit, window, CRC-32 and length
+ * so far): the hand-over of the device gzip path when a batch has no room */
+int64_t scfq_debug_gz_resume(const char* path, uint64_t after_bytes, void* dst, uint64_t cap, uint64_t chunk_bytes);
 /* Diagnostic only: inflate a whole BGZF image (host memory) with the device-side inflate kernel, result to host memory.
  * Returns the inflated size, SCFQ_EARG when the image is not pure BGZF or does not fit into cap, SCFQ_EGZ for a corrupt
  * member (deflate data, ISIZE or CRC-32). */

@@ -7,7 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 make -C $R/oracle asan >/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -shared \
   -o /tmp/libsc_fqcount_hip_asan.so $R/seq-collection_amd/csrc/scfq_api.hip $R/seq-collection_amd/csrc/scfq_host.cpp \
-  $R/seq-collection_amd/csrc/scfq_synth.hip $R/seq-collection_amd/csrc/scfq_dedup.hip $R/seq-collection_amd/csrc/scfq_meta.cpp -lz -lpthread
+  $R/seq-collection_amd/csrc/scfq_synth.hip $R/seq-collection_amd/csrc/scfq_dedup.hip $R/seq-collection_amd/csrc/scfq_meta.cpp $R/seq-collection_amd/csrc/scfq_comm.cpp -lz -lpthread -ldl
 ASAN=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cd $R
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 SCFQ_LIB_OVERRIDE=/tmp/libsc_fqcount_hip_asan.so \

@@ -1805,6 +1805,60 @@ static int index_lines_two_pass(Ctx* c, const uint8_t* base, uint64_t n, uint64_
 // ---- diagnostic: run the host-side source selection (plain pread / BGZF parallel inflate / serial gzread) of
 // scfq_count_file without any device, writing the byte stream the scan would see into dst. Returns the byte
 // count, or a negative SCFQ_* code; SCFQ_EARG when the stream is longer than cap.
+// Test hook (host only, no device): the inflated bytes of a gzip file whose FIRST member is read in two halves — the serial decoder up to the
+// first block boundary at or after `after_bytes` of output, then scfq_gzfast::Resume from that exact bit with the window, CRC-32 and
+// length of the first half: the hand-over the device gzip path makes when a batch has no room (scfq_gzdev.hpp), without a device.
+// Returns the number of bytes written to dst (the whole stream as gzread yields it), SCFQ_EGZ on a corrupt stream.
+int64_t scfq_debug_gz_resume(const char* path, uint64_t after_bytes, void* dst, uint64_t cap, uint64_t chunk) {
+  if (!path || (!dst && cap)) return SCFQ_EARG;
+  if (chunk < (1u << 16)) chunk = 1u << 20;
+  const int fd = open(path, O_RDONLY);
+  struct stat sb;
+  if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) { if (fd >= 0) close(fd); return SCFQ_EOPEN; }
+  const size_t n = (size_t)sb.st_size;
+  void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return SCFQ_EIO;
+  struct Unmap { void* m; size_t n; ~Unmap() { munmap(m, n); } } um{m, n};
+  const uint8_t* img = static_cast<const uint8_t*>(m);
+  const long h0 = scfq_gzfast::member_header(img, n);
+  if (h0 <= 0) return SCFQ_EGZ;
+  // first half: the serial decoder over the first member, logging every block header (bit, bytes before it)
+  uint8_t* out = static_cast<uint8_t*>(dst);
+  std::vector<uint64_t> log(2 * 65536);
+  auto dec = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
+  dec->begin(img, img + n);
+  dec->in_next = img + h0;
+  dec->boundary_log = log.data();
+  dec->boundary_cap = log.size() / 2;
+  std::vector<uint8_t> tmp(cap + scfq_inflate::kOutSlack + 64);
+  uint8_t* o = tmp.data();
+  const int r = dec->run(o, tmp.data() + cap);
+  if (r < 0 && r != scfq_inflate::kErrTruncated) { /* a damaged first member may still have boundaries in front of the damage */ }
+  uint64_t bit = 0, before = 0;
+  bool have = false;
+  for (size_t k = 0; k < dec->boundary_n; ++k)
+    if (log[2 * k + 1] >= after_bytes || k + 1 == dec->boundary_n) { bit = log[2 * k]; before = log[2 * k + 1]; have = true; break; }
+  if (!have || before > cap) return SCFQ_EGZ;
+  std::memcpy(out, tmp.data(), (size_t)before);
+  std::vector<uint8_t> window(scfq_gzfast::kWindow, 0);
+  const uint32_t valid = (uint32_t)std::min<uint64_t>(before, scfq_gzfast::kWindow);
+  std::memcpy(window.data() + scfq_gzfast::kWindow - valid, out + before - valid, valid);
+  scfq_gzfast::Resume rs;
+  rs.open(img, n, bit, window.data(), valid, scfq_crc::crc32(0u, out, (size_t)before), before);
+  uint64_t total = before;
+  std::vector<uint8_t> buf(chunk);
+  for (;;) {
+    const int64_t got = rs.next_chunk(buf.data(), chunk);
+    if (got < 0) return SCFQ_EGZ;
+    if (got == 0) break;
+    if (total + (uint64_t)got > cap) return SCFQ_EARG;
+    std::memcpy(out + total, buf.data(), (size_t)got);
+    total += (uint64_t)got;
+  }
+  return (int64_t)total;
+}
+
 int64_t scfq_debug_read_file(const char* path, void* dst, uint64_t cap, uint64_t chunk) {
   if (!path || (!dst && cap)) return SCFQ_EARG;
   if (chunk == 0) chunk = kDefaultChunk;

@@ -49,6 +49,9 @@ struct Decoder {
   uint32_t lit[kLitSize];
   uint32_t dist[kDistSize];
 
+  // (tests: every block header's bit position and the bytes produced before it, as pairs — scfq_debug_gz_resume cuts a stream there)
+  uint64_t* boundary_log = nullptr;
+  size_t boundary_cap = 0, boundary_n = 0;
   const uint8_t* in_base = nullptr;   // bit positions are counted from here
   uint64_t stop_bit = ~0ull;          // run16: return kAtBoundary at the first block boundary at or after this bit
 
@@ -208,6 +211,7 @@ struct Decoder {
     for (;;) {
       if (state == kDone) return kStreamEnd;
       if (state == kHeader) {
+        if (boundary_log && boundary_n < boundary_cap) { boundary_log[2 * boundary_n] = bitpos(); boundary_log[2 * boundary_n + 1] = total_out; ++boundary_n; }
         refill();
         if (bitcnt < 3) return kErrTruncated;
         last_block = peek(1); drop(1);

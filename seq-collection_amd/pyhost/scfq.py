@@ -33,7 +33,7 @@ EXPORTS = [
     "scfq_partial_combine", "scfq_partial_finalize", "scfq_format_tsv", "scfq_strerror",
     "scfq_last_error_detail", "scfq_last_timing", "scfq_device_bytes_now", "scfq_device_bytes_high_water", "scfq_device_count", "scfq_shutdown",
     "scfq_debug_partial_simple", "scfq_synth_plan", "scfq_synth_host", "scfq_synth_device", "scfq_synth_locate",
-    "scfq_debug_read_file", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
+    "scfq_debug_read_file", "scfq_debug_gz_resume", "scfq_debug_stream_ms", "scfq_debug_hist_stats",
     "scfq_index_lines", "scfq_dedup_buffer", "scfq_dedup_file", "scfq_dedup_error_detail", "scfq_stage_file",
     "scfq_device_free", "scfq_meta_header", "scfq_meta_file_tsv", "scfq_debug_bgzf_inflate",
     "scfq_set_wait_stream", "scfq_get_wait_stream", "scfq_count_file_sharded",
@@ -129,6 +129,8 @@ def lib():
                                          ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(SynthInfo)]
         L.scfq_debug_read_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.scfq_debug_read_file.restype = ctypes.c_int64
+        L.scfq_debug_gz_resume.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        L.scfq_debug_gz_resume.restype = ctypes.c_int64
         L.scfq_dedup_buffer.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
                                         ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(DedupStats)]
         L.scfq_dedup_file.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(DedupStats)]
@@ -425,6 +427,15 @@ def partial_simple_device(dev_ptr, n, prev_byte=-1):
     _check(lib().scfq_debug_partial_simple(ctypes.c_void_p(dev_ptr), n, prev_byte, ctypes.byref(p)),
            "scfq_debug_partial_simple")
     return p
+
+
+def debug_gz_resume(path, after_bytes, cap, chunk_bytes=0):
+    """host only: a gzip file's bytes with the first member read in two halves (serial decoder, then the mid-member take-over)"""
+    buf = ctypes.create_string_buffer(max(cap, 1))
+    n = lib().scfq_debug_gz_resume(os.fsencode(path), after_bytes, buf, cap, chunk_bytes)
+    if n < 0:
+        raise ScfqError(int(n), "scfq_debug_gz_resume", lib().scfq_last_error_detail().decode())
+    return buf.raw[:n]
 
 
 def debug_read_file(path, cap, chunk_bytes=0):

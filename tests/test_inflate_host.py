@@ -265,3 +265,56 @@ def test_parallel_reader_hands_many_small_members_to_the_serial_reader(scfq, tmp
         assert read(scfq, tmp_path, blob, len(data) + 16, 1 << 20) == data
         assert read(scfq, tmp_path, big_then_small, len(data) + 16, 1 << 20) == data
         assert time.time() - t < 20
+
+
+def _gzm(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    co = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+    return co.compress(data) + co.flush()
+
+
+def test_take_over_in_the_middle_of_a_member(scfq, tmp_path):
+    """scfq_gzfast::Resume — the decoder the device gzip path hands the REST of a file to when a batch has no room: it starts at an
+    exact bit inside a member with the 32 KiB in front of it and the member's CRC-32 / length so far.  Here without a device: the
+    serial decoder reads the first member up to a block boundary, Resume the rest; the bytes must be zlib's whatever the cut, the
+    layout behind it and the state of the trailer."""
+    data = fastq_bytes(2_500_000, seed=91)
+    rng = np.random.default_rng(92)
+    cases = {
+        "one_member": _gzm(data, 6),
+        "level1": _gzm(data, 1),
+        "stored_and_fixed": _gzm(data[:900_000], 0) + _gzm(data[900_000:], 6, zlib.Z_FIXED),
+        "four_members_garbage": b"".join(_gzm(data[a:b], lvl) for (a, b), lvl in zip(((0, 700_001), (700_001, 700_040), (700_040, 1_900_000), (1_900_000, len(data))), (6, 9, 1, 6))) + b"\x00junk",
+        "empty_members": _gzm(data[:1_000_000]) + _gzm(b"") + _gzm(data[1_000_000:]) + _gzm(b""),
+        "random_bytes": _gzm(rng.integers(0, 256, 600_000, dtype=np.uint8).tobytes() + data[:400_000]),
+    }
+    for name, img in cases.items():
+        f = tmp_path / (name + ".fq.gz")
+        f.write_bytes(img)
+        want = gzip.decompress(img[:-5]) if name == "four_members_garbage" else gzip.decompress(img)
+        for after in (0, 1, 40_000, 333_333, len(want) // 2, len(want) - 10, 10 * len(want)):
+            for chunk in (1 << 16, 1 << 20):
+                got = scfq.debug_gz_resume(str(f), after, len(want) + 16, chunk)
+                assert got == want, (name, after, chunk, len(got), len(want))
+    # damage behind the cut: the take-over rejects what zlib rejects (trailer bits, a flipped bit in the data, a cut file)
+    img = bytearray(cases["one_member"])
+    bad = {"crc": bytes(img[:-6]) + bytes([img[-6] ^ 0x40]) + bytes(img[-5:]), "isize": bytes(img[:-2]) + bytes([img[-2] ^ 1]) + bytes(img[-1:]),
+           "cut": bytes(img[: len(img) * 3 // 4]), "no_trailer": bytes(img[:-8])}
+    flip = bytearray(img)
+    flip[len(flip) * 2 // 3] ^= 0x10
+    bad["flip"] = bytes(flip)
+    for name, raw in bad.items():
+        f = tmp_path / (name + ".fq.gz")
+        f.write_bytes(raw)
+        try:
+            gzip.decompress(raw)
+            zlib_ok = True
+        except Exception:      # noqa: BLE001
+            zlib_ok = False
+        for after in (0, 100_000):
+            try:
+                scfq.debug_gz_resume(str(f), after, len(data) + 16)
+                ok = True
+            except scfq.ScfqError as e:
+                assert e.rc == scfq.SCFQ_EGZ, (name, e)
+                ok = False
+            assert ok == zlib_ok, (name, after)
