@@ -612,9 +612,275 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
   stp->pf[0] = pf.x; stp->pf[1] = pf.y; stp->pf[2] = pf.z; stp->pf[3] = pf.w; stp->pf_sh = (a2 & 3u) << 3;
 }
 
+// ---- the symbol loop, boundary-first form -----------------------------------------------------------------------------------
+// symbol_loop_lanes decodes 64 bit positions completely (value, extra bits, distance) to find the 4-5 of them that hold symbols: 27
+// vector instructions per symbol, and vector issue is what bounds the kernel.  Here the two halves are apart:
+//  A. rounds over 64 bit positions that only find out HOW LONG the code at every position is (one gather per table, first level only:
+//     ~25 vector instructions); the scalar unit follows the chain as before and the positions of the chain's symbols are collected
+//     in LDS, one after the other, over as many rounds as it takes to have 64 of them;
+//  B. then lane k decodes symbol k completely (the same arithmetic as step 1 of symbol_loop_lanes, now with every lane on a real
+//     symbol), one scan gives every symbol's place in the output, and the output goes out in chunks of 64 symbols: every lane finds the
+//     symbol it belongs to, and is a literal or one load `distance` back.
+// A code that needs the second table level, a length code whose distance code does, and the end-of-block code end part A early ("hard":
+// 1-2 % of the symbols): the position is collected as the group's last, part B decodes it like any other and says where the chain goes on.
+// A match that reads output of its own group ends a SUB-GROUP in front of it: the stores of everything before are issued first (the
+// memory pipeline keeps a wave's accesses in order, as in symbol_loop_lanes); one that overlaps its own output is copied alone, with
+// its period.  The last store of a sub-group waits for its load only when the next sub-group begins.
+// LDS scratch (256 dwords: the table builder's work area): positions [0, 128), chunk owners [128, 192), symbol info [192, 256).
+template <bool SYM16>
+__device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const uint8_t* in_aligned, uint32_t in_off, uint32_t ip_end, void* out_base,
+                                                           uint32_t limit, uint32_t lit_lds, uint32_t dist_lds, uint32_t scratch_lds) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t in_u = ((uint64_t)uni((uint32_t)((uintptr_t)in_aligned >> 32)) << 32) | uni((uint32_t)(uintptr_t)in_aligned);
+  const uint64_t out_u = ((uint64_t)uni((uint32_t)((uintptr_t)out_base >> 32)) << 32) | uni((uint32_t)(uintptr_t)out_base);
+  const_byte_t* const in4 = (const_byte_t*)in_u;
+  out_base = (void*)out_u;
+  in_off = uni(in_off);
+  ip_end = uni(ip_end);
+  limit = uni(limit);
+  uint32_t pos = uni(stp->pos), err = kOk;
+  const uint64_t bit0 = (uint64_t)uni(stp->ip) * 8u - uni(stp->bc);   // the block's first symbol, in bits from in_aligned + in_off
+  uint32_t rel = 0;                                                   // the chain's position = bit0 + rel
+  const uint32_t b0 = (uint32_t)(bit0 >> 3), f0 = (uint32_t)bit0 & 7u;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_base, 0, (int)(limit * (SYM16 ? 2u : 1u)), 0x00020000);
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  typedef const uint32_t __attribute__((address_space(1))) glob_u32;
+  lds_u32* const litp = (lds_u32*)(uintptr_t)uni(lit_lds);
+  lds_u32* const distp = (lds_u32*)(uintptr_t)uni(dist_lds);
+  volatile lds_u32* const scr = (volatile lds_u32*)(uintptr_t)uni(scratch_lds);
+  constexpr uint32_t kP = 0u, kC = 128u, kI = 192u;
+  auto store_sym = [&](uint32_t v, uint32_t off) {
+    if (SYM16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, orsrc, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, orsrc, off, 0, 0);
+  };
+  auto load_sym = [&](uint32_t off) -> uint32_t {
+    if (SYM16) return __builtin_amdgcn_raw_buffer_load_b16(orsrc, off, 0, 1 /*sc0*/);
+    return __builtin_amdgcn_raw_buffer_load_b8(orsrc, off, 0, 1 /*sc0*/);
+  };
+  auto store_raw = [&](auto v, uint32_t off) {
+    if constexpr (SYM16) __builtin_amdgcn_raw_buffer_store_b16(v, orsrc, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b8(v, orsrc, off, 0, 0);
+  };
+  auto load_raw = [&](uint32_t off) {
+    if constexpr (SYM16) return __builtin_amdgcn_raw_buffer_load_b16(orsrc, off, 0, 1 /*sc0*/);
+    else return __builtin_amdgcn_raw_buffer_load_b8(orsrc, off, 0, 1 /*sc0*/);
+  };
+  constexpr uint32_t kSh = SYM16 ? 1u : 0u;
+  constexpr uint32_t kOob = 0xFFFFFFFFu;
+  const uint32_t sft = lane & 31u;
+  const bool upper = lane >= 32u;
+  const uint32_t le_lo = lane >= 31u ? 0xFFFFFFFFu : (2u << lane) - 1u;
+  const uint32_t le_hi = lane < 32u ? 0u : (lane == 63u ? 0xFFFFFFFFu : (2u << (lane - 32u)) - 1u);
+#define SCFQ_XBYTE(rel_) ((b0 + ((f0 + (rel_)) >> 3)) < ip_end ? (b0 + ((f0 + (rel_)) >> 3)) : ip_end)
+#define SCFQ_XLOAD(rel_) do { D = *(const_dword4_t*)(in4 + ((in_off + SCFQ_XBYTE(rel_)) & ~3u)); } while (0)
+  typedef typename std::conditional<SYM16, uint16_t, uint8_t>::type sym_t;
+  sym_t pend_ld = 0;
+  uint32_t pend_sel = 0, pend_off = kOob;
+#define SCFQ_XFLUSH() do { store_raw((pend_sel & 0x100u) ? (sym_t)(pend_sel & 0xFFu) : pend_ld, pend_off); pend_off = kOob; } while (0)
+  scr[kP + lane] = 0u;                                 // (positions nobody has collected yet are read by the lanes beyond a group's end)
+  scr[kP + 64u + lane] = 0u;
+  uint32_t n_sym = 0;                                  // positions collected and not yet decoded
+  uint32_t endk = 0;                                   // 1: the chain has ended (end of block: rel is behind its code); 2: the last position collected is a hard one
+  uint32_t stop = 0;
+  dword4_t D;
+  SCFQ_XLOAD(rel);
+  do {
+    // ---- A. lengths only, until 64 symbols are known -----------------------------------------------------------------------------
+    while (n_sym < 64u && endk == 0u) {
+      const uint32_t sh = (((in_off + SCFQ_XBYTE(rel)) & 3u) << 3) | ((f0 + rel) & 7u);
+      const uint32_t W0 = (uint32_t)((((uint64_t)D.y << 32) | D.x) >> sh), W1 = (uint32_t)((((uint64_t)D.z << 32) | D.y) >> sh),
+                     W2 = (uint32_t)((((uint64_t)D.w << 32) | D.z) >> sh);
+      const uint32_t wa = upper ? W1 : W0, wb = upper ? W2 : W1;
+      const uint32_t x0 = __builtin_amdgcn_alignbit(wb, wa, sft);                    // 32 bits from bit `lane` on: 10 + 5 + 8 of them are looked at
+      const uint32_t e1 = litp[x0 & ((1u << kLitRoot) - 1u)];
+      const uint32_t n1 = e1 & 15u, lx = (e1 >> 4) & 15u;
+      const bool islen = (e1 & kVal) != 0u;
+      const uint32_t d1 = distp[(x0 >> (n1 + lx)) & ((1u << kDistRoot) - 1u)];
+      const bool dval = (d1 & kVal) != 0u;
+      const uint32_t tot = islen ? n1 + lx + (d1 & 15u) + ((d1 >> 4) & 15u) : n1;    // (< 64 whatever the entries hold)
+      // a literal, or a length code with a distance code of the first level: the chain steps over it.  Anything else ends the round's chain:
+      // 0x200 a hard one (second level, or a distance entry that is not a distance), 0x400 the end-of-block code, neither: not assigned
+      const bool go = ((e1 & kLit) != 0u) | (islen & dval);
+      const bool hard = ((e1 & kSub) != 0u) | (islen & !dval);
+      const uint32_t A = (lane + tot) | (go ? 0u : 0x100u) | (hard ? 0x200u : 0u) | ((e1 & kEob) ? 0x400u : 0u);
+      uint32_t cur, a;
+      uint64_t chain;
+      asm volatile(
+          "s_mov_b32 %[cur], 0\n\t"
+          "s_mov_b64 %[chain], 0\n"
+          "1:\n\t"
+          "v_readlane_b32 %[a], %[A], %[cur]\n\t"
+          "s_bitcmp1_b32 %[a], 8\n\t"
+          "s_cbranch_scc1 2f\n\t"
+          "s_bitset1_b64 %[chain], %[cur]\n\t"
+          "s_and_b32 %[cur], %[a], 0x7f\n\t"
+          "s_cmp_lt_u32 %[cur], 64\n\t"
+          "s_cbranch_scc1 1b\n"
+          "2:\n"
+          : [cur] "=&s"(cur), [a] "=&s"(a), [chain] "=&s"(chain)
+          : [A] "v"(A)
+          : "scc");
+      uint32_t nxt = rel + cur;
+      if (a & 0x100u) {
+        if (a & 0x200u) { chain |= 1ull << cur; endk = 2u; nxt = rel; }
+        else { endk = 1u; nxt = rel + (a & 127u); if (!(a & 0x400u)) err = kErrData; }
+      }
+      const bool on = ((chain >> lane) & 1ull) != 0ull;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chain, 0u));
+      scr[on ? kP + n_sym + rank : kC] = rel + lane;                                  // (kC: a word nobody reads in part A)
+      n_sym += (uint32_t)__builtin_popcountll(chain);
+      rel = nxt;
+      if (endk == 0u) {
+        SCFQ_XLOAD(rel);
+        // a malformed stream reading (clamped) bytes far past the end of the data: over (the caller sees the position); a block of 256 MiB: not here
+        if ((ip_end + 16u - (b0 + ((f0 + rel) >> 3))) >> 31) endk = 1u;
+        if ((0x7FFFFFFFu - rel) >> 31) { endk = 1u; err = kErrData; }
+      }
+    }
+    // ---- B. lane k: symbol k ----------------------------------------------------------------------------------------------------
+    const uint32_t m = n_sym < 64u ? n_sym : 64u;
+    if (m != 0u && err == kOk) {
+      __builtin_amdgcn_wave_barrier();
+      const bool valid = lane < m;
+      const uint32_t p = scr[kP + lane];
+      const uint32_t q = f0 + p;
+      const uint32_t by = b0 + (q >> 3);
+      const uint32_t a_ = in_off + (by < ip_end ? by : ip_end);
+      glob_u32* const w = (glob_u32*)(in_u + (a_ & ~3u));
+      const uint32_t g0 = w[0], g1 = w[1], g2 = w[2];
+      const uint32_t sh = ((a_ & 3u) << 3) | (q & 7u);
+      const uint32_t x0 = __builtin_amdgcn_alignbit(g1, g0, sh), x1 = __builtin_amdgcn_alignbit(g2, g1, sh);      // 64 bits from the symbol's first
+      const uint32_t e1 = litp[x0 & ((1u << kLitRoot) - 1u)];
+      const bool sub = (e1 & kSub) != 0u;
+      const uint32_t i2 = sub ? (e1 >> 16) + __builtin_amdgcn_ubfe(x0, kLitRoot, (e1 >> 4) & 15u) : 0u;
+      const uint32_t e2 = litp[i2];
+      const uint32_t ef = sub ? e2 : e1;
+      const uint32_t n1 = sub ? (uint32_t)kLitRoot + (e2 & 15u) : (e1 & 15u);
+      const uint32_t y0 = __builtin_amdgcn_alignbit(x1, x0, n1), y1 = x1 >> n1;
+      const uint32_t lx = (ef >> 4) & 15u;
+      const uint32_t mlen = (ef >> 16) + __builtin_amdgcn_ubfe(y0, 0, lx);
+      const uint32_t z0 = __builtin_amdgcn_alignbit(y1, y0, lx);
+      const uint32_t d1 = distp[z0 & ((1u << kDistRoot) - 1u)];
+      const bool dsub = (d1 & kSub) != 0u;
+      const uint32_t j2 = dsub ? (d1 >> 16) + __builtin_amdgcn_ubfe(z0, kDistRoot, (d1 >> 4) & 15u) : 0u;
+      const uint32_t d2 = distp[j2];
+      const uint32_t df = dsub ? d2 : d1;
+      const uint32_t dn = dsub ? (uint32_t)kDistRoot + (d2 & 15u) : (d1 & 15u);
+      const uint32_t dx = (df >> 4) & 15u;
+      const uint32_t moff = (df >> 16) + __builtin_amdgcn_ubfe(z0 >> dn, 0, dx);
+      const uint32_t kind = (ef & kLit) ? 0u : ((ef & kVal) ? 1u : ((ef & kEob) ? 2u : 3u));
+      const uint32_t tot = kind == 1u ? n1 + lx + dn + dx : n1;
+      const uint32_t B = (df & kVal) ? moff : 0u;
+      const uint32_t len = valid ? (kind == 0u ? 1u : (kind == 1u ? mlen : 0u)) : 0u;
+      const uint32_t incl = dscan(len);
+      const uint32_t st = incl - len;                    // the symbol's place in the group's output
+      const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const bool tail = (endk == 2u) & (n_sym <= 64u);   // the group's last symbol is the hard one
+      // a code that is not assigned; a distance that is not one, or reaches back further than there is output; an end-of-block code anywhere
+      // but behind a hard position
+      const bool bad = valid & ((kind == 3u) | ((kind == 1u) & (B - 1u >= pos + st)) | ((kind == 2u) & !(tail & (lane == m - 1u))));
+      if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+        err = kErrData;
+      } else {
+        scr[kI + lane] = kind == 1u ? B : 0x80000000u | ((ef >> 16) & 0xFFu);
+        uint32_t k0 = 0, s0 = 0;
+        while (k0 < m) {
+          // the first symbol from k0 on that reads what the sub-group starting at k0 puts out
+          const uint64_t cutm = __builtin_amdgcn_ballot_w64(valid & (lane >= k0) & (kind == 1u) & (B < st + len - s0));
+          const uint32_t kc = cutm ? (uint32_t)__builtin_ctzll(cutm) : m;
+          if (kc == k0) {
+            // it is the first itself: a match that overlaps its own output (distance < length), period `off`
+            const uint32_t mlen_s = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)k0);
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)B, (int)k0);
+            SCFQ_XFLUSH();
+            const uint32_t dst0 = pos + s0, src0 = dst0 - off;
+            for (uint32_t base = 0; base < mlen_s; base += 64) {
+              const uint32_t k = base + lane;
+              const uint32_t j = off == 1u ? 0u : k % off;
+              const uint32_t v = load_sym((src0 + j) << kSh);
+              store_sym(v, k < mlen_s ? (dst0 + k) << kSh : kOob);
+            }
+            k0 += 1u;
+            s0 += mlen_s;
+          } else {
+            const uint32_t s1 = kc < m ? (uint32_t)__builtin_amdgcn_readlane((int)st, (int)kc) : R;
+            uint32_t carry = k0;
+            uint32_t first = 1;
+            for (uint32_t base = s0; base < s1; base += 64u) {
+              // every lane is one output symbol: its owner is the symbol with the highest start at or below it
+              scr[kC + lane] = 0u;
+              __builtin_amdgcn_wave_barrier();
+              if (valid & (lane - k0 < kc - k0) & (st - base < 64u) & (len != 0u)) scr[kC + (st - base)] = lane + 1u;
+              __builtin_amdgcn_wave_barrier();
+              const uint64_t starts = __builtin_amdgcn_ballot_w64(scr[kC + lane] != 0u);
+              const uint32_t m_lo = (uint32_t)starts & le_lo, m_hi = (uint32_t)(starts >> 32) & le_hi;
+              const uint32_t s = m_hi ? 63u - (uint32_t)__builtin_clz(m_hi) : 31u - (uint32_t)__builtin_clz(m_lo | 1u);
+              const uint32_t oc = scr[kC + s];
+              const uint32_t own = (m_lo | m_hi) ? oc - 1u : carry;
+              const uint32_t inf = scr[kI + own];
+              const bool act = base + lane < s1;
+              const bool is_match = (inf >> 31) == 0u;
+              if (first) SCFQ_XFLUSH();                  // what the sub-group before put out is what this one may read
+              const sym_t ld = load_raw((act && is_match) ? (pos + base + lane - inf) << kSh : kOob);
+              if (!first) SCFQ_XFLUSH();                 // (the chunk before: its load is older than the one just issued)
+              pend_ld = ld;
+              pend_sel = is_match ? 0u : 0x100u | (inf & 0xFFu);
+              pend_off = act ? (pos + base + lane) << kSh : kOob;
+              carry = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
+              first = 0;
+            }
+            k0 = kc;
+            s0 = s1;
+          }
+        }
+        pos += R;
+        if (n_sym <= 64u && endk == 2u) {
+          // the hard symbol has been decoded: the chain goes on behind it, or the block ends with it
+          const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)kind, (int)(m - 1u));
+          rel = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)(m - 1u)) + (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)(m - 1u));
+          if (kl == 2u) stop = 1;
+          endk = 0u;
+          SCFQ_XLOAD(rel);
+          if ((ip_end + 16u - (b0 + ((f0 + rel) >> 3))) >> 31) stop = 1;
+          if ((0x7FFFFFFFu - rel) >> 31) err = kErrData;
+        }
+      }
+    }
+    if (n_sym > 64u) {
+      const uint32_t v = scr[kP + 64u + lane];
+      __builtin_amdgcn_wave_barrier();
+      scr[kP + lane] = v;
+      n_sym -= 64u;
+    } else {
+      n_sym = 0u;
+      if (endk == 1u) stop = 1;
+    }
+    stop |= err != kOk ? 1u : 0u;
+    stop |= (limit - pos) >> 31;                         // pos > limit: the descriptor dropped the excess
+  } while (!stop);
+  SCFQ_XFLUSH();
+#undef SCFQ_XFLUSH
+#undef SCFQ_XLOAD
+#undef SCFQ_XBYTE
+  // back to the byte-wise reader of the caller (as symbol_loop_lanes)
+  const uint64_t bit = bit0 + rel;
+  const uint32_t ipn = (uint32_t)((bit + 7u) >> 3);
+  const uint32_t bcn = (uint32_t)((uint64_t)ipn * 8u - bit);
+  uint32_t bbn = 0;
+  if (bcn) {
+    const uint32_t a_ = in_off + (ipn - 1u < ip_end ? ipn - 1u : ip_end);
+    const uint32_t dw = *(const_dword1_t*)(in4 + (a_ & ~3u));
+    bbn = ((dw >> ((a_ & 3u) << 3)) & 0xFFu) >> (8u - bcn);
+  }
+  const uint32_t a2 = in_off + (ipn < ip_end ? ipn : ip_end);
+  const dword4_t pf = *(const_dword4_t*)(in4 + (a2 & ~3u));
+  stp->bb = bbn; stp->bc = bcn; stp->ip = ipn; stp->pos = pos; stp->err = err;
+  stp->pf[0] = pf.x; stp->pf[1] = pf.y; stp->pf[2] = pf.z; stp->pf[3] = pf.w; stp->pf_sh = (a2 & 3u) << 3;
+}
+
 __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* __restrict__ comp, const Block* __restrict__ blocks,
                                                                 uint32_t n_blocks, uint8_t* out, uint32_t* status /* one word, OR of (1 << error) */,
-                                                                uint32_t serial_loop /* 1: the serial symbol loop (A/B measurements) */) {
+                                                                uint32_t serial_loop /* 0: symbol_loop_lanes, 1: symbol_loop (A/B measurements), 2: symbol_loop_dense */) {
   extern __shared__ uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -789,7 +1055,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
       SymState sst;
       sst.bb = bb; sst.bc = bc; sst.ip = ip; sst.pos = pos; sst.err = kOk;
       sst.pf[0] = pf.x; sst.pf[1] = pf.y; sst.pf[2] = pf.z; sst.pf[3] = pf.w; sst.pf_sh = pf_sh;
-      if (serial_loop) symbol_loop<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      if (serial_loop == 1u) symbol_loop<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      else if (serial_loop == 2u) symbol_loop_dense<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist, (uint32_t)(uintptr_t)lens);
       else symbol_loop_lanes<false>(&sst, comp + (blk.in_off & ~3u), blk.in_off & 3u, ip_end, o, isize, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist, (uint32_t)(uintptr_t)lens);
       // (every lane holds the same state in its private copy: read it back as wave-uniform values)
       bb = ((uint64_t)uni((uint32_t)(sst.bb >> 32)) << 32) | uni((uint32_t)sst.bb);

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint
       SymState sst;
       sst.bb = bb; sst.bc = bc; sst.ip = ip; sst.pos = pos; sst.err = kOk;
       sst.pf[0] = pf.x; sst.pf[1] = pf.y; sst.pf[2] = pf.z; sst.pf[3] = pf.w; sst.pf_sh = pf_sh;
-      if (serial_loop) symbol_loop<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      if (serial_loop == 1u) symbol_loop<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist);
+      else if (serial_loop == 2u) symbol_loop_dense<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist, (uint32_t)(uintptr_t)lens);
       else symbol_loop_lanes<true>(&sst, comp + (seg_byte & ~3ull), in_off, ip_end, o, cap_total, (uint32_t)(uintptr_t)lit, (uint32_t)(uintptr_t)dist, (uint32_t)(uintptr_t)lens);
       bb = ((uint64_t)uni((uint32_t)(sst.bb >> 32)) << 32) | uni((uint32_t)sst.bb);
       bc = uni(sst.bc); ip = uni(sst.ip); pos = uni(sst.pos);

@@ -677,9 +677,10 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
 
 // ---- BGZF with device-side inflate: the host only walks the member headers and moves COMPRESSED bytes ---------------
 constexpr uint32_t kMaxBlocksPerChunk = 1u << 18;
-// SCFQ_INFLATE_LOOP=serial: the device inflate kernels use the serial symbol loop (A/B measurements); default: the lane-parallel one
+// Which symbol loop the device inflate kernels run (bgzf_inflate_kernel.hpp): SCFQ_INFLATE_LOOP=lanes (0, the default), serial (1, A/B
+// measurements), dense (2, boundary-first)
 inline uint32_t inflate_serial_loop() {
-  static const uint32_t v = [] { const char* e = std::getenv("SCFQ_INFLATE_LOOP"); return (e && e[0] == 's') ? 1u : 0u; }();
+  static const uint32_t v = [] { const char* e = std::getenv("SCFQ_INFLATE_LOOP"); return !e ? 0u : (e[0] == 's' ? 1u : (e[0] == 'd' ? 2u : 0u)); }();
   return v;
 }
 constexpr int kFallbackToHost = 1;        // ingest_bgzf_device: could not set up, nothing queued
