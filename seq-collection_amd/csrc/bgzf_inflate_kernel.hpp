@@ -347,7 +347,7 @@ __device__ __attribute__((noinline)) void symbol_loop(SymState* stp, const uint8
 // inside the tables and no lane consumes more than 48 bits.  The next round's window is requested from the scalar cache as soon
 // as the chain has been followed.
 #ifdef SCFQ_LPROF      // measurement builds only (scripts/gpu_lanes_prof.sh): where a round's cycles go, summed over all waves
-__device__ unsigned long long g_lprof[16];
+__device__ unsigned long long g_lprof[24];
 #define SCFQ_LP_T(var_) const uint64_t var_ = __builtin_readcyclecounter()
 #define SCFQ_LP_ADD(slot_, v_) lp[slot_] += (v_)
 #else
@@ -667,12 +667,6 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
   };
   constexpr uint32_t kSh = SYM16 ? 1u : 0u;
   constexpr uint32_t kOob = 0xFFFFFFFFu;
-  const uint32_t sft = lane & 31u;
-  const bool upper = lane >= 32u;
-  const uint32_t le_lo = lane >= 31u ? 0xFFFFFFFFu : (2u << lane) - 1u;
-  const uint32_t le_hi = lane < 32u ? 0u : (lane == 63u ? 0xFFFFFFFFu : (2u << (lane - 32u)) - 1u);
-#define SCFQ_XBYTE(rel_) ((b0 + ((f0 + (rel_)) >> 3)) < ip_end ? (b0 + ((f0 + (rel_)) >> 3)) : ip_end)
-#define SCFQ_XLOAD(rel_) do { D = *(const_dword4_t*)(in4 + ((in_off + SCFQ_XBYTE(rel_)) & ~3u)); } while (0)
   typedef typename std::conditional<SYM16, uint16_t, uint8_t>::type sym_t;
   sym_t pend_ld = 0;
   uint32_t pend_sel = 0, pend_off = kOob;
@@ -682,65 +676,119 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
   uint32_t n_sym = 0;                                  // positions collected and not yet decoded
   uint32_t endk = 0;                                   // 1: the chain has ended (end of block: rel is behind its code); 2: the last position collected is a hard one
   uint32_t stop = 0;
-  dword4_t D;
-  SCFQ_XLOAD(rel);
+  const uint32_t scr_base = uni(scratch_lds);
+  const uint32_t in_last = (in_off + ip_end) & ~3u;     // the last dword a clamped read may start at (the callers' buffers have 20 bytes behind it)
+  uint32_t sv = 0, sv_rel = 0u - 4096u;                // (nothing loaded yet)
+#ifdef SCFQ_LPROF
+  uint64_t lp[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   do {
     // ---- A. lengths only, until 64 symbols are known -----------------------------------------------------------------------------
-    while (n_sym < 64u && endk == 0u) {
-      const uint32_t sh = (((in_off + SCFQ_XBYTE(rel)) & 3u) << 3) | ((f0 + rel) & 7u);
-      const uint32_t W0 = (uint32_t)((((uint64_t)D.y << 32) | D.x) >> sh), W1 = (uint32_t)((((uint64_t)D.z << 32) | D.y) >> sh),
-                     W2 = (uint32_t)((((uint64_t)D.w << 32) | D.z) >> sh);
-      const uint32_t wa = upper ? W1 : W0, wb = upper ? W2 : W1;
-      const uint32_t x0 = __builtin_amdgcn_alignbit(wb, wa, sft);                    // 32 bits from bit `lane` on: 10 + 5 + 8 of them are looked at
+    // The stream comes through a VECTOR register: lane i holds dword i of the 2048 bits from sv_rel's dword on, and every lane pulls the
+    // two dwords its position lies in with ds_bpermute — no scalar loads, shifts or waits per round (the scalar unit is what the CU's
+    // sixteen waves share, and it has the chain to follow).
+    if (n_sym < 64u && endk == 0u) do {
+      SCFQ_LP_T(t0);
+      uint32_t T = rel - sv_rel;                       // the chain's position inside sv, in bits
+      if (T >= 1900u) {
+        const uint64_t ab = bit0 + rel + 8u * in_off;  // in bits from in_aligned
+        const uint32_t dw = (uint32_t)(ab >> 5);
+        T = (uint32_t)ab & 31u;
+        sv_rel = rel - T;
+        const uint32_t ad = 4u * (dw + lane);
+        sv = *(glob_u32*)(in_u + (ad < in_last ? ad : in_last));
+      }
+      const uint32_t t = T + lane;
+      const uint32_t j4 = (t >> 3) & 0x1FCu;
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)j4, (int)sv), hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j4 + 4u), (int)sv);
+      const uint32_t x0 = __builtin_amdgcn_alignbit(hi, lo, t);                      // 32 bits from bit `lane` on: 10 + 5 + 8 of them are looked at
       const uint32_t e1 = litp[x0 & ((1u << kLitRoot) - 1u)];
-      const uint32_t n1 = e1 & 15u, lx = (e1 >> 4) & 15u;
-      const bool islen = (e1 & kVal) != 0u;
-      const uint32_t d1 = distp[(x0 >> (n1 + lx)) & ((1u << kDistRoot) - 1u)];
-      const bool dval = (d1 & kVal) != 0u;
-      const uint32_t tot = islen ? n1 + lx + (d1 & 15u) + ((d1 >> 4) & 15u) : n1;    // (< 64 whatever the entries hold)
-      // a literal, or a length code with a distance code of the first level: the chain steps over it.  Anything else ends the round's chain:
-      // 0x200 a hard one (second level, or a distance entry that is not a distance), 0x400 the end-of-block code, neither: not assigned
-      const bool go = ((e1 & kLit) != 0u) | (islen & dval);
-      const bool hard = ((e1 & kSub) != 0u) | (islen & !dval);
-      const uint32_t A = (lane + tot) | (go ? 0u : 0x100u) | (hard ? 0x200u : 0u) | ((e1 & kEob) ? 0x400u : 0u);
-      uint32_t cur, a;
+      const uint32_t s1 = (e1 & 15u) + ((e1 >> 4) & 15u);                            // code + extra bits (a literal's entry has no extra bits)
+      const uint32_t d1 = distp[__builtin_amdgcn_ubfe(x0, s1, kDistRoot)];
+      const uint32_t dd = ((d1 & 15u) + ((d1 >> 4) & 15u)) & (uint32_t)__builtin_amdgcn_sbfe(e1, 10, 1);     // (kVal is bit 10: a length code)
+      // a literal, or a length code with a distance code of the first level: the chain steps over it (to lane + bits, 123 at most).  Anything
+      // else ends the round's chain: 128
+      const bool go = ((((e1 << 2) | (e1 & d1)) & kVal) != 0u);
+      const uint32_t A = go ? lane + s1 + dd : 128u;
+#ifdef SCFQ_LPROF
+      asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(A) : "memory");
+#endif
+      SCFQ_LP_T(t1);
+      uint32_t cur;
       uint64_t chain;
+      // (two steps per pass with the registers swapped, so that no s_mov is needed; the lane select of v_readlane must not be a register a
+      // vector instruction has written within the last four instructions — nobody inserts wait states into inline assembly —: s_nop.
+      // Straight-line code of eight steps over a copy of A that ends at 64, with no branch per symbol, was slower: 346 against 300 cycles.)
+      uint32_t nx;
       asm volatile(
-          "s_mov_b32 %[cur], 0\n\t"
+          "s_mov_b32 %[nx], 0\n\t"
           "s_mov_b64 %[chain], 0\n"
           "1:\n\t"
-          "v_readlane_b32 %[a], %[A], %[cur]\n\t"
-          "s_bitcmp1_b32 %[a], 8\n\t"
-          "s_cbranch_scc1 2f\n\t"
-          "s_bitset1_b64 %[chain], %[cur]\n\t"
-          "s_and_b32 %[cur], %[a], 0x7f\n\t"
+          "v_readlane_b32 %[cur], %[A], %[nx]\n\t"
+          "s_bitset1_b64 %[chain], %[nx]\n\t"
           "s_cmp_lt_u32 %[cur], 64\n\t"
-          "s_cbranch_scc1 1b\n"
+          "s_cbranch_scc0 2f\n\t"
+          "s_nop 0\n\t"
+          "v_readlane_b32 %[nx], %[A], %[cur]\n\t"
+          "s_bitset1_b64 %[chain], %[cur]\n\t"
+          "s_cmp_lt_u32 %[nx], 64\n\t"
+          "s_nop 0\n\t"
+          "s_cbranch_scc1 1b\n\t"
+          "s_mov_b32 %[cur], %[nx]\n"
           "2:\n"
-          : [cur] "=&s"(cur), [a] "=&s"(a), [chain] "=&s"(chain)
+          : [cur] "=&s"(cur), [nx] "=&s"(nx), [chain] "=&s"(chain)
           : [A] "v"(A)
           : "scc");
+#ifdef SCFQ_LPROF
+      asm volatile("" : : "s"(chain), "s"(cur));
+#endif
+      SCFQ_LP_T(t2);
       uint32_t nxt = rel + cur;
-      if (a & 0x100u) {
-        if (a & 0x200u) { chain |= 1ull << cur; endk = 2u; nxt = rel; }
-        else { endk = 1u; nxt = rel + (a & 127u); if (!(a & 0x400u)) err = kErrData; }
+      if (cur >= 128u) {
+        // the chain has come to a lane it cannot step over (the last one it noted): what is there
+        const uint32_t sl = 63u - (uint32_t)__builtin_clzll(chain);
+        const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)e1, (int)sl), ds = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)sl);
+        nxt = rel;
+        if ((es & kSub) || ((es & kVal) && !(ds & kVal))) endk = 2u;                 // hard: collected, part B says what it is
+        else {
+          chain &= ~(1ull << sl);
+          endk = 1u;
+          nxt = rel + sl + (es & 15u);                                               // behind an end-of-block code
+          if (!(es & kEob)) err = kErrData;
+        }
       }
-      const bool on = ((chain >> lane) & 1ull) != 0ull;
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chain, 0u));
-      scr[on ? kP + n_sym + rank : kC] = rel + lane;                                  // (kC: a word nobody reads in part A)
+      {
+        // the chain's lanes note their positions behind those already collected (only they execute this: five vector instructions)
+        uint64_t save;
+        uint32_t t_, u_;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "s_mov_b64 exec, %[chain]\n\t"
+            "v_mbcnt_lo_u32_b32 %[t], %[clo], 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[t], %[chi], %[t]\n\t"
+            "v_lshl_add_u32 %[t], %[t], 2, %[base]\n\t"
+            "v_add_u32 %[u], %[rel], %[lane]\n\t"
+            "ds_write_b32 %[t], %[u]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [save] "=&s"(save), [t] "=&v"(t_), [u] "=&v"(u_)
+            : [chain] "s"(chain), [clo] "s"((uint32_t)chain), [chi] "s"((uint32_t)(chain >> 32)), [base] "s"(scr_base + 4u * (kP + n_sym)), [rel] "s"(rel), [lane] "v"(lane)
+            : "memory");
+      }
       n_sym += (uint32_t)__builtin_popcountll(chain);
       rel = nxt;
-      if (endk == 0u) {
-        SCFQ_XLOAD(rel);
-        // a malformed stream reading (clamped) bytes far past the end of the data: over (the caller sees the position); a block of 256 MiB: not here
-        if ((ip_end + 16u - (b0 + ((f0 + rel) >> 3))) >> 31) endk = 1u;
-        if ((0x7FFFFFFFu - rel) >> 31) { endk = 1u; err = kErrData; }
-      }
-    }
+#ifdef SCFQ_LPROF
+      { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); SCFQ_LP_T(t3); SCFQ_LP_ADD(8, t1 - t0); SCFQ_LP_ADD(9, t2 - t1); SCFQ_LP_ADD(10, t3 - t2); SCFQ_LP_ADD(11, 1); }
+#endif
+    } while ((n_sym | (0u - endk)) < 64u);
+    // (once per group — at most 64 rounds, 8 KiB of clamped reads:) a malformed stream reading far past the end of the data: over, the caller
+    // sees the position; a block of 256 MiB: not here
+    if ((ip_end + 16u - (b0 + ((f0 + rel) >> 3))) >> 31) stop = 1;
+    if ((0x7FFFFFFFu - rel) >> 31) { stop = 1; err = kErrData; }
     // ---- B. lane k: symbol k ----------------------------------------------------------------------------------------------------
     const uint32_t m = n_sym < 64u ? n_sym : 64u;
     if (m != 0u && err == kOk) {
       __builtin_amdgcn_wave_barrier();
+      SCFQ_LP_T(t4);
       const bool valid = lane < m;
       const uint32_t p = scr[kP + lane];
       const uint32_t q = f0 + p;
@@ -783,6 +831,13 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
         err = kErrData;
       } else {
         scr[kI + lane] = kind == 1u ? B : 0x80000000u | ((ef >> 16) & 0xFFu);
+#ifdef SCFQ_LPROF
+        asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(st) : "memory");
+#endif
+        SCFQ_LP_T(t5);
+        SCFQ_LP_ADD(12, t5 - t4); SCFQ_LP_ADD(14, 1); SCFQ_LP_ADD(17, m);
+        // (Chunks that do not restart at sub-groups and end in front of the first LANE that reads the chunk's own output — fewer waits, 2.4
+        // against 3.8 per group — took more instructions per chunk and were slower: 8200 against 6450 cycles per group.)
         uint32_t k0 = 0, s0 = 0;
         while (k0 < m) {
           // the first symbol from k0 on that reads what the sub-group starting at k0 puts out
@@ -793,6 +848,7 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
             const uint32_t mlen_s = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)k0);
             const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)B, (int)k0);
             SCFQ_XFLUSH();
+            SCFQ_LP_ADD(16, 1);
             const uint32_t dst0 = pos + s0, src0 = dst0 - off;
             for (uint32_t base = 0; base < mlen_s; base += 64) {
               const uint32_t k = base + lane;
@@ -804,20 +860,23 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
             s0 += mlen_s;
           } else {
             const uint32_t s1 = kc < m ? (uint32_t)__builtin_amdgcn_readlane((int)st, (int)kc) : R;
-            uint32_t carry = k0;
+            uint32_t ka = k0;                            // symbols of the group that start in front of the chunk
             uint32_t first = 1;
+            SCFQ_LP_ADD(16, 1);
             for (uint32_t base = s0; base < s1; base += 64u) {
               // every lane is one output symbol: its owner is the symbol with the highest start at or below it
+              SCFQ_LP_ADD(15, 1);
               scr[kC + lane] = 0u;
               __builtin_amdgcn_wave_barrier();
-              if (valid & (lane - k0 < kc - k0) & (st - base < 64u) & (len != 0u)) scr[kC + (st - base)] = lane + 1u;
+              if (valid & (lane - k0 < kc - k0) & (st - base < 64u) & (len != 0u)) scr[kC + (st - base)] = 1u;
               __builtin_amdgcn_wave_barrier();
-              const uint64_t starts = __builtin_amdgcn_ballot_w64(scr[kC + lane] != 0u);
-              const uint32_t m_lo = (uint32_t)starts & le_lo, m_hi = (uint32_t)(starts >> 32) & le_hi;
-              const uint32_t s = m_hi ? 63u - (uint32_t)__builtin_clz(m_hi) : 31u - (uint32_t)__builtin_clz(m_lo | 1u);
-              const uint32_t oc = scr[kC + s];
-              const uint32_t own = (m_lo | m_hi) ? oc - 1u : carry;
-              const uint32_t inf = scr[kI + own];
+              // symbols start in order: the owner is symbol ka - 1 plus the number of starts at or below the lane
+              // (beyond the sub-group's end the sum may pass 63: those lanes put nothing out, and what they read from LDS is not used)
+              const bool starts_here = scr[kC + lane] != 0u;
+              const uint64_t starts = __builtin_amdgcn_ballot_w64(starts_here);
+              const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, ka - 1u)) + (starts_here ? 1u : 0u);
+              ka += (uint32_t)__builtin_popcountll(starts);
+              const uint32_t inf = scr[kI + (own & 63u)];
               const bool act = base + lane < s1;
               const bool is_match = (inf >> 31) == 0u;
               if (first) SCFQ_XFLUSH();                  // what the sub-group before put out is what this one may read
@@ -826,7 +885,6 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
               pend_ld = ld;
               pend_sel = is_match ? 0u : 0x100u | (inf & 0xFFu);
               pend_off = act ? (pos + base + lane) << kSh : kOob;
-              carry = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
               first = 0;
             }
             k0 = kc;
@@ -834,13 +892,15 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
           }
         }
         pos += R;
+#ifdef SCFQ_LPROF
+        { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); SCFQ_LP_T(t6); SCFQ_LP_ADD(13, t6 - t5); }
+#endif
         if (n_sym <= 64u && endk == 2u) {
           // the hard symbol has been decoded: the chain goes on behind it, or the block ends with it
           const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)kind, (int)(m - 1u));
           rel = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)(m - 1u)) + (uint32_t)__builtin_amdgcn_readlane((int)tot, (int)(m - 1u));
           if (kl == 2u) stop = 1;
           endk = 0u;
-          SCFQ_XLOAD(rel);
           if ((ip_end + 16u - (b0 + ((f0 + rel) >> 3))) >> 31) stop = 1;
           if ((0x7FFFFFFFu - rel) >> 31) err = kErrData;
         }
@@ -859,9 +919,10 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
     stop |= (limit - pos) >> 31;                         // pos > limit: the descriptor dropped the excess
   } while (!stop);
   SCFQ_XFLUSH();
+#ifdef SCFQ_LPROF
+  if (lane == 0) for (int q = 8; q < 18; ++q) atomicAdd(&g_lprof[q], (unsigned long long)lp[q]);
+#endif
 #undef SCFQ_XFLUSH
-#undef SCFQ_XLOAD
-#undef SCFQ_XBYTE
   // back to the byte-wise reader of the caller (as symbol_loop_lanes)
   const uint64_t bit = bit0 + rel;
   const uint32_t ipn = (uint32_t)((bit + 7u) >> 3);

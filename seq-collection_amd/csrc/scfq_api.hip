@@ -677,10 +677,11 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
 
 // ---- BGZF with device-side inflate: the host only walks the member headers and moves COMPRESSED bytes ---------------
 constexpr uint32_t kMaxBlocksPerChunk = 1u << 18;
-// Which symbol loop the device inflate kernels run (bgzf_inflate_kernel.hpp): SCFQ_INFLATE_LOOP=lanes (0, the default), serial (1, A/B
-// measurements), dense (2, boundary-first)
+// Which symbol loop the device inflate kernels run (bgzf_inflate_kernel.hpp): the boundary-first one (2, symbol_loop_dense) unless
+// SCFQ_INFLATE_LOOP says lanes (0, symbol_loop_lanes: r2's) or serial (1, r1's) — both kept for A/B measurements and covered by
+// tests/test_gpu_bgzf_device.py::test_the_other_symbol_loops
 inline uint32_t inflate_serial_loop() {
-  static const uint32_t v = [] { const char* e = std::getenv("SCFQ_INFLATE_LOOP"); return !e ? 0u : (e[0] == 's' ? 1u : (e[0] == 'd' ? 2u : 0u)); }();
+  static const uint32_t v = [] { const char* e = std::getenv("SCFQ_INFLATE_LOOP"); return !e ? 2u : (e[0] == 's' ? 1u : (e[0] == 'l' ? 0u : 2u)); }();
   return v;
 }
 constexpr int kFallbackToHost = 1;        // ingest_bgzf_device: could not set up, nothing queued
@@ -1644,11 +1645,16 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
   uint32_t st = 0;
   HIPCHK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
 #ifdef SCFQ_LPROF
-  { unsigned long long w[16]; HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(scfq_dinflate::g_lprof), sizeof w));
+  { unsigned long long w[24]; HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(scfq_dinflate::g_lprof), sizeof w));
+    if (w[14]) {
+      const double g = (double)w[14], ra = (double)std::max<unsigned long long>(1, w[11]);
+      std::fprintf(stderr, "dprof: groups %llu symbols/group %.1f rounds/group %.2f chunks/group %.2f sub-groups+alone/group %.2f | cycles per round: window+lengths %.0f walk %.0f collect %.0f | per group: part A %.0f decode %.0f emit %.0f\n",
+                   w[14], w[17] / g, w[11] / g, w[15] / g, w[16] / g, w[8] / ra, w[9] / ra, w[10] / ra, (w[8] + w[9] + w[10]) / g, w[12] / g, w[13] / g);
+    }
     const double r = (double)std::max<unsigned long long>(1, w[5]);
     std::fprintf(stderr, "lprof: rounds %llu symbols/round %.2f slow rounds %.3f | cycles per round: window wait %.0f decode %.0f walk %.0f pending store (load wait) %.0f emit %.0f\n", w[5],
                  w[6] / r, w[7] / r, w[0] / r, w[1] / r, w[2] / r, w[3] / r, w[4] / r);
-    unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(scfq_dinflate::g_lprof), z, sizeof z)); }
+    unsigned long long z[24] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(scfq_dinflate::g_lprof), z, sizeof z)); }
 #endif
 #ifdef SCFQ_DSTATS
   { uint32_t w[8]; HIPCHK(hipMemcpy(w, d_status, 32, hipMemcpyDeviceToHost));

@@ -277,7 +277,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     const int dev = c->dev;
     warm.th = std::thread([sd, dev] {
       if (hipSetDevice(dev) != hipSuccess) return;
-      hipLaunchKernelGGL(gz_segment_decode, dim3(1), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, sd, (const uint8_t*)nullptr, 0ull, (const GzSeg*)nullptr, 0u,
+      hipLaunchKernelGGL(gz_segment_decode, dim3(1), dim3(64 * kWavesPerWg), kWavesPerWg * kGzWaveLdsBytes, sd, (const uint8_t*)nullptr, 0ull, (const GzSeg*)nullptr, 0u,
                          (uint16_t*)nullptr, (GzSegOut*)nullptr, 0u);
       (void)hipGetLastError();
     });
@@ -547,7 +547,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       const uint8_t* vbase = g.comp[k % 4].p - byte0_of(k);
       span_begin(sp_decode, sd);
       HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs, h_segs, sizeof(GzSeg) * n_seg, hipMemcpyHostToDevice, sd));
-      hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, sd,
+      hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kGzWaveLdsBytes, sd,
                          vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs), n_seg, sl.sym.base(),
                          reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs), inflate_serial_loop());
       HIPCHK(hipGetLastError());
@@ -729,7 +729,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       if (verbose) std::fprintf(stderr, "scfq gzdev:   batch %u round %d: %u gap segments\n", k, round + 1, n_seg - first);
       ++n_gap_rounds;
       HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs + sizeof(GzSeg) * first, h_segs + first, sizeof(GzSeg) * (n_seg - first), hipMemcpyHostToDevice, s_gap));
-      hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg - first + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kWaveLdsBytes, s_gap,
+      hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg - first + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kGzWaveLdsBytes, s_gap,
                          vbase, copy_end_of(k), reinterpret_cast<const GzSeg*>(sl.d_meta + off_segs) + first, n_seg - first, sl.sym.base(),
                          reinterpret_cast<GzSegOut*>(sl.d_meta + off_outs) + first, inflate_serial_loop());
       HIPCHK(hipGetLastError());

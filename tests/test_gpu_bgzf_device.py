@@ -155,3 +155,34 @@ def test_file_that_stops_being_bgzf_restarts_on_the_host_path(gpu, scfq, oracle,
     g.write_bytes(bgzf_file(d1)[:-40])
     with pytest.raises(scfq.ScfqError):
         scfq.count_file(str(g))
+
+
+def test_the_other_symbol_loops(gpu, tmp_path):
+    """the default is the boundary-first loop (symbol_loop_dense); the lane-parallel loop of r2 and the serial one of r1 stay selectable
+    (SCFQ_INFLATE_LOOP, read once per process) and must put out the same bytes: BGZF members and an ordinary gzip member, each in a
+    process of its own"""
+    import os, subprocess, sys
+    data = (fastq_bytes(6_000_000, seed=21) + b"@long\n" + b"A" * 70_000 + b"\n+\n" + b"F" * 70_000 + b"\n"
+            + b"".join(b"@p%d\n" % i + b"ACGTN" * 9 + b"\n+\n" + b"FF:,#" * 9 + b"\n" for i in range(3000)))
+    (tmp_path / "b.fq.gz").write_bytes(bgzf_file(data))
+    (tmp_path / "g.fq.gz").write_bytes(gzip.compress(data, 6))
+    code = """
+import sys, hashlib
+sys.path.insert(0, sys.argv[1])
+import scfq
+img = open(sys.argv[2], "rb").read()
+out = scfq.debug_bgzf_inflate(img, int(sys.argv[4]) + 16)
+c = scfq.count_file(sys.argv[3])
+print(hashlib.sha256(bytes(out)).hexdigest(), c.reads, c.gc_bases, c.n_bases, c.bases, c.input_bytes)
+"""
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seq-collection_amd", "pyhost")
+    import hashlib
+    seen = {}
+    for loop in ("dense", "lanes", "serial"):
+        r = subprocess.run([sys.executable, "-c", code, here, str(tmp_path / "b.fq.gz"), str(tmp_path / "g.fq.gz"), str(len(data))],
+                           env=dict(os.environ, SCFQ_INFLATE_LOOP=loop), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (loop, r.stderr[-2000:])
+        seen[loop] = r.stdout.split()
+    assert seen["dense"][0] == hashlib.sha256(data).hexdigest()
+    assert int(seen["dense"][5]) == len(data)
+    assert seen["lanes"] == seen["dense"] and seen["serial"] == seen["dense"]
