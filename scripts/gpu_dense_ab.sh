@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the symbol loops (SCFQ_INFLATE_LOOP=lanes | dense) on configs[3] (one member, default 10 GB) and on a 4 GB BGZF file;
-# with ablate/libsc_fqcount_hip_noalias.so present (a -DSCFQ_GZ_CLTAB_ALIAS=0 build: 16 waves per CU), that build as well.
+# with ablate/libsc_fqcount_hip_noalias.so present (a -DSCFQ_GZ_CLTAB_ALIAS=0 build of the library — `make -C seq-collection_amd noalias` —:
+# 16 decode waves per CU instead of 20), that build as well.
 mkdir -p gpurun_out/r03
 A=$PWD/seq-collection_amd/ablate/libsc_fqcount_hip_noalias.so
 V='[{"name":"lanes","env":{"SCFQ_INFLATE_LOOP":"lanes"}},{"name":"dense","env":{"SCFQ_INFLATE_LOOP":"dense"}}'
