@@ -61,6 +61,10 @@ rows = []
 for f in glob.glob(out + "/prof_bgzf/**/*kernel_trace.csv", recursive=True):
     rows += [r for r in csv.DictReader(open(f)) if "bgzf_inflate" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# (the library's first call launches an empty one-workgroup bgzf_inflate on a helper thread to have the kernel's code and scratch set up:
+# it is not in the launch log)
+while len(rows) > len(launch) and int(rows[0]["Grid_Size_X"]) == int(rows[0]["Workgroup_Size_X"]): rows.pop(0)
+assert len(rows) == len(launch), (len(rows), len(launch))
 with open(out + "/bgzf_dispatches.tsv", "w") as w:
     w.write("# bgzf_inflate dispatches of three counts of a %d-byte (inflated) BGZF level-6 file: rocprofv3 --kernel-trace durations joined, in dispatch order, with the library's launch log\n" % inflated)
     w.write("dispatch\tmembers\tcompressed_bytes\tinflated_bytes\tduration_us\tinflated_GBps\n")
@@ -73,6 +77,7 @@ with open(out + "/bgzf_dispatches.tsv", "w") as w:
 agg = {}
 for f in glob.glob(out + "/prof_gz/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
+        if "gz_segment_decode" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == int(r["Workgroup_Size_X"]) and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 200000: continue   # the empty warm-up launch of a process's first call
         n = r["Kernel_Name"].split("(")[0][:60]
         a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 with open(out + "/gz_device_kernels.tsv", "w") as w:
