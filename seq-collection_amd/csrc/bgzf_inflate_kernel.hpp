@@ -718,7 +718,8 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
       uint64_t chain;
       // (two steps per pass with the registers swapped, so that no s_mov is needed; the lane select of v_readlane must not be a register a
       // vector instruction has written within the last four instructions — nobody inserts wait states into inline assembly —: s_nop.
-      // Straight-line code of eight steps over a copy of A that ends at 64, with no branch per symbol, was slower: 346 against 300 cycles.)
+      // Straight-line code of eight steps over a copy of A that ends at 64, with no branch per symbol, was slower: 346 against 300 cycles;
+      // rounds over 128 positions, two per lane, took twice the time per round: the same per symbol.)
       uint32_t nx;
       asm volatile(
           "s_mov_b32 %[nx], 0\n\t"
