@@ -68,12 +68,12 @@ st = dict(blocks=len(blocks), symbols=0, out=0, hard=0, groups=0, rounds=0, subg
 for syms in blocks:
     i = 0; n_s = len(syms); g = []
     while i < n_s or g:
-        # part A: rounds of 64 bit positions from the first symbol not yet collected, until 64 symbols are there or a hard one is
+        # part A: rounds of 128 bit positions from the first symbol not yet collected, until 64 symbols are there or a hard one is
         hard = bool(g) and g[-1][4]
         if i < n_s and not hard: rel = syms[i][0]
         while len(g) < 64 and i < n_s and not hard:
             st["rounds"] += 1
-            end = rel + 64
+            end = rel + 128
             while i < n_s and syms[i][0] < end:
                 g.append(syms[i]); i += 1
                 if g[-1][4]: hard = True; break

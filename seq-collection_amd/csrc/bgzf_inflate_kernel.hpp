@@ -615,9 +615,9 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
 // ---- the symbol loop, boundary-first form -----------------------------------------------------------------------------------
 // symbol_loop_lanes decodes 64 bit positions completely (value, extra bits, distance) to find the 4-5 of them that hold symbols: 27
 // vector instructions per symbol, and vector issue is what bounds the kernel.  Here the two halves are apart:
-//  A. rounds over 64 bit positions that only find out HOW LONG the code at every position is (one gather per table, first level only:
-//     ~25 vector instructions); the scalar unit follows the chain as before and the positions of the chain's symbols are collected
-//     in LDS, one after the other, over as many rounds as it takes to have 64 of them;
+//  A. rounds over 128 bit positions, two per lane, that only find out HOW LONG the code at every position is (one gather per table, first
+//     level only: ~25 vector instructions per 64 positions); the scalar unit follows the chain as before and the positions of the chain's
+//     symbols are collected in LDS, one after the other, over as many rounds as it takes to have 64 of them;
 //  B. then lane k decodes symbol k completely (the same arithmetic as step 1 of symbol_loop_lanes, now with every lane on a real
 //     symbol), one scan gives every symbol's place in the output, and the output goes out in chunks of 64 symbols: every lane finds the
 //     symbol it belongs to, and is a literal or one load `distance` back.
@@ -626,7 +626,7 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
 // A match that reads output of its own group ends a SUB-GROUP in front of it: the stores of everything before are issued first (the
 // memory pipeline keeps a wave's accesses in order, as in symbol_loop_lanes); one that overlaps its own output is copied alone, with
 // its period.  The last store of a sub-group waits for its load only when the next sub-group begins.
-// LDS scratch (256 dwords: the table builder's work area): positions [0, 128), chunk owners [128, 192), symbol info [192, 256).
+// LDS scratch (256 dwords: the table builder's work area): positions [0, 192), a chunk's start flags [192, 256).
 template <bool SYM16>
 __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const uint8_t* in_aligned, uint32_t in_off, uint32_t ip_end, void* out_base,
                                                            uint32_t limit, uint32_t lit_lds, uint32_t dist_lds, uint32_t scratch_lds) {
@@ -648,7 +648,7 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
   lds_u32* const litp = (lds_u32*)(uintptr_t)uni(lit_lds);
   lds_u32* const distp = (lds_u32*)(uintptr_t)uni(dist_lds);
   volatile lds_u32* const scr = (volatile lds_u32*)(uintptr_t)uni(scratch_lds);
-  constexpr uint32_t kP = 0u, kC = 128u, kI = 192u;
+  constexpr uint32_t kP = 0u, kC = 192u;          // positions collected (up to 63 + 128), start flags of a chunk
   auto store_sym = [&](uint32_t v, uint32_t off) {
     if (SYM16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)v, orsrc, off, 0, 0);
     else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, orsrc, off, 0, 0);
@@ -673,6 +673,7 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
 #define SCFQ_XFLUSH() do { store_raw((pend_sel & 0x100u) ? (sym_t)(pend_sel & 0xFFu) : pend_ld, pend_off); pend_off = kOob; } while (0)
   scr[kP + lane] = 0u;                                 // (positions nobody has collected yet are read by the lanes beyond a group's end)
   scr[kP + 64u + lane] = 0u;
+  scr[kP + 128u + lane] = 0u;
   uint32_t n_sym = 0;                                  // positions collected and not yet decoded
   uint32_t endk = 0;                                   // 1: the chain has ended (end of block: rel is behind its code); 2: the last position collected is a hard one
   uint32_t stop = 0;
@@ -685,12 +686,13 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
   do {
     // ---- A. lengths only, until 64 symbols are known -----------------------------------------------------------------------------
     // The stream comes through a VECTOR register: lane i holds dword i of the 2048 bits from sv_rel's dword on, and every lane pulls the
-    // two dwords its position lies in with ds_bpermute — no scalar loads, shifts or waits per round (the scalar unit is what the CU's
-    // sixteen waves share, and it has the chain to follow).
+    // dwords its positions lie in with ds_bpermute — no scalar loads, shifts or waits per round (the scalar unit is what the CU's
+    // twenty waves share, and it has the chain to follow).  A round covers 128 bit positions, two per lane (lane and 64 + lane), written
+    // stage by stage for both so that the waits of the dependent steps — bpermute, gather, gather — are paid once for the two.
     if (n_sym < 64u && endk == 0u) do {
       SCFQ_LP_T(t0);
       uint32_t T = rel - sv_rel;                       // the chain's position inside sv, in bits
-      if (T >= 1900u) {
+      if (T >= 1800u) {
         const uint64_t ab = bit0 + rel + 8u * in_off;  // in bits from in_aligned
         const uint32_t dw = (uint32_t)(ab >> 5);
         T = (uint32_t)ab & 31u;
@@ -698,68 +700,92 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
         const uint32_t ad = 4u * (dw + lane);
         sv = *(glob_u32*)(in_u + (ad < in_last ? ad : in_last));
       }
-      const uint32_t t = T + lane;
-      const uint32_t j4 = (t >> 3) & 0x1FCu;
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)j4, (int)sv), hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j4 + 4u), (int)sv);
-      const uint32_t x0 = __builtin_amdgcn_alignbit(hi, lo, t);                      // 32 bits from bit `lane` on: 10 + 5 + 8 of them are looked at
-      const uint32_t e1 = litp[x0 & ((1u << kLitRoot) - 1u)];
-      const uint32_t s1 = (e1 & 15u) + ((e1 >> 4) & 15u);                            // code + extra bits (a literal's entry has no extra bits)
-      const uint32_t d1 = distp[__builtin_amdgcn_ubfe(x0, s1, kDistRoot)];
-      const uint32_t dd = ((d1 & 15u) + ((d1 >> 4) & 15u)) & (uint32_t)__builtin_amdgcn_sbfe(e1, 10, 1);     // (kVal is bit 10: a length code)
-      // a literal, or a length code with a distance code of the first level: the chain steps over it (to lane + bits, 123 at most).  Anything
-      // else ends the round's chain: 128
-      const bool go = ((((e1 << 2) | (e1 & d1)) & kVal) != 0u);
-      const uint32_t A = go ? lane + s1 + dd : 128u;
+      const uint32_t ta = T + lane;                                                  // (the second position is 64 bits = two dwords on)
+      const uint32_t j4 = (ta >> 3) & 0x1FCu;
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)j4, (int)sv), w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j4 + 4u), (int)sv),
+                     w2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j4 + 8u), (int)sv), w3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j4 + 12u), (int)sv);
+      const uint32_t xa = __builtin_amdgcn_alignbit(w1, w0, ta), xb = __builtin_amdgcn_alignbit(w3, w2, ta);     // 32 bits from each position on
+      const uint32_t e1a = litp[xa & ((1u << kLitRoot) - 1u)], e1b = litp[xb & ((1u << kLitRoot) - 1u)];
+      const uint32_t s1a = (e1a & 15u) + ((e1a >> 4) & 15u), s1b = (e1b & 15u) + ((e1b >> 4) & 15u);             // code + extra bits
+      const uint32_t d1a = distp[__builtin_amdgcn_ubfe(xa, s1a, kDistRoot)], d1b = distp[__builtin_amdgcn_ubfe(xb, s1b, kDistRoot)];
+      const uint32_t dda = ((d1a & 15u) + ((d1a >> 4) & 15u)) & (uint32_t)__builtin_amdgcn_sbfe(e1a, 10, 1);     // (kVal is bit 10: a length code)
+      const uint32_t ddb = ((d1b & 15u) + ((d1b >> 4) & 15u)) & (uint32_t)__builtin_amdgcn_sbfe(e1b, 10, 1);
+      // a literal, or a length code with a distance code of the first level: the chain steps over it (to position + bits, 127 + 36 at most).
+      // Anything else ends the round's chain: 256
+      const uint32_t Aa = ((((e1a << 2) | (e1a & d1a)) & kVal) != 0u) ? lane + s1a + dda : 256u;
+      const uint32_t Ab = ((((e1b << 2) | (e1b & d1b)) & kVal) != 0u) ? 64u + lane + s1b + ddb : 256u;
 #ifdef SCFQ_LPROF
-      asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(A) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(Aa), "v"(Ab) : "memory");
 #endif
       SCFQ_LP_T(t1);
-      uint32_t cur;
-      uint64_t chain;
-      // (two steps per pass with the registers swapped, so that no s_mov is needed; the lane select of v_readlane must not be a register a
+      uint32_t cur, nx;
+      uint64_t ca, cb;                                 // the chain's lanes in the first and in the second half
+      // Two steps per pass with the registers swapped, so that no s_mov is needed; the lane select of v_readlane must not be a register a
       // vector instruction has written within the last four instructions — nobody inserts wait states into inline assembly —: s_nop.
-      // Straight-line code of eight steps over a copy of A that ends at 64, with no branch per symbol, was slower: 346 against 300 cycles;
-      // rounds over 128 positions, two per lane, took twice the time per round: the same per symbol.)
-      uint32_t nx;
+      // (Lane select and bit index take the low six bits: positions 64 .. 127 address the second half's registers as they are.)
+      // Straight-line code of eight steps with no branch per symbol was slower: 346 against 300 cycles per 64 positions.
       asm volatile(
           "s_mov_b32 %[nx], 0\n\t"
-          "s_mov_b64 %[chain], 0\n"
+          "s_mov_b64 %[ca], 0\n\t"
+          "s_mov_b64 %[cb], 0\n"
           "1:\n\t"
-          "v_readlane_b32 %[cur], %[A], %[nx]\n\t"
-          "s_bitset1_b64 %[chain], %[nx]\n\t"
+          "v_readlane_b32 %[cur], %[Aa], %[nx]\n\t"
+          "s_bitset1_b64 %[ca], %[nx]\n\t"
           "s_cmp_lt_u32 %[cur], 64\n\t"
           "s_cbranch_scc0 2f\n\t"
           "s_nop 0\n\t"
-          "v_readlane_b32 %[nx], %[A], %[cur]\n\t"
-          "s_bitset1_b64 %[chain], %[cur]\n\t"
+          "v_readlane_b32 %[nx], %[Aa], %[cur]\n\t"
+          "s_bitset1_b64 %[ca], %[cur]\n\t"
           "s_cmp_lt_u32 %[nx], 64\n\t"
           "s_nop 0\n\t"
           "s_cbranch_scc1 1b\n\t"
           "s_mov_b32 %[cur], %[nx]\n"
-          "2:\n"
-          : [cur] "=&s"(cur), [nx] "=&s"(nx), [chain] "=&s"(chain)
-          : [A] "v"(A)
+          "2:\n\t"
+          "s_cmp_lt_u32 %[cur], 128\n\t"
+          "s_cbranch_scc0 5f\n\t"
+          "s_mov_b32 %[nx], %[cur]\n"
+          "3:\n\t"
+          "v_readlane_b32 %[cur], %[Ab], %[nx]\n\t"
+          "s_bitset1_b64 %[cb], %[nx]\n\t"
+          "s_cmp_lt_u32 %[cur], 128\n\t"
+          "s_cbranch_scc0 5f\n\t"
+          "s_nop 0\n\t"
+          "v_readlane_b32 %[nx], %[Ab], %[cur]\n\t"
+          "s_bitset1_b64 %[cb], %[cur]\n\t"
+          "s_cmp_lt_u32 %[nx], 128\n\t"
+          "s_nop 0\n\t"
+          "s_cbranch_scc1 3b\n\t"
+          "s_mov_b32 %[cur], %[nx]\n"
+          "5:\n"
+          : [cur] "=&s"(cur), [nx] "=&s"(nx), [ca] "=&s"(ca), [cb] "=&s"(cb)
+          : [Aa] "v"(Aa), [Ab] "v"(Ab)
           : "scc");
 #ifdef SCFQ_LPROF
-      asm volatile("" : : "s"(chain), "s"(cur));
+      asm volatile("" : : "s"(ca), "s"(cb), "s"(cur));
 #endif
       SCFQ_LP_T(t2);
       uint32_t nxt = rel + cur;
-      if (cur >= 128u) {
-        // the chain has come to a lane it cannot step over (the last one it noted): what is there
-        const uint32_t sl = 63u - (uint32_t)__builtin_clzll(chain);
-        const uint32_t es = (uint32_t)__builtin_amdgcn_readlane((int)e1, (int)sl), ds = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)sl);
+      if (cur >= 256u) {
+        // the chain has come to a position it cannot step over (the last one it noted): what is there
+        uint32_t sl, es, ds;
+        if (cb) {
+          sl = 127u - (uint32_t)__builtin_clzll(cb);
+          es = (uint32_t)__builtin_amdgcn_readlane((int)e1b, (int)(sl - 64u)); ds = (uint32_t)__builtin_amdgcn_readlane((int)d1b, (int)(sl - 64u));
+        } else {
+          sl = 63u - (uint32_t)__builtin_clzll(ca);
+          es = (uint32_t)__builtin_amdgcn_readlane((int)e1a, (int)sl); ds = (uint32_t)__builtin_amdgcn_readlane((int)d1a, (int)sl);
+        }
         nxt = rel;
         if ((es & kSub) || ((es & kVal) && !(ds & kVal))) endk = 2u;                 // hard: collected, part B says what it is
         else {
-          chain &= ~(1ull << sl);
+          if (cb) cb &= ~(1ull << (sl - 64u)); else ca &= ~(1ull << sl);
           endk = 1u;
           nxt = rel + sl + (es & 15u);                                               // behind an end-of-block code
           if (!(es & kEob)) err = kErrData;
         }
       }
-      {
-        // the chain's lanes note their positions behind those already collected (only they execute this: five vector instructions)
+      // the chain's lanes note their positions behind those already collected (only they execute this: five vector instructions per half)
+      auto note = [&](uint64_t chain, uint32_t first, uint32_t position0) {
         uint64_t save;
         uint32_t t_, u_;
         asm volatile(
@@ -772,10 +798,13 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
             "ds_write_b32 %[t], %[u]\n\t"
             "s_mov_b64 exec, %[save]"
             : [save] "=&s"(save), [t] "=&v"(t_), [u] "=&v"(u_)
-            : [chain] "s"(chain), [clo] "s"((uint32_t)chain), [chi] "s"((uint32_t)(chain >> 32)), [base] "s"(scr_base + 4u * (kP + n_sym)), [rel] "s"(rel), [lane] "v"(lane)
+            : [chain] "s"(chain), [clo] "s"((uint32_t)chain), [chi] "s"((uint32_t)(chain >> 32)), [base] "s"(scr_base + 4u * (kP + first)), [rel] "s"(position0), [lane] "v"(lane)
             : "memory");
-      }
-      n_sym += (uint32_t)__builtin_popcountll(chain);
+      };
+      const uint32_t na = (uint32_t)__builtin_popcountll(ca);
+      note(ca, n_sym, rel);
+      if (cb) note(cb, n_sym + na, rel + 64u);
+      n_sym += na + (uint32_t)__builtin_popcountll(cb);
       rel = nxt;
 #ifdef SCFQ_LPROF
       { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); SCFQ_LP_T(t3); SCFQ_LP_ADD(8, t1 - t0); SCFQ_LP_ADD(9, t2 - t1); SCFQ_LP_ADD(10, t3 - t2); SCFQ_LP_ADD(11, 1); }
@@ -831,7 +860,8 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
       if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
         err = kErrData;
       } else {
-        scr[kI + lane] = kind == 1u ? B : 0x80000000u | ((ef >> 16) & 0xFFu);
+        // what an output symbol needs to know about its symbol, pulled from the symbol's lane: a literal (bit 31) and its value, or a match's distance
+        const uint32_t info = kind == 1u ? B : 0x80000000u | ((ef >> 16) & 0xFFu);
 #ifdef SCFQ_LPROF
         asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(st) : "memory");
 #endif
@@ -877,7 +907,7 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
               const uint64_t starts = __builtin_amdgcn_ballot_w64(starts_here);
               const uint32_t own = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, ka - 1u)) + (starts_here ? 1u : 0u);
               ka += (uint32_t)__builtin_popcountll(starts);
-              const uint32_t inf = scr[kI + (own & 63u)];
+              const uint32_t inf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(own << 2), (int)info);
               const bool act = base + lane < s1;
               const bool is_match = (inf >> 31) == 0u;
               if (first) SCFQ_XFLUSH();                  // what the sub-group before put out is what this one may read
@@ -908,9 +938,10 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
       }
     }
     if (n_sym > 64u) {
-      const uint32_t v = scr[kP + 64u + lane];
+      const uint32_t v = scr[kP + 64u + lane], v2 = scr[kP + 128u + lane];
       __builtin_amdgcn_wave_barrier();
       scr[kP + lane] = v;
+      scr[kP + 64u + lane] = v2;
       n_sym -= 64u;
     } else {
       n_sym = 0u;

@@ -1,6 +1,6 @@
 """The rules of the boundary-first symbol loop (csrc/bgzf_inflate_kernel.hpp: symbol_loop_dense) restated in Python and run against
 zlib.  Part A looks only at the FIRST table level (10 bits of a literal/length code, 8 of a distance code) to learn how long the code
-at each of 64 bit positions is, follows the chain and collects the positions of its symbols; a code of the second level, a length
+at each of 128 bit positions (two per lane) is, follows the chain and collects the positions of its symbols; a code of the second level, a length
 code whose distance code is one, and the end-of-block code end the chain there ("hard": collected, decoded in part B, which says where
 the chain goes on).  Part B decodes up to 64 collected symbols at once, puts them at the prefix sum of their lengths and writes the
 output in SUB-GROUPS — a match that reads output of its own sub-group starts the next one, one that overlaps its own output is copied
@@ -52,10 +52,10 @@ def huffman_block_dense(bits, lit, dist, mem, stats):
     P, endk, rel, stop = [], 0, bits.p, False             # collected positions | 0 chain goes on, 1 ended (rel behind the end-of-block code), 2 last one is hard
     while not stop:
         # ---- A
-        while len(P) < 64 and endk == 0:
-            lanes = [length_at(bits, rel + i, lit, dist) for i in range(64)]
+        while len(P) < 64 and endk == 0:                  # (P holds up to 63 + 128 positions)
+            lanes = [length_at(bits, rel + i, lit, dist) for i in range(128)]      # (two positions per lane: i and 64 + i)
             cur, chain = 0, []
-            while cur < 64:
+            while cur < 128:
                 a = lanes[cur]
                 chain.append(cur)                         # (the walk notes a lane before it knows whether it can step over it)
                 if a[0] != "go":
