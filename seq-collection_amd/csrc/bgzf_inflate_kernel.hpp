@@ -627,6 +627,9 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
 // memory pipeline keeps a wave's accesses in order, as in symbol_loop_lanes); one that overlaps its own output is copied alone, with
 // its period.  The last store of a sub-group waits for its load only when the next sub-group begins.
 // LDS scratch (256 dwords: the table builder's work area): positions [0, 192), a chunk's start flags [192, 256).
+#ifndef SCFQ_DENSE_EMIT2
+#define SCFQ_DENSE_EMIT2 0      // 1: the output chunks of a sub-group go out two at a time (not yet the default: measured on BGZF only)
+#endif
 template <bool SYM16>
 __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const uint8_t* in_aligned, uint32_t in_off, uint32_t ip_end, void* out_base,
                                                            uint32_t limit, uint32_t lit_lds, uint32_t dist_lds, uint32_t scratch_lds) {
@@ -670,7 +673,14 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
   typedef typename std::conditional<SYM16, uint16_t, uint8_t>::type sym_t;
   sym_t pend_ld = 0;
   uint32_t pend_sel = 0, pend_off = kOob;
+#if SCFQ_DENSE_EMIT2
+  sym_t pend2_ld = 0;                                  // the second chunk of a pair (below)
+  uint32_t pend2_sel = 0, pend2_off = kOob;
+#define SCFQ_XFLUSH() do { store_raw((pend_sel & 0x100u) ? (sym_t)(pend_sel & 0xFFu) : pend_ld, pend_off); pend_off = kOob; \
+                           store_raw((pend2_sel & 0x100u) ? (sym_t)(pend2_sel & 0xFFu) : pend2_ld, pend2_off); pend2_off = kOob; } while (0)
+#else
 #define SCFQ_XFLUSH() do { store_raw((pend_sel & 0x100u) ? (sym_t)(pend_sel & 0xFFu) : pend_ld, pend_off); pend_off = kOob; } while (0)
+#endif
   scr[kP + lane] = 0u;                                 // (positions nobody has collected yet are read by the lanes beyond a group's end)
   scr[kP + 64u + lane] = 0u;
   scr[kP + 128u + lane] = 0u;
@@ -894,7 +904,42 @@ __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const
             uint32_t ka = k0;                            // symbols of the group that start in front of the chunk
             uint32_t first = 1;
             SCFQ_LP_ADD(16, 1);
+#if SCFQ_DENSE_EMIT2
+            // TWO chunks per pass while the sub-group has more than 64 symbols left: the start flags are bytes (128 of them in the 64
+            // dwords), one clear, one scatter, and the dependent steps — flags, owner, info, load — of both chunks run side by side
+            // (what the 128-position round of part A showed: a wave's time is its chain of dependent LDS steps).
+            typedef __attribute__((address_space(3))) uint8_t lds_u8;
+            volatile lds_u8* const c8 = (volatile lds_u8*)(uintptr_t)(scr_base + 4u * kC);
+            const uint32_t stv = (valid & (lane - k0 < kc - k0) & (len != 0u)) ? st : 0xFFFFFF00u;
+            uint32_t base2 = s0;
+            while (base2 + 64u < s1) {
+              SCFQ_LP_ADD(15, 2);
+              scr[kC + (lane & 31u)] = 0u;
+              __builtin_amdgcn_wave_barrier();
+              if (stv - base2 < 128u) c8[stv - base2] = 1;
+              __builtin_amdgcn_wave_barrier();
+              const bool f0 = c8[lane] != 0, f1 = c8[64u + lane] != 0;
+              const uint64_t starts0 = __builtin_amdgcn_ballot_w64(f0), starts1 = __builtin_amdgcn_ballot_w64(f1);
+              const uint32_t n0 = (uint32_t)__builtin_popcountll(starts0);
+              const uint32_t own0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts0, ka - 1u)) + (f0 ? 1u : 0u);
+              const uint32_t own1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts1, ka + n0 - 1u)) + (f1 ? 1u : 0u);
+              ka += n0 + (uint32_t)__builtin_popcountll(starts1);
+              const uint32_t inf0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(own0 << 2), (int)info), inf1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(own1 << 2), (int)info);
+              const bool act1 = base2 + 64u + lane < s1;                             // (the first chunk of a pair is whole)
+              const bool m0 = (inf0 >> 31) == 0u, m1 = (inf1 >> 31) == 0u;
+              if (first) SCFQ_XFLUSH();
+              const sym_t ld0 = load_raw(m0 ? (pos + base2 + lane - inf0) << kSh : kOob);
+              const sym_t ld1 = load_raw((act1 && m1) ? (pos + base2 + 64u + lane - inf1) << kSh : kOob);
+              if (!first) SCFQ_XFLUSH();
+              pend_ld = ld0; pend_sel = m0 ? 0u : 0x100u | (inf0 & 0xFFu); pend_off = (pos + base2 + lane) << kSh;
+              pend2_ld = ld1; pend2_sel = m1 ? 0u : 0x100u | (inf1 & 0xFFu); pend2_off = act1 ? (pos + base2 + 64u + lane) << kSh : kOob;
+              first = 0;
+              base2 += 128u;
+            }
+            for (uint32_t base = base2; base < s1; base += 64u) {
+#else
             for (uint32_t base = s0; base < s1; base += 64u) {
+#endif
               // every lane is one output symbol: its owner is the symbol with the highest start at or below it
               SCFQ_LP_ADD(15, 1);
               scr[kC + lane] = 0u;
