@@ -129,11 +129,32 @@ def ingest_rows(scfq, nbytes):
         sc = os.path.join(ROOT, "seq-collection_amd", "sc")
         for name, path, how in (("gzip_member", gz, "one gzip member, zlib level 6, 64 MiB pieces joined by sync flushes (as pigz writes it)"),
                                 ("bgzf", bg, "BGZF (bgzip layout, 65280-byte blocks, level 6)")):
-            t = time.perf_counter()
-            r = subprocess.run([sc, "fq-count", path], capture_output=True, text=True)
-            cold = time.perf_counter() - t
-            f_ = r.stdout.strip().split("\t")
-            assert r.returncode == 0 and (int(f_[0]), int(f_[2]), int(f_[3]), int(f_[4])) == want, ("cold row", r.stdout, r.stderr[-500:], want)
+            # a fresh process three times over, each with --stats: the library's stage marks (ms since it was loaded) say where a slow
+            # one spent its time — runtime initialisation, context, allocations, first copy, first kernel, fold, exit
+            colds = []
+            for _ in range(3):
+                t = time.perf_counter()
+                r = subprocess.run([sc, "fq-count", "--stats", path], capture_output=True, text=True)
+                wall = time.perf_counter() - t
+                f_ = r.stdout.strip().split("\t")
+                assert r.returncode == 0 and (int(f_[0]), int(f_[2]), int(f_[3]), int(f_[4])) == want, ("cold row", r.stdout, r.stderr[-500:], want)
+                stages = None
+                for line in r.stderr.splitlines():
+                    if line.startswith("{") and "stages_ms" in line:
+                        try:
+                            stages = json.loads(line).get("stages_ms")
+                        except ValueError:
+                            pass
+                colds.append((wall, stages))
+            colds.sort(key=lambda x: x[0])
+            cold = colds[1][0]
+
+            def stage_row(wall, stages):
+                if not stages:
+                    return {"wall_ms": round(wall * 1e3, 1)}
+                row = {"wall_ms": round(wall * 1e3, 1), "marks": [[n, ms] for n, ms in stages]}
+                row["process_start_and_exit_ms"] = round(wall * 1e3 - stages[-1][1], 1)      # exec -> library loaded, plus row computed -> reaped
+                return row
             walls = []
             for _ in range(2):
                 t = time.perf_counter()
@@ -141,6 +162,10 @@ def ingest_rows(scfq, nbytes):
                 walls.append(time.perf_counter() - t)
                 assert (c.reads, c.gc_bases, c.n_bases, c.bases) == want, ("in-process row", name)
             rows[name] = {"layout": how, "compressed_bytes": os.path.getsize(path), "cold_process_wall_s": round(cold, 4), "cold_GBps": round(data.size / cold / 1e9, 2),
+                          "cold_process_walls_s": {"min": round(colds[0][0], 4), "median": round(colds[1][0], 4), "max": round(colds[2][0], 4),
+                                                   "what": "three fresh `sc fq-count --stats FILE` processes one after the other; cold_process_wall_s is their median"},
+                          "cold_stages_ms": {"median_run": stage_row(*colds[1]), "slowest_run": stage_row(*colds[2]),
+                                             "what": "[stage, ms since the library was loaded] (include/sc_fqcount_debug.h: scfq_debug_stages)"},
                           "first_call_wall_s": round(walls[0], 4), "warm_wall_s": round(walls[1], 4), "warm_GBps": round(data.size / walls[1] / 1e9, 2),
                           "counters_match_generator": True}
         rows["device_bytes_high_water"] = int(scfq.lib().scfq_device_bytes_high_water())
@@ -211,8 +236,10 @@ def main():
 
     kind = 0 if args.workload == "illumina" else 1
     # N=1: BASELINE configs[1] (10 GB, seed 20260101); N>1: configs[2] (25 GB per GPU = 200 GB / 8, seed 20260102)
-    seed = (SEED if world == 1 else 20260102) if kind == 0 else 20260103
     per = int(args.bytes_per_gpu) if args.bytes_per_gpu > 0 else int(10e9 if world == 1 else 25e9)
+    # `--bytes-per-gpu 25e9` at N=1 is the like-for-like anchor of the configs[2] curve: rank 0's 25 GB shard of the seed-20260102 stream
+    anchor = world == 1 and kind == 0 and args.bytes_per_gpu > 0 and per != int(10e9)
+    seed = (SEED if (world == 1 and not anchor) else 20260102) if kind == 0 else 20260103
     lo, hi = rank * per, (rank + 1) * per   # this rank's byte range of the N x per stream: arbitrary cut points
 
     # ---- build this rank's shard directly in HBM (not timed) ------------------------------------------
@@ -246,7 +273,8 @@ def main():
             if rank == 0:
                 import socket
                 s_ = socket.socket()
-                s_.bind(("127.0.0.1", 0))
+                # (probed on the address the library's rank 0 will bind — MASTER_ADDR — not on loopback whatever that is)
+                s_.bind((os.environ.get("MASTER_ADDR", "127.0.0.1"), 0))
                 port[0] = s_.getsockname()[1]
                 s_.close()
             if world > 1:
@@ -429,7 +457,11 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": (("synthetic %.0f GB uncompressed 150 bp Illumina FASTQ per GPU, HBM-resident (BASELINE configs[1])" % (per / 1e9))
+            "workload": (("synthetic %.0f GB uncompressed 150 bp Illumina FASTQ per GPU, HBM-resident (BASELINE configs[1]; the N>1 lines of this "
+                          "bench hold 25 GB per GPU — `--bytes-per-gpu 25e9` at N=1 is their like-for-like anchor)" % (per / 1e9))
+                         if (world == 1 and not anchor) else
+                         ("synthetic %.0f GB uncompressed 150 bp Illumina FASTQ on 1 GPU, HBM-resident: the N=1 anchor of the configs[2] curve "
+                          "(one shard of the seed-20260102 stream at the shard size of the N>1 lines; not BASELINE configs[1])" % (per / 1e9))
                          if world == 1 else
                          ("synthetic %.0f GB uncompressed 150 bp Illumina FASTQ byte-sharded across %d GPUs, %.0f GB per GPU, HBM-resident "
                           "(BASELINE configs[2]: 200 GB across 8 x MI355X + RCCL exchange%s)"

@@ -35,6 +35,14 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
  * practical read-stream ceiling on this device, reported next to the roofline by bench.py. Negative on error. */
 double scfq_debug_stream_ms(const void* device_ptr, uint64_t n, int reps);
 
+/* Diagnostic only: where this process's time went so far.  The library marks its stages (first device call returned, context up,
+ * buffers allocated, first copy queued, first kernel queued, session folded ...) with the milliseconds since it was loaded;
+ * scfq_debug_stages writes them as one JSON array of [name, ms] pairs and returns its length (the length needed, with nothing
+ * written, when cap is too small); scfq_debug_stage_mark lets the host add marks of its own (`sc`: main entered, rows out).
+ * `sc fq-count --stats` prints the array; bench.py's cold-process legs carry it. */
+int64_t scfq_debug_stages(char* buf, uint64_t cap);
+void scfq_debug_stage_mark(const char* what);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
 // Everything between "open the file" and "format the row" is one call into libsc_fqcount_hip.so.
 // GPU-only additions are new long options and never change the reference's 5-column row.
 #include "../../include/sc_fqcount.h"
+#include "../../include/sc_fqcount_debug.h"      // --stats: the library's stage marks
 
 #include <limits.h>
 #include <signal.h>
@@ -196,11 +197,17 @@ static FileResult fq_count_compute(const std::string& fastq, bool basename, bool
     std::snprintf(js, sizeof js,
                   "{\"file\": \"%s\", \"input_bytes\": %llu, \"scan_kernel_ms\": %.4f, \"fold_kernel_ms\": %.4f, "
                   "\"scan_launches\": %llu, \"scan_GBps\": %.1f, \"hbm_peak_GBps\": 8000, \"roofline_frac\": %.4f, "
-                  "\"host_fill_ms\": %.2f, \"ingest_wall_ms\": %.2f, \"h2d_bytes\": %llu, \"device_bytes_high_water\": %llu}\n",
+                  "\"host_fill_ms\": %.2f, \"ingest_wall_ms\": %.2f, \"h2d_bytes\": %llu, \"device_bytes_high_water\": %llu, \"stages_ms\": ",
                   fastq.c_str(), (unsigned long long)c.input_bytes, t.scan_kernel_ms, t.fold_kernel_ms,
                   (unsigned long long)t.scan_launches, gbs, gbs / 8000.0, t.host_fill_ms, t.ingest_wall_ms,
                   (unsigned long long)t.h2d_bytes, (unsigned long long)scfq_device_bytes_high_water());
     r.extra += js;
+    // where the process's time went up to this row: [name, ms since the library was loaded] (include/sc_fqcount_debug.h)
+    scfq_debug_stage_mark("sc: row computed");
+    std::string stages((size_t)scfq_debug_stages(nullptr, 0) + 1, '\0');
+    scfq_debug_stages(&stages[0], stages.size());
+    stages.resize(std::strlen(stages.c_str()));
+    r.extra += stages + "}\n";
   }
   return r;
 }
@@ -302,6 +309,7 @@ static int cmd_fq_meta(const std::vector<std::string>& params) {
 }
 
 int main(int argc, char** argv) {
+  scfq_debug_stage_mark("sc: main entered");
   signal(SIGPIPE, SIG_IGN);   // sc.nim:45-46
   std::vector<std::string> params(argv + 1, argv + argc);
   if (stdin_is_fifo())        // sc.nim:274-284

@@ -34,6 +34,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -52,12 +53,21 @@ thread_local char g_err[512] = "";
     }                                                                                         \
   } while (0)
 
-// SCFQ_VERBOSE: where a call's time goes, as milliseconds since the library was loaded (process start, near enough)
+// Where a call's time goes, as milliseconds since the library was loaded (process start, near enough).  Every stage mark is kept (the
+// first 256 of a process: a mark is a clock read and a push) and handed out by scfq_debug_stages() — `sc fq-count --stats` prints them,
+// bench.py's cold legs carry them —, and SCFQ_VERBOSE=1 also writes each one to stderr as it happens.
 const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
 inline bool trace_on() { static const bool v = std::getenv("SCFQ_VERBOSE") != nullptr; return v; }
+struct StageLog { std::mutex mu; std::vector<std::pair<std::string, double>> v; };
+inline StageLog& stage_log() { static StageLog* g = new StageLog; return *g; }      // (leaked on purpose: marks may come from exit paths)
 inline void trace(const char* what) {
-  if (!trace_on()) return;
-  std::fprintf(stderr, "scfq t+%8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_loaded).count(), what);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_loaded).count();
+  {
+    StageLog& g = stage_log();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.v.size() < 256) g.v.emplace_back(what, ms);
+  }
+  if (trace_on()) std::fprintf(stderr, "scfq t+%8.1f ms  %s\n", ms, what);
 }
 // device memory the library holds for ingest (staging, inflate buffers, arenas): current and high-water, per process
 std::atomic<uint64_t> g_dev_bytes{0}, g_dev_high{0};
@@ -123,6 +133,7 @@ struct GzShared {
   bool busy[kMax] = {false, false, false, false, false, false, false, false};
   int n_busy = 0;
   bool big_running = false;
+  int big_waiting = 0;                 // files of more than 1 GiB waiting for the pool to drain: no small file is admitted meanwhile
 };
 inline GzShared& gz_shared(int dev) { static GzShared g[64]; return g[dev & 63]; }
 
@@ -168,6 +179,11 @@ struct Ctx {
   uint8_t* d_inf[2] = {nullptr, nullptr};      // inflated chunks (kStagePad + inf_cap each)
   uint32_t* d_dstatus = nullptr;
   uint64_t comp_cap = 0, inf_cap = 0;
+  // the FIRST chunk of a BGZF file has small buffers of its own (64 MiB inflated): a process's first decode starts behind four small
+  // allocations, and the big double buffers above are allocated on a helper thread under it (ensure_bgzf_first / ingest_bgzf_device)
+  uint8_t* d_comp_first = nullptr;
+  uint8_t* d_inf_first = nullptr;
+  uint64_t comp_first_cap = 0, inf_first_cap = 0;
   uint8_t* h_pin[2] = {nullptr, nullptr};
   uint64_t stage_cap = 0;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_scanned[2] = {nullptr, nullptr};
@@ -197,36 +213,43 @@ thread_local uint64_t g_hist_stats[2] = {0, 0};   // ranges of the last session 
 int new_ctx(int dev, std::unique_ptr<Ctx>* out);
 
 std::map<int, int> g_ctx_creating;      // (under g_mu) contexts of a device being created right now
+std::condition_variable g_ctx_cv;       // a context joined a pool, or a creation ended (with or without one)
 
 int get_ctx(Ctx** out, SessionLock& sl) {
   int dev = 0;
+  { static std::once_flag once; std::call_once(once, [] { trace("first device call of the process (runtime initialisation starts)"); }); }
   HIPCHK(hipGetDevice(&dev));
+  { static std::once_flag once; std::call_once(once, [] { trace("runtime initialised (hipGetDevice returned)"); }); }
   static const int max_ctx = std::max(1, std::min(64, env_int("SCFQ_MAX_SESSIONS", 16)));
   Ctx* wait_on = nullptr;
   {
     std::unique_lock<std::mutex> lk(g_mu);
-    auto& pool = g_ctx[dev];
-    for (auto& c : pool) {
-      std::unique_lock<std::mutex> try_lk(c->mu, std::try_to_lock);
-      if (try_lk.owns_lock()) { sl.lk = std::move(try_lk); *out = c.get(); return SCFQ_OK; }
-    }
-    if ((int)pool.size() + g_ctx_creating[dev] < max_ctx) {
-      // a new context is made OUTSIDE the registry's lock (its streams and pinned words take tens of milliseconds): the sessions of
-      // `--jobs=N` set their contexts up side by side, not one after the other
-      ++g_ctx_creating[dev];
-      lk.unlock();
-      std::unique_ptr<Ctx> c;
-      const int rc = new_ctx(dev, &c);
-      lk.lock();
-      --g_ctx_creating[dev];
-      if (rc) return rc;
-      sl.lk = std::unique_lock<std::mutex>(c->mu);
-      *out = c.get();
-      g_ctx[dev].push_back(std::move(c));
-      return SCFQ_OK;
-    }
-    if (pool.empty()) {      // (every allowed context is still being created by another thread: wait for the first to appear)
-      while (g_ctx[dev].empty()) { lk.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); lk.lock(); }
+    for (;;) {
+      auto& pool = g_ctx[dev];
+      for (auto& c : pool) {
+        std::unique_lock<std::mutex> try_lk(c->mu, std::try_to_lock);
+        if (try_lk.owns_lock()) { sl.lk = std::move(try_lk); *out = c.get(); return SCFQ_OK; }
+      }
+      if ((int)pool.size() + g_ctx_creating[dev] < max_ctx) {
+        // a new context is made OUTSIDE the registry's lock (its streams and pinned words take tens of milliseconds): the sessions of
+        // `--jobs=N` set their contexts up side by side, not one after the other
+        ++g_ctx_creating[dev];
+        lk.unlock();
+        std::unique_ptr<Ctx> c;
+        const int rc = new_ctx(dev, &c);
+        lk.lock();
+        --g_ctx_creating[dev];
+        if (rc) { g_ctx_cv.notify_all(); return rc; }
+        sl.lk = std::unique_lock<std::mutex>(c->mu);
+        *out = c.get();
+        g_ctx[dev].push_back(std::move(c));
+        g_ctx_cv.notify_all();
+        return SCFQ_OK;
+      }
+      if (!pool.empty()) break;
+      // every allowed context is still being created by another thread: wait for the first to appear — or for the creators to give up
+      // (out of memory, no stream), in which case the loop comes round to try a creation of its own and returns ITS error
+      g_ctx_cv.wait(lk, [&] { return !g_ctx[dev].empty() || g_ctx_creating[dev] == 0; });
     }
     static unsigned rr = 0;
     wait_on = g_ctx[dev][rr++ % g_ctx[dev].size()].get();
@@ -306,9 +329,10 @@ int ensure_staging(Ctx* c, uint64_t chunk, bool pinned) {
       c->d_stage[b] = nullptr;
       c->h_pin[b] = nullptr;
     }
+    note_dev_bytes(-(int64_t)(2 * c->stage_cap));      // (what was freed above)
     c->stage_cap = 0;
     for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc(&c->d_stage[b], chunk));
-    note_dev_bytes((int64_t)(2 * chunk) - (int64_t)(2 * c->stage_cap));
+    note_dev_bytes((int64_t)(2 * chunk));
     c->stage_cap = chunk;
   }
   if (pinned) {
@@ -538,12 +562,21 @@ int check_opts(const scfq_opts* o) {
 // that names a device twice, so a list with repeats (several ingest sessions sharing one GPU to overlap file reads) folds
 // its partials on the host, as does SCFQ_EXCHANGE=host (a host that does not want librccl mapped for 256 bytes per rank).
 std::mutex g_comm_mu;
-std::map<std::vector<int>, std::vector<scfq_comm*>> g_comms;
+// A set is shared by the registry and by every session that is using it: a set that failed is taken OUT of the registry at once (the next
+// count builds a fresh one) but its communicators are only destroyed when the last session that still holds it lets go — another thread
+// may be parked on the set's mutex or inside its own exchange with copies of the same pointers.
+struct CommSet {
+  std::vector<scfq_comm*> comms;
+  std::mutex one_at_a_time;             // exchanges of concurrent sessions on the same communicators must not interleave
+  bool retired = false;                 // (under one_at_a_time) an exchange on this set failed: whoever comes next does not use it
+  ~CommSet() { for (scfq_comm* c : comms) if (c) scfq_comm_destroy(c); }
+};
+std::map<std::vector<int>, std::shared_ptr<CommSet>> g_comms;
 
 void release_comms() {
-  std::lock_guard<std::mutex> lk(g_comm_mu);
-  for (auto& kv : g_comms) for (scfq_comm* c : kv.second) scfq_comm_destroy(c);
-  g_comms.clear();
+  std::map<std::vector<int>, std::shared_ptr<CommSet>> gone;
+  { std::lock_guard<std::mutex> lk(g_comm_mu); gone.swap(g_comms); }
+  // (destroyed here, outside the registry's lock, unless a session still holds a set: then when that session ends)
 }
 
 bool exchange_on_host(const int32_t* ids, int nd) {
@@ -561,51 +594,63 @@ int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_part
     for (int d = 0; d < nd; ++d) scfq_partial_combine(p, &parts[d], want_hist ? hist : nullptr, want_hist ? hists[d].data() : nullptr);
     return SCFQ_OK;
   }
-  std::vector<scfq_comm*> comms;
+  std::shared_ptr<CommSet> set, given_up;      // (given_up: destroyed — if this is its last holder — after the registry's lock is released)
   std::vector<int> key(o.device_ids, o.device_ids + nd);
   {
     std::lock_guard<std::mutex> lk(g_comm_mu);
     auto it = g_comms.find(key);
     if (it != g_comms.end()) {
       // a set with a broken member (an exchange timed out) is given up here, so that one stuck collective does not fail
-      // every later multi-device count of the process: the next lines build a fresh set
+      // every later multi-device count of the process: the next lines build a fresh set (the old one goes when its last user does)
       bool broken = false;
-      for (scfq_comm* c : it->second) broken = broken || scfq_comm_is_broken(c);
-      if (broken) { for (scfq_comm* c : it->second) scfq_comm_destroy(c); g_comms.erase(it); it = g_comms.end(); }
+      for (scfq_comm* c : it->second->comms) broken = broken || scfq_comm_is_broken(c);
+      if (broken) { given_up = std::move(it->second); g_comms.erase(it); it = g_comms.end(); }
     }
     if (it == g_comms.end()) {
-      std::vector<scfq_comm*> cs(nd, nullptr);
-      const int rc = scfq_comm_init_all(nd, o.device_ids, 0, cs.data());
+      auto fresh = std::make_shared<CommSet>();
+      fresh->comms.assign((size_t)nd, nullptr);
+      const int rc = scfq_comm_init_all(nd, o.device_ids, 0, fresh->comms.data());
       if (rc) { std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return rc; }
-      it = g_comms.emplace(key, cs).first;
+      it = g_comms.emplace(key, std::move(fresh)).first;
     }
-    comms = it->second;
+    set = it->second;
   }
   if (!p) return SCFQ_OK;               // scfq_prepare(): only the communicators were wanted
-  static std::mutex one_at_a_time;      // exchanges of concurrent sessions on the same communicators must not interleave
-  std::lock_guard<std::mutex> lk(one_at_a_time);
+  const std::vector<scfq_comm*>& comms = set->comms;
   int rc = SCFQ_OK;
-  int started = 0;
-  for (int d = 0; d < nd && !rc; ++d) {
-    rc = scfq_comm_exchange_start(comms[d], &parts[d], want_hist ? hists[d].data() : nullptr, 0);
-    if (!rc) ++started;
-  }
-  if (rc) std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail());
-  std::vector<uint64_t> h2(want_hist ? SCFQ_HIST_WORDS : 0);
-  for (int d = 0; d < started; ++d) {
-    scfq_partial q;
-    const int r = scfq_comm_exchange_finish(comms[d], d == 0 ? p : &q, want_hist ? (d == 0 ? hist : h2.data()) : nullptr, 0);
-    if (r && !rc) { rc = r; std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); }
-    if (!r && !rc && d > 0 && (std::memcmp(&q, p, sizeof q) != 0 || (want_hist && std::memcmp(h2.data(), hist, SCFQ_HIST_WORDS * sizeof(uint64_t)) != 0))) {
-      std::snprintf(g_err, sizeof g_err, "exchange: rank %d folded a different result than rank 0", d);
-      rc = SCFQ_ERCCL;
+  {
+    std::lock_guard<std::mutex> lk(set->one_at_a_time);
+    // (a set that broke while this session waited for its turn: not used, the caller's count fails like the one that broke it)
+    if (set->retired) rc = SCFQ_ERCCL;
+    for (scfq_comm* c : comms) if (scfq_comm_is_broken(c)) rc = SCFQ_ERCCL;
+    if (rc) std::snprintf(g_err, sizeof g_err, "exchange: the communicator set was broken by an earlier exchange");
+    int started = 0;
+    for (int d = 0; d < nd && !rc; ++d) {
+      rc = scfq_comm_exchange_start(comms[d], &parts[d], want_hist ? hists[d].data() : nullptr, 0);
+      if (!rc) ++started;
+      else std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail());
     }
+    std::vector<uint64_t> h2(want_hist ? SCFQ_HIST_WORDS : 0);
+    for (int d = 0; d < started; ++d) {
+      scfq_partial q;
+      const int r = scfq_comm_exchange_finish(comms[d], d == 0 ? p : &q, want_hist ? (d == 0 ? hist : h2.data()) : nullptr, 0);
+      if (r && !rc) { rc = r; std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); }
+      if (!r && !rc && d > 0 && (std::memcmp(&q, p, sizeof q) != 0 || (want_hist && std::memcmp(h2.data(), hist, SCFQ_HIST_WORDS * sizeof(uint64_t)) != 0))) {
+        std::snprintf(g_err, sizeof g_err, "exchange: rank %d folded a different result than rank 0", d);
+        rc = SCFQ_ERCCL;
+      }
+    }
+    if (rc) set->retired = true;
   }
   if (rc) {
-    // whatever went wrong, this set is not used again (a started exchange that was never finished would answer the next one)
-    std::lock_guard<std::mutex> lk2(g_comm_mu);
-    auto it = g_comms.find(key);
-    if (it != g_comms.end() && it->second == comms) { for (scfq_comm* c : comms) scfq_comm_destroy(c); g_comms.erase(it); }
+    // whatever went wrong, this set is not handed out again (a started exchange that was never finished would answer the next one);
+    // it is destroyed when the last session holding it — this one, or one still waiting for its turn above — drops it
+    {
+      std::lock_guard<std::mutex> lk2(g_comm_mu);
+      auto it = g_comms.find(key);
+      if (it != g_comms.end() && it->second == set) g_comms.erase(it);
+    }
+    set.reset();
   }
   return rc;
 }
@@ -710,8 +755,41 @@ bool bgzf_is_pure(const uint8_t* img, uint64_t n) {
   return n > 0;
 }
 
+// block tables (device + pinned) of both slots and the status word: small, allocated once per context
+bool ensure_bgzf_tables(Ctx* c) {
+  bool ok = true;
+  for (int b = 0; b < 2 && ok; ++b) {
+    if (!c->d_blk[b]) ok = hipMalloc(&c->d_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block)) == hipSuccess;
+    if (ok && !c->h_blk[b]) ok = hipHostMalloc(&c->h_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block), hipHostMallocDefault) == hipSuccess;
+  }
+  if (ok && !c->d_dstatus) ok = hipMalloc(&c->d_dstatus, sizeof(uint32_t)) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  return ok;
+}
+
+// The first chunk's own buffers: kBgzfFirstInflated of inflated bytes (1024 members of the maximum size) and as much of compressed
+// ones (a member that does not compress is a stored block: its deflate data is a few bytes longer than what it holds).
+constexpr uint64_t kBgzfFirstInflated = 64ull << 20;
+int ensure_bgzf_first(Ctx* c) {
+  if (c->d_comp_first && c->d_inf_first) return SCFQ_OK;
+  bool ok = ensure_bgzf_tables(c);
+  if (ok && !c->d_comp_first) ok = hipMalloc(&c->d_comp_first, kBgzfFirstInflated + 64) == hipSuccess;
+  if (ok && !c->d_inf_first) ok = hipMalloc(&c->d_inf_first, kBgzfFirstInflated + kStagePad) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (c->d_comp_first) (void)hipFree(c->d_comp_first);
+    if (c->d_inf_first) (void)hipFree(c->d_inf_first);
+    c->d_comp_first = c->d_inf_first = nullptr;
+    return kFallbackToHost;
+  }
+  c->comp_first_cap = c->inf_first_cap = kBgzfFirstInflated;
+  note_dev_bytes((int64_t)(2 * kBgzfFirstInflated));
+  trace("BGZF first-chunk buffers allocated");
+  return SCFQ_OK;
+}
+
 // buffers of the device-inflate path; kFallbackToHost when they cannot be had (nothing queued yet)
-int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
+int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize, bool on_helper = false) {
   // One wave inflates one member and a member is slow on its own (a serial bit stream): the kernel needs thousands of
   // members per launch to fill 256 CUs, so the device path works in large inflated chunks (up to 1 GiB, i.e. ~16 K
   // members) whatever the staging chunk of the host path is; compressed chunks are a third to a quarter of that.
@@ -720,21 +798,23 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
   const uint64_t want_inf = std::min<uint64_t>(max_inf, std::max<uint64_t>(64ull << 20, (fsize * 5 + 4095) & ~4095ull));
   const uint64_t want_comp = std::min<uint64_t>(want_inf / 2, std::max<uint64_t>(32ull << 20, (fsize + 4095) & ~4095ull));
   if (c->comp_cap < want_comp || c->inf_cap < want_inf) {
-    HIPCHK(hipStreamSynchronize(c->compute));
-    HIPCHK(hipStreamSynchronize(c->copy));
+    // (on the helper thread of ingest_bgzf_device the streams carry the first chunk of the NEW call, which does not touch these
+    // buffers; the call before ended with both streams idle)
+    if (!on_helper) {
+      HIPCHK(hipStreamSynchronize(c->compute));
+      HIPCHK(hipStreamSynchronize(c->copy));
+    }
     for (int b = 0; b < 2; ++b) {
       if (c->d_comp[b]) HIPCHK(hipFree(c->d_comp[b]));
       if (c->d_inf[b]) HIPCHK(hipFree(c->d_inf[b]));
       c->d_comp[b] = nullptr; c->d_inf[b] = nullptr;
     }
+    note_dev_bytes(-(int64_t)(2 * (c->comp_cap + c->inf_cap)));      // (what was freed above)
     c->comp_cap = c->inf_cap = 0;
     bool ok = true;
-    for (int b = 0; b < 2 && ok; ++b) {
+    for (int b = 0; b < 2 && ok; ++b)
       ok = hipMalloc(&c->d_comp[b], want_comp + 64) == hipSuccess && hipMalloc(&c->d_inf[b], want_inf + kStagePad) == hipSuccess;
-      if (ok && !c->d_blk[b]) ok = hipMalloc(&c->d_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block)) == hipSuccess;
-      if (ok && !c->h_blk[b]) ok = hipHostMalloc(&c->h_blk[b], kMaxBlocksPerChunk * sizeof(scfq_dinflate::Block), hipHostMallocDefault) == hipSuccess;
-    }
-    if (ok && !c->d_dstatus) ok = hipMalloc(&c->d_dstatus, sizeof(uint32_t)) == hipSuccess;
+    ok = ok && ensure_bgzf_tables(c);
     if (!ok) {
       // not enough device / pinned memory for the big chunks (many concurrent sessions): nothing was queued yet, so the
       // caller can still take the host inflate path
@@ -746,7 +826,7 @@ int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize) {
       }
       return kFallbackToHost;
     }
-    note_dev_bytes((int64_t)(2 * (want_comp + want_inf)) - (int64_t)(2 * (c->comp_cap + c->inf_cap)));
+    note_dev_bytes((int64_t)(2 * (want_comp + want_inf)));
     c->comp_cap = want_comp;
     c->inf_cap = want_inf;
     trace("BGZF device buffers allocated");
@@ -785,7 +865,9 @@ static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, int launch = 3)
 int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1) {
   // (bgzf_inflate keeps 72 bytes of scratch per lane and the runtime sets the device's scratch up inside the first launch of such
   // a kernel — 35 - 50 ms on the launching thread: an empty launch on a helper thread, under the buffers' allocation and the first copy)
-  struct Warm { std::thread th; ~Warm() { if (th.joinable()) th.join(); } } warm;
+  struct Helper { std::thread th; ~Helper() { if (th.joinable()) th.join(); } };
+  Helper warm, alloc;          // (declared before everything that they touch: joined last)
+  int alloc_rc = SCFQ_OK;
   if (!c->bgzf_warmed) {
     c->bgzf_warmed = true;
     hipStream_t st = c->compute;
@@ -795,11 +877,16 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
       hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3(1), dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, st,
                          (const uint8_t*)nullptr, (const scfq_dinflate::Block*)nullptr, 0u, (uint8_t*)nullptr, (uint32_t*)nullptr, 0u);
       (void)hipGetLastError();
+      trace("bgzf_inflate's empty first launch returned (device scratch set up)");
     });
   }
-  int rc = ensure_bgzf_device_buffers(c, fsize);
+  // The first chunk is SMALL and has buffers of its own (64 MiB inflated: four allocations of tens of MiB), so that the first members are
+  // being inflated a few milliseconds into the call; the big double buffers (up to 2 x 1.5 GiB) are allocated on a helper thread under
+  // that chunk's copy and decode, and only a file that goes on behind its first chunk waits for them.  Round 3 allocated everything up
+  // front: whatever a big allocation costs on a given box at a given moment (the driver's cold BGZF process of BENCH_r03 took 3.4 s
+  // before its first kernel where the builder's took 0.1 s) was paid before the first byte moved.
+  int rc = ensure_bgzf_first(c);
   if (rc) return rc;
-  const uint64_t chunk = c->inf_cap, comp_chunk = c->comp_cap;
   HIPCHK(hipMemsetAsync(c->d_dstatus, 0, sizeof(uint32_t), c->compute));
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
@@ -813,38 +900,63 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
   uint64_t prev_n = 0;
   for (unsigned it = 0; pos < fsize; ++it) {
     const int b = it & 1;
-    if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));      // pinned buffer + pinned table b are free again
+    if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));      // pinned table b is free again
+    if (it == 1 && alloc.th.joinable()) {
+      alloc.th.join();
+      if (alloc_rc) {
+        // no room for the big buffers (many concurrent sessions): the first chunk is in flight — drained here, and the caller starts
+        // the session again on the host path (kNotPureBgzf's contract)
+        (void)hipStreamSynchronize(c->copy);
+        (void)hipStreamSynchronize(c->compute);
+        return alloc_rc == kFallbackToHost ? kNotPureBgzf : alloc_rc;
+      }
+    }
+    const bool first = it == 0;
+    const uint64_t chunk = first ? c->inf_first_cap : c->inf_cap, comp_chunk = first ? c->comp_first_cap : c->comp_cap;
+    uint8_t* const d_comp = first ? c->d_comp_first : c->d_comp[b];
+    uint8_t* const d_inf = first ? c->d_inf_first : c->d_inf[b];
     const auto tf = clk::now();
     uint32_t nb = 0;
     uint64_t ob = 0;
-    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, bgzf_members_per_launch(chunk, (int)std::min(it, 3u)), c->h_blk[b], &nb, &ob);
+    const uint32_t members = first ? (uint32_t)(kBgzfFirstInflated >> 16) : bgzf_members_per_launch(chunk, (int)std::min(it, 3u));
+    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, members, c->h_blk[b], &nb, &ob);
     if (used < 0) {                                    // not a BGZF member, or a truncated one: the host path decides what it is
       HIPCHK(hipStreamSynchronize(c->copy));
       HIPCHK(hipStreamSynchronize(c->compute));
       return kNotPureBgzf;
     }
     if (used == 0) break;
+    if (first && (uint64_t)used < fsize) {
+      // more than one chunk: the big buffers, sized by the file, on a helper thread under this chunk's copy and decode
+      const int dev = c->dev;
+      alloc.th = std::thread([c, fsize, dev, &alloc_rc] {
+        if (hipSetDevice(dev) != hipSuccess) { alloc_rc = SCFQ_EHIP; return; }
+        alloc_rc = ensure_bgzf_device_buffers(c, fsize, true);
+      });
+    }
     const uint8_t* src = img + pos;
     c->timing.h2d_bytes += (uint64_t)used;
-    if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));       // device buffers b were consumed
+    if (it >= 3) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));       // device buffers b were consumed (chunk 0 had its own)
     if (timing) {
       while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
       HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
     }
-    if ((rc = copy_through_ring(c, c->d_comp[b], src, (uint64_t)used))) return rc;
+    if ((rc = copy_through_ring(c, d_comp, src, (uint64_t)used))) return rc;
     fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
     if (timing) { HIPCHK(hipEventRecord(c->cp_pool[c->cp_used + 1], c->copy)); c->cp_used += 2; }
     HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
+    if (first) trace("BGZF: first chunk's compressed bytes queued for the device");
     HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));
-    uint8_t* base = c->d_inf[b] + kStagePad;
+    uint8_t* base = d_inf + kStagePad;
     if (prev_base) HIPCHK(hipMemcpyAsync(base - 1, prev_base + prev_n - 1, 1, hipMemcpyDeviceToDevice, c->compute));
     if (warm.th.joinable()) warm.th.join();
     if (nb) {
       hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
                          dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
-                         c->d_comp[b], c->d_blk[b], nb, base, c->d_dstatus, inflate_serial_loop());
+                         d_comp, c->d_blk[b], nb, base, c->d_dstatus, inflate_serial_loop());
       HIPCHK(hipGetLastError());
+      if (first) trace("BGZF: first inflate kernel queued");
       // measurement aid: one line per bgzf_inflate dispatch (members, compressed bytes, inflated bytes), in dispatch order, so
       // that a rocprofv3 kernel trace of the same run can be priced in GB/s per dispatch (scripts/gpu_profile_inflate.sh)
       if (const char* lp = std::getenv("SCFQ_BGZF_LAUNCH_LOG")) {
@@ -918,6 +1030,27 @@ int scfq_debug_hist_stats(uint64_t* fast_ranges, uint64_t* redone_ranges) {
   if (redone_ranges) *redone_ranges = g_hist_stats[1];
   return SCFQ_OK;
 }
+
+// the stage marks of this process so far as one JSON array of [name, ms since the library was loaded]; returns the length written
+// (without the terminator), or the length needed when cap is too small (nothing is written then)
+int64_t scfq_debug_stages(char* buf, uint64_t cap) {
+  std::string js = "[";
+  {
+    StageLog& g = stage_log();
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (size_t k = 0; k < g.v.size(); ++k) {
+      char num[48];
+      std::snprintf(num, sizeof num, "\", %.2f]", g.v[k].second);
+      js += k ? ", [\"" : "[\"";
+      for (char ch : g.v[k].first) if (ch != '"' && ch != '\\' && (unsigned char)ch >= 32) js += ch;
+      js += num;
+    }
+  }
+  js += "]";
+  if (buf && cap > js.size()) std::memcpy(buf, js.c_str(), js.size() + 1);
+  return (int64_t)js.size();
+}
+void scfq_debug_stage_mark(const char* what) { if (what) trace(what); }
 
 uint64_t scfq_device_bytes_high_water(void) { return g_dev_high.load(); }
 uint64_t scfq_device_bytes_now(void) { return g_dev_bytes.load(); }
@@ -1004,6 +1137,7 @@ static int count_buffer_once(const void* ptr, uint64_t n, int is_device, const s
 }
 
 static int count_file_once(const char* path, const scfq_opts* opts, scfq_counts* out) {
+  trace("scfq_count_file entered");
   if (!path || !out || out->struct_size != sizeof(scfq_counts)) return SCFQ_EARG;
   int rc = check_opts(opts);
   if (rc) return rc;
@@ -1401,6 +1535,10 @@ int scfq_shutdown(void) {
       if (c->ev_piece[b]) (void)hipEventDestroy(c->ev_piece[b]);
     }
     if (c->d_dstatus) (void)hipFree(c->d_dstatus);
+    if (c->d_comp_first) (void)hipFree(c->d_comp_first);
+    if (c->d_inf_first) (void)hipFree(c->d_inf_first);
+    // (what scfq_device_bytes_now() counted for this context goes with it)
+    note_dev_bytes(-(int64_t)(2 * c->stage_cap + 2 * (c->comp_cap + c->inf_cap) + c->comp_first_cap + c->inf_first_cap));
     { GzShared& gs = gz_shared(c->dev); std::lock_guard<std::mutex> lk(gs.mu); for (int e = 0; e < GzShared::kMax; ++e) gz_free(&gs.buf[e]); }
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);

@@ -66,7 +66,11 @@ class SymPool {
       *delta = (int64_t)(2 * cap);
       used_ = 0;
     }
-    *off = (uint64_t)(chunks_[cur_].p - chunks_[0].p) + used_;      // (two's complement when the chunk lies below the first one)
+    // (the chunks are unrelated allocations: their distance is taken between ADDRESSES — two's complement when the chunk lies below the
+    // first one; hipMalloc hands out 256-byte-aligned pointers, so the division by the symbol size is exact, and an arithmetic shift
+    // keeps a negative distance negative)
+    const int64_t dist = (int64_t)((uintptr_t)chunks_[cur_].p - (uintptr_t)chunks_[0].p);
+    *off = (uint64_t)(dist >> 1) + used_;
     used_ += n;
     return hipSuccess;
   }

@@ -146,8 +146,10 @@ bool resolve(const char* host, int port, sockaddr_in* sa) {
 struct Star {
   int world = 1, rank = 0;
   std::vector<int> fds;
-  // shared secret of one launch (FNV-1a of SCFQ_RENDEZVOUS_TOKEN; 0 when unset): a process that does not know it cannot take a
-  // rank's slot.  Rank 0 binds to 127.0.0.1 unless the host names another address explicitly.
+  // Label of one launch (FNV-1a of SCFQ_RENDEZVOUS_TOKEN; 0 when unset).  It guards against COLLISIONS — two launches that picked
+  // the same port, a stale rank of an earlier run — and is NOT authentication: the hash crosses the wire in clear text and can be
+  // replayed.  The rendezvous is meant for one node: rank 0 binds to 127.0.0.1 unless the host names another address explicitly,
+  // and a host that does so is expected to do it on a network it trusts.
   static uint64_t token() {
     static const uint64_t t = [] {
       const char* e = std::getenv("SCFQ_RENDEZVOUS_TOKEN");
@@ -191,11 +193,19 @@ struct Star {
         // deadline; with SCFQ_RENDEZVOUS_TOKEN set in the launcher's environment the hello must carry that token too)
         int32_t hello[4] = {0, 0, 0, 0};
         const auto hello_deadline = std::min(deadline, clk::now() + std::chrono::seconds(1));
-        if (!io_all(fd, hello, sizeof hello, false, hello_deadline) || hello[0] != 0x53434651 || hello[1] <= 0 || hello[1] >= world ||
-            hello[2] != (int32_t)(uint32_t)token() || hello[3] != (int32_t)(uint32_t)(token() >> 32) || fds[hello[1]] >= 0) {
-          close(fd);     // not one of ours (or a duplicate rank): ignore it and keep waiting
+        if (!io_all(fd, hello, sizeof hello, false, hello_deadline) || hello[0] != 0x53434651) {
+          close(fd);     // not one of ours (or too slow to say so: a genuine rank sees the close and connects again)
           continue;
         }
+        // A peer that speaks the protocol gets a VERDICT word back, so that a rank that was turned away learns it here and now —
+        // not later, as an unrelated failure of the id exchange: 1 = slot taken, 2 = wrong token, 3 = that rank is already here,
+        // 4 = no such rank in this world.
+        int32_t verdict = 1;
+        if (hello[2] != (int32_t)(uint32_t)token() || hello[3] != (int32_t)(uint32_t)(token() >> 32)) verdict = 2;
+        else if (hello[1] <= 0 || hello[1] >= world) verdict = 4;
+        else if (fds[hello[1]] >= 0) verdict = 3;
+        const bool told = io_all(fd, &verdict, sizeof verdict, true, std::min(deadline, clk::now() + std::chrono::seconds(1)));
+        if (verdict != 1 || !told) { close(fd); continue; }
         fds[hello[1]] = fd;
         ++have;
       }
@@ -208,9 +218,18 @@ struct Star {
       if (connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof sa) == 0) {
         setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
         int32_t hello[4] = {0x53434651, rank, (int32_t)(uint32_t)token(), (int32_t)(uint32_t)(token() >> 32)};
-        if (!io_all(fd, hello, sizeof hello, true, deadline)) { close(fd); return false; }
-        fds[0] = fd;
-        return true;
+        int32_t verdict = 0;
+        if (io_all(fd, hello, sizeof hello, true, deadline) && io_all(fd, &verdict, sizeof verdict, false, deadline)) {
+          if (verdict == 1) { fds[0] = fd; return true; }
+          close(fd);
+          set_err("rendezvous: rank 0 at %s:%d turned rank %d away: %s", host ? host : "127.0.0.1", port, rank,
+                  verdict == 2 ? "SCFQ_RENDEZVOUS_TOKEN differs (another launch on the same port?)"
+                  : verdict == 3 ? "a process with this rank is already connected"
+                  : verdict == 4 ? "no such rank in its world (different --shard-world?)" : "unknown verdict");
+          return false;
+        }
+        // (no verdict: whoever listens there closed the connection — rank 0 does that to a hello that took more than a second — or
+        // is not rank 0 at all: try again until the deadline)
       }
       close(fd);
       if (ms_left(deadline) == 0) { set_err("rendezvous: rank 0 at %s:%d did not answer before the deadline", host ? host : "127.0.0.1", port); return false; }

@@ -338,6 +338,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     note_dev_bytes((int64_t)g.wcarry_cap - (int64_t)w0);
   }
   uint8_t* d_out = nullptr;                            // (set when the first batch's bytes get their room)
+  trace("gzip engine: plan made, tables and compressed-byte buffers allocated");
   const double alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
   if (verbose) std::fprintf(stderr, "scfq gzdev: plan + tables in %.1f ms: %u batch(es), segments of %llu KiB, %.2f symbols per compressed byte assumed, literal classes the search rules out 0x%02x\n", alloc_ms, nb,
                             (unsigned long long)(seg_bytes >> 10), ratio_est, lit_mask);
@@ -352,6 +353,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
                                            : comp > (1ull << 30) ? (128ull << 20) : comp > (256ull << 20) ? (64ull << 20) : (16ull << 20);
   rc = ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
   if (rc) return rc;
+  trace("gzip engine: pinned ring ready");
   const uint64_t pin_chunk = want_piece;
 
   // ---- measurement aid (SCFQ_VERBOSE): device time of the stages, summed over the batches ---------------------------------------
@@ -432,6 +434,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     if (verbose) (void)hipEventRecord(cp.spans.back().b, c->copy);
     HIPCHK(hipEventRecord(g.ev_copy[cb], c->copy));
     cp.bytes += b1 - b0;
+    if (k == 0) trace("gzip engine: first batch's compressed bytes queued for the device");
     cp.fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     return SCFQ_OK;
   };
@@ -555,6 +558,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       span_end(sp_decode, sd);
     }
     HIPCHK(hipEventRecord(g.ev_dec[k % n_slots], sd));
+    if (k == 0) trace("gzip engine: first decode kernel queued");
     n_decoded_total += n_seg;
     return SCFQ_OK;
   };
@@ -889,6 +893,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     valid = valid_end;
     finished = finished_end;
     release_comp(k);
+    if (k == 0) trace("gzip engine: first batch walked, its windows / bytes / CRC / scan queued");
     return SCFQ_OK;
   };
 
@@ -1021,7 +1026,11 @@ int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags,
   int e = -1;
   {
     std::unique_lock<std::mutex> lk(gs.mu);
-    gs.cv.wait(lk, [&] { return !gs.big_running && (big ? gs.n_busy == 0 : gs.n_busy < n_engines); });
+    // (a big file waits for the pool to drain, and while one waits no further small file is admitted: a steady stream of small
+    // sessions would otherwise keep n_busy above zero for ever and the big one — which holds its context all along — would starve)
+    if (big) ++gs.big_waiting;
+    gs.cv.wait(lk, [&] { return !gs.big_running && (big ? gs.n_busy == 0 : (gs.big_waiting == 0 && gs.n_busy < n_engines)); });
+    if (big) --gs.big_waiting;
     for (int k = 0; k < n_engines; ++k) if (!gs.busy[k]) { e = k; break; }
     gs.busy[e] = true;
     ++gs.n_busy;

@@ -174,3 +174,26 @@ def test_hist_class_algebra(scfq):
     scfq.combine(acc, shard(4, 2))
     with pytest.raises(scfq.ScfqError):
         scfq.finalize(acc, h)
+
+
+def test_stage_marks_are_json(scfq):
+    """scfq_debug_stages: [name, ms since the library was loaded] pairs, in order — what `sc fq-count --stats` prints and bench.py's
+    cold-process legs carry"""
+    import json
+    L = scfq.lib()
+    L.scfq_debug_stages.restype = ctypes.c_int64
+    L.scfq_debug_stages.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+    L.scfq_debug_stage_mark.argtypes = [ctypes.c_char_p]
+    L.scfq_debug_stage_mark.restype = None
+    L.scfq_debug_stage_mark(b'test: a mark with "quotes" and a \\ backslash')
+    L.scfq_debug_stage_mark(b"test: second")
+    need = L.scfq_debug_stages(None, 0)
+    assert need > 10
+    buf = ctypes.create_string_buffer(need + 1)
+    assert L.scfq_debug_stages(buf, need + 1) == need
+    marks = json.loads(buf.value.decode())
+    names = [m[0] for m in marks]
+    assert names[-1] == "test: second" and names[-2].startswith("test: a mark with quotes")
+    assert all(isinstance(m[1], float) for m in marks) and marks[-1][1] >= marks[-2][1] >= 0
+    small = ctypes.create_string_buffer(4)
+    assert L.scfq_debug_stages(small, 4) == need and small.value == b""

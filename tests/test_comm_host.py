@@ -107,6 +107,46 @@ def test_missing_rank_is_an_error_not_a_hang(scfq):
     assert time.time() - t0 < 20
 
 
+def _token_worker(rank, world, port, token, timeout_ms, q):
+    sys.path.insert(0, os.path.join(PKG, "pyhost"))
+    if token:
+        os.environ["SCFQ_RENDEZVOUS_TOKEN"] = token
+    import scfq
+    t0 = time.time()
+    try:
+        comm = scfq.Comm.init_rendezvous("127.0.0.1", port, world, rank, transport=scfq.SCFQ_COMM_TCP, timeout_ms=timeout_ms)
+        q.put((rank, "up", time.time() - t0))
+        comm.destroy()
+    except scfq.ScfqError as e:
+        q.put((rank, "rc=%d %s" % (e.rc, e), time.time() - t0))
+
+
+def test_a_rank_that_is_turned_away_learns_it_at_once(scfq):
+    """rank 0 answers every hello with a verdict word: a rank with another launch's token, and a rank number outside rank 0's world, fail
+    FAST with the reason (not at the deadline, and not later with an unrelated message of the id exchange), while rank 0 keeps
+    waiting for its real rank — which then arrives and is admitted"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    r0 = ctx.Process(target=_token_worker, args=(0, 2, port, "launch-A", 20000, q))
+    r0.start()
+    time.sleep(0.5)
+    wrong = ctx.Process(target=_token_worker, args=(1, 2, port, "launch-B", 20000, q))
+    wrong.start()
+    rank, what, dt = q.get(timeout=30)
+    assert rank == 1 and "rc=%d" % scfq.SCFQ_ERCCL in what and "SCFQ_RENDEZVOUS_TOKEN differs" in what and dt < 5, (what, dt)
+    stray = ctx.Process(target=_token_worker, args=(2, 3, port, "launch-A", 20000, q))      # (a rank of a launch with another --shard-world)
+    stray.start()
+    rank, what, dt = q.get(timeout=30)
+    assert rank == 2 and "no such rank" in what and dt < 5, (what, dt)
+    good = ctx.Process(target=_token_worker, args=(1, 2, port, "launch-A", 20000, q))
+    good.start()
+    got = sorted(q.get(timeout=30)[:2] for _ in range(2))
+    assert got == [(0, "up"), (1, "up")], got
+    for p in (r0, wrong, stray, good):
+        p.join(timeout=30)
+
+
 def _half_worker(rank, port, q):
     sys.path.insert(0, os.path.join(PKG, "pyhost"))
     import scfq
