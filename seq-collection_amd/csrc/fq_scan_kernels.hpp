@@ -66,6 +66,9 @@ constexpr int kQWords = 256 * kQRep;
 #define SCFQ_QWAVES 8
 #endif
 constexpr int kQWaves = SCFQ_QWAVES;   // waves (= ranges) per workgroup of the speculative form: they share one histogram
+#ifndef SCFQ_QOCC
+#define SCFQ_QOCC 5                    // waves per SIMD the speculative form is compiled for (the register budget the compiler is given)
+#endif
 constexpr uint32_t kNoGuess = 255u;
 
 // ------------------------------------------------------------------------------------------------
@@ -186,10 +189,12 @@ __device__ __forceinline__ void transpose4x4(uint32_t a, uint32_t b, uint32_t c,
 // Cost per 64-byte lane: 32 v_perm + 96 cheap ops for the planes, then 8 v_bitop3 per symbol — against
 // 48 (xor/add, shift, merge) ops per symbol for the carry-SWAR form it replaced.
 struct PlaneConsts {
-  uint32_t m1, m1s, m2, m2s, m4, m4s;   // swap masks and their shifted forms, pinned in VGPRs (an SGPR source halves the issue rate)
+  uint32_t m1, m2, m4;   // swap masks, pinned in VGPRs (an SGPR source halves the issue rate; VOP3 takes no literal on gfx9).  The
+                         // shifted form of a mask is its complement, and a complemented select is the same v_bitop3 with its
+                         // operands swapped: three registers, not six
   __device__ __forceinline__ void init() {
-    m1 = 0x55555555u; m1s = 0xAAAAAAAAu; m2 = 0x33333333u; m2s = 0xCCCCCCCCu; m4 = 0x0F0F0F0Fu; m4s = 0xF0F0F0F0u;
-    asm volatile("" : "+v"(m1), "+v"(m1s), "+v"(m2), "+v"(m2s), "+v"(m4), "+v"(m4s));
+    m1 = 0x55555555u; m2 = 0x33333333u; m4 = 0x0F0F0F0Fu;
+    asm volatile("" : "+v"(m1), "+v"(m2), "+v"(m4));
   }
 };
 
@@ -197,21 +202,21 @@ struct PlaneConsts {
 __device__ __forceinline__ uint32_t bsel(uint32_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA); }
 
 template <int S>
-__device__ __forceinline__ void plane_swap(uint32_t& lo, uint32_t& hi, uint32_t m, uint32_t ms) {
-  // exchange the bits of `lo` selected by (m << S) with the bits of `hi` selected by m
-  const uint32_t nlo = bsel(ms, hi << S, lo);
+__device__ __forceinline__ void plane_swap(uint32_t& lo, uint32_t& hi, uint32_t m) {
+  // exchange the bits of `lo` selected by (m << S) = ~m with the bits of `hi` selected by m
+  const uint32_t nlo = bsel(m, lo, hi << S);
   const uint32_t nhi = bsel(m, lo >> S, hi);
   lo = nlo; hi = nhi;
 }
 
 // x[0..7] (byte-transposed dwords of one 32-byte group) -> bit planes in place
 __device__ __forceinline__ void to_bit_planes(uint32_t* x, const PlaneConsts& pc) {
-  plane_swap<1>(x[0], x[1], pc.m1, pc.m1s); plane_swap<1>(x[2], x[3], pc.m1, pc.m1s);
-  plane_swap<1>(x[4], x[5], pc.m1, pc.m1s); plane_swap<1>(x[6], x[7], pc.m1, pc.m1s);
-  plane_swap<2>(x[0], x[2], pc.m2, pc.m2s); plane_swap<2>(x[1], x[3], pc.m2, pc.m2s);
-  plane_swap<2>(x[4], x[6], pc.m2, pc.m2s); plane_swap<2>(x[5], x[7], pc.m2, pc.m2s);
-  plane_swap<4>(x[0], x[4], pc.m4, pc.m4s); plane_swap<4>(x[1], x[5], pc.m4, pc.m4s);
-  plane_swap<4>(x[2], x[6], pc.m4, pc.m4s); plane_swap<4>(x[3], x[7], pc.m4, pc.m4s);
+  plane_swap<1>(x[0], x[1], pc.m1); plane_swap<1>(x[2], x[3], pc.m1);
+  plane_swap<1>(x[4], x[5], pc.m1); plane_swap<1>(x[6], x[7], pc.m1);
+  plane_swap<2>(x[0], x[2], pc.m2); plane_swap<2>(x[1], x[3], pc.m2);
+  plane_swap<2>(x[4], x[6], pc.m2); plane_swap<2>(x[5], x[7], pc.m2);
+  plane_swap<4>(x[0], x[4], pc.m4); plane_swap<4>(x[1], x[5], pc.m4);
+  plane_swap<4>(x[2], x[6], pc.m4); plane_swap<4>(x[3], x[7], pc.m4);
 }
 
 // minterm selectors for v_bitop3 (truth-table bit index = A<<2 | B<<1 | C)
@@ -286,9 +291,9 @@ struct Acc16 {
 };
 
 struct WaveState {
-  Acc16 gc, nn, len, crlf, starts, fat, fplus;
+  Acc16 gc, nn, len, crlf, fat, fplus;      // (line starts per class are not counted tile by tile: range_starts() derives them)
   uint32_t p_gc, p_nn, p_len, p_crlf;   // 8-bit x 4-class fields of up to 3 tiles, not yet widened
-  uint32_t p_st, p_fat, p_fpl;          // ... K4 fields (STRUCT only)
+  uint32_t p_fat, p_fpl;                // ... K4 fields (STRUCT only)
   uint32_t pending;                     // wave-uniform: tiles accumulated in p_*
   uint32_t phase;      // wave-uniform: newlines seen so far in this range, mod 4
   uint32_t nl_total;   // wave-uniform: newlines seen so far in this range
@@ -296,12 +301,13 @@ struct WaveState {
   uint32_t qcls;       // wave-uniform, HIST == 2: relative class guessed to be the quality line (4 = no guess: no histogram)
   uint32_t piv4;       // wave-uniform, HIST == 2: the range's pivot quality byte, replicated into all four bytes
   uint32_t piv_set;    // wave-uniform: piv4 is valid
-  uint32_t piv_cnt;    // per lane: quality dwords equal to piv4 (counted here instead of four LDS atomics each)
   // HIST == 2, plane-matching form (hist_tile_planes): the byte values met so far on quality lines ("hot" values, at most
   // kHot) are counted from the bit planes into per-lane registers; anything else goes to the LDS histogram
   uint32_t hotp[2];    // wave-uniform: the hot byte values in order of discovery, four per word
-  uint32_t p_hot[2];   // per lane: 8-bit fields, quality bytes equal to hot value k of up to 3 tiles (k = 4 * word + field)
-  Acc16 hot_lo, hot_hi;// per lane: the same widened to 16-bit fields (values 0..3 / 4..7), like the class counters
+  uint32_t hot16[4];   // per lane: 16-bit fields, quality bytes of the range so far equal to hot value k (k = 2 * word + field; a range
+                       // is at most kMaxTilesPerRange tiles of 64 bytes per lane: the fields cannot overflow).  Once a range has
+                       // gone over to the dword loop (qmode 1: its counts so far are moved to the LDS histogram at that moment)
+                       // hot16[0] is that loop's pivot counter: quality dwords equal to piv4, counted here instead of four LDS atomics each
   uint32_t n_hot;      // wave-uniform
   uint32_t qmode;      // wave-uniform: 0 = plane matching, 1 = the alphabet of this range is too large for it: hist_tile_q
   uint32_t qover;      // wave-uniform: tiles that held quality bytes outside a full hot set
@@ -315,13 +321,9 @@ __device__ __forceinline__ void flush_pending(WaveState& st) {
   st.nn.add_tile8(st.p_nn);
   st.len.add_tile8(st.p_len);
   st.crlf.add_tile8(st.p_crlf);
-  st.starts.add_tile8(st.p_st);
   st.fat.add_tile8(st.p_fat);
   st.fplus.add_tile8(st.p_fpl);
-  st.hot_lo.add_tile8(st.p_hot[0]);
-  st.hot_hi.add_tile8(st.p_hot[1]);
-  st.p_gc = st.p_nn = st.p_len = st.p_crlf = st.p_st = st.p_fat = st.p_fpl = 0;
-  st.p_hot[0] = st.p_hot[1] = 0;
+  st.p_gc = st.p_nn = st.p_len = st.p_crlf = st.p_fat = st.p_fpl = 0;
   st.pending = 0;
 }
 
@@ -374,7 +376,7 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
     }
   }
 
-  uint32_t t_gc = 0, t_nn = 0, t_len = 0, t_crlf = 0, t_st = 0, t_fat = 0, t_fpl = 0;
+  uint32_t t_gc = 0, t_nn = 0, t_len = 0, t_crlf = 0, t_fat = 0, t_fpl = 0;
   const int lane_base = lane * 64;
   uint64_t x = NL;
   for (;;) {
@@ -388,7 +390,6 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
     t_nn += popc64(NN & below) << sh;
     if (STRUCT) {
       const uint64_t ls = LS & upto;      // a line start may itself be the newline (empty line)
-      t_st += popc64(ls) << sh;
       t_fat += popc64(ls & m.at) << sh;
       t_fpl += popc64(ls & m.pl) << sh;
     }
@@ -432,7 +433,7 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
   }
 
   st.p_gc += t_gc; st.p_nn += t_nn; st.p_len += t_len; st.p_crlf += t_crlf;
-  if (STRUCT) { st.p_st += t_st; st.p_fat += t_fat; st.p_fpl += t_fpl; }
+  if (STRUCT) { st.p_fat += t_fat; st.p_fpl += t_fpl; }
   if (++st.pending == 3) flush_pending(st);
   st.phase = (st.phase + total) & 3u;
   st.nl_total += total;
@@ -468,7 +469,7 @@ __device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist
 // first quality segment [a, b) is split into whole dwords [A, Bd) - four unpredicated atomics under one dword-level
 // exec mask, byte -> bin offset in two cheap ops - and at most 3 head + 3 tail bytes re-read from LDS.  Further quality
 // segments of the same lane (5+ newlines in 64 bytes) take a per-byte loop.
-__device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, const uint8_t* slot, int lane, uint32_t cls0,
+__device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, int lane, uint32_t cls0,
                                             uint64_t NL, uint32_t cnt, WaveState& st) {
   const uint32_t qcls = st.qcls;
   const uint8_t* lane_bytes = slot + lane * 64;
@@ -500,12 +501,37 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
   const uint32_t b = xb ? (uint32_t)__builtin_ctzll(xb) : 64u;
   // long reads: most tiles lie entirely inside a header / sequence / separator line and hold no quality byte at all
   if (__builtin_amdgcn_ballot_w64(a < b || cnt >= i0 + 4u) == 0) return;
+  // The lane's 16 dwords come from LDS again (4 x ds_read_b128 of the slot the classifier read them from): kept in registers
+  // from the top of the tile they were 16 VGPRs that every tile of the kernel paid for — with them gone the kernel fits
+  // 5 waves per SIMD instead of 4, and occupancy is what this variant is short of.
+  const uint4* lane_q = reinterpret_cast<const uint4*>(lane_bytes);
+  if (__builtin_amdgcn_ballot_w64(cnt != 0u) == 0) {
+    // long reads: a tile without any newline that lies inside a quality line (i0 == 0 for every lane, or the test above would have
+    // left) is 4096 quality bytes — no segment bounds, no predicates, no head or tail: shift, v_and_or, ds_add per byte
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = lane_q[q];
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w = w4[j];
+        bump_byte(w << kQShift);
+        bump_byte(w >> (8 - kQShift));
+        bump_byte(w >> (16 - kQShift));
+        bump_byte(w >> (24 - kQShift));
+      }
+    }
+    return;
+  }
   const uint32_t A = (a + 3u) >> 2, Bd = b >> 2;
   const uint32_t width = (Bd > A) ? Bd - A : 0u;
   // Pivot: quality strings are dominated by one value (one byte is ~90 % of an Illumina quality line), which would
   // serialise the lanes of every atomic on one bin.  A dword made of four pivot bytes is counted in a register instead;
   // the pivot is whatever byte starts the first whole quality dword this wave meets (any choice is exact).
-  if (!st.piv_set) {
+  // (the pivot counter shares a register with the plane-matching form's counts: a tile that comes here while the range is still
+  // in that form — a lane with three or more newlines — sends every dword through the atomics)
+  const bool use_pivot = st.qmode != 0u;
+  if (use_pivot && !st.piv_set) {
     const uint64_t have = __builtin_amdgcn_ballot_w64(width != 0);
     if (have) {
       const int L = __builtin_ctzll(have);
@@ -516,21 +542,29 @@ __device__ __forceinline__ void hist_tile_q(const uint32_t* d, uint32_t* hq, con
     }
   }
   const uint32_t piv4 = st.piv4;
-  uint32_t pc = st.piv_cnt;
+  uint32_t pc = st.hot16[0];
+  // (four dwords at a time: the loads of the next four are not issued before these are used up)
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t w = d[j];
-    const bool in = (uint32_t)j - A < width;
-    const bool is_piv = (w == piv4);
-    pc += (in && is_piv) ? 1u : 0u;
-    if (in && !is_piv) {
-      bump_byte(w << kQShift);
-      bump_byte(w >> (8 - kQShift));
-      bump_byte(w >> (16 - kQShift));
-      bump_byte(w >> (24 - kQShift));
+  for (int q = 0; q < 4; ++q) {
+    const uint4 v = lane_q[q];
+    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * q + jj;
+      const uint32_t w = w4[jj];
+      const bool in = (uint32_t)j - A < width;
+      const bool is_piv = use_pivot && (w == piv4);
+      pc += (in && is_piv) ? 1u : 0u;
+      if (in && !is_piv) {
+        bump_byte(w << kQShift);
+        bump_byte(w >> (8 - kQShift));
+        bump_byte(w >> (16 - kQShift));
+        bump_byte(w >> (24 - kQShift));
+      }
     }
+    asm volatile("" ::: "memory");
   }
-  st.piv_cnt = pc;
+  st.hot16[0] = pc;
   const uint32_t he = (b < 4u * A) ? b : 4u * A;               // head bytes [a, he)
   const uint32_t ts = (Bd > A) ? 4u * Bd : 4u * A;             // tail bytes [ts, b)
 #pragma unroll
@@ -604,56 +638,79 @@ __device__ __forceinline__ void hist_tile_planes(const uint32_t* xa, const uint3
   const uint64_t seg1 = (~x1 & x1m1) & ~(NL ^ xm1);      // above the first newline, below the second; none without a first
   const uint64_t seg2 = ~(x1 ^ x1m1);                    // above the second newline; none without a second
   const uint64_t M = (i0 == 0) ? seg0 : (i0 == 1) ? seg1 : (i0 == 2) ? seg2 : 0ull;
-  uint32_t ra = (uint32_t)M, rb = (uint32_t)(M >> 32);   // quality bytes not yet accounted for
-  uint64_t have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
-  if (have == 0) return;                                 // long reads: most tiles hold no quality byte at all
+  const uint32_t Ma = (uint32_t)M, Mb = (uint32_t)(M >> 32);
+  if (__builtin_amdgcn_ballot_w64((Ma | Mb) != 0) == 0) return;      // long reads: most tiles hold no quality byte at all
+  // Wave-uniform loop over the hot values — they sit in a 64-bit scalar shift register —, TWO per pass: each is matched inside M
+  // (six v_bitop3 in its stanza + two), counted (two v_bcnt), the two counts go into the 16-bit fields of one register with one
+  // shift-or and one add, and the union of the matches — what M minus it leaves is not covered by the set — grows by one 3-input OR
+  // per group: 12 vector instructions per value, and nothing to widen every third tile.
+  const uint32_t n_hot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
+  uint64_t hv = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0]);
+  auto add_field = [&](uint32_t word, uint32_t v) {          // word is wave-uniform: scalar branches, one v_add
+    if (word == 0u) st.hot16[0] += v; else if (word == 1u) st.hot16[1] += v; else if (word == 2u) st.hot16[2] += v; else st.hot16[3] += v;
+  };
+  uint32_t ua = 0, ub = 0;
   uint32_t k = 0;
+  for (; k + 1u < n_hot0; k += 2u, hv >>= 16) {
+    uint32_t ma0, mb0, ma1, mb1;
+    hot_match(xa, xb, Ma, Mb, (uint32_t)hv & 0xFFu, ma0, mb0);
+    hot_match(xa, xb, Ma, Mb, (uint32_t)(hv >> 8) & 0xFFu, ma1, mb1);
+    const uint32_t c0 = (uint32_t)__builtin_popcount(ma0) + (uint32_t)__builtin_popcount(mb0);
+    const uint32_t c1 = (uint32_t)__builtin_popcount(ma1) + (uint32_t)__builtin_popcount(mb1);
+    add_field(k >> 1, (c1 << 16) | c0);
+    ua = __builtin_amdgcn_bitop3_b32(ua, ma0, ma1, 0xFE);     // a | b | c
+    ub = __builtin_amdgcn_bitop3_b32(ub, mb0, mb1, 0xFE);
+  }
+  // an odd value out, and every value that joins the set in this tile (the first tiles of a range), one at a time
+  uint32_t n_hot = n_hot0;
+  uint64_t have;
   for (;;) {
-    const uint32_t n_hot = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
-    // wave-uniform loop, one dispatch per hot value; the values sit in a 64-bit scalar shift register, the counts go to
-    // 8-bit fields of two registers (values 0..3 / 4..7) with one shift-add each
-    uint64_t hv = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0])) >> (8u * k);
-    uint32_t p0 = st.p_hot[0], p1 = st.p_hot[1];
-    for (; k < n_hot && k < 4u; ++k, hv >>= 8) {
+    if (k < n_hot) {
       uint32_t ma, mb;
-      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);    // hot values are distinct: matching inside the rest is exact
+      hot_match(xa, xb, Ma, Mb, (uint32_t)hv & 0xFFu, ma, mb);
       const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
-      p0 = (c << (8u * k)) + p0;
-      ra &= ~ma;
-      rb &= ~mb;
+      add_field(k >> 1, c << (16u * (k & 1u)));
+      ua |= ma;
+      ub |= mb;
+      ++k;
     }
-    for (; k < n_hot; ++k, hv >>= 8) {
-      uint32_t ma, mb;
-      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);
-      const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
-      p1 = (c << (8u * (k - 4u))) + p1;
-      ra &= ~ma;
-      rb &= ~mb;
-    }
-    st.p_hot[0] = p0;
-    st.p_hot[1] = p1;
-    have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
+    have = __builtin_amdgcn_ballot_w64(((Ma & ~ua) | (Mb & ~ub)) != 0);
     if (have == 0 || n_hot >= (uint32_t)kHot) break;
-    // a byte outside the hot set while the set has room: its value joins (the loop above then counts it)
+    // a byte outside the hot set while the set has room: its value joins (the lines above then count it)
     const int L = __builtin_ctzll(have);
-    const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)ra, L), lb = (uint32_t)__builtin_amdgcn_readlane((int)rb, L);
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)(Ma & ~ua), L), lb = (uint32_t)__builtin_amdgcn_readlane((int)(Mb & ~ub), L);
     const uint32_t kbit = la ? (uint32_t)__builtin_ctz(la) : 32u + (uint32_t)__builtin_ctz(lb);
     const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)slot[L * 64 + kbit]);
     if (n_hot < 4u) st.hotp[0] |= v << (n_hot * 8u); else st.hotp[1] |= v << ((n_hot - 4u) * 8u);
-    st.n_hot = n_hot + 1u;
+    hv = v;
+    k = n_hot;
+    st.n_hot = ++n_hot;
   }
   if (have == 0) return;
   // the hot set is full: the rest is counted in the workgroup's LDS histogram byte by byte; a range that keeps coming
   // here has a large alphabet (unbinned qualities) and is better served by the dword loop of hist_tile_q
-  uint64_t r = (uint64_t)ra | ((uint64_t)rb << 32);
+  uint64_t r = (uint64_t)(Ma & ~ua) | ((uint64_t)(Mb & ~ub) << 32);
   const uint8_t* lane_bytes = slot + lane * 64;
   while (r) {
     const int kb = __builtin_ctzll(r);
     r &= r - 1;
     atomicAdd(&hq[(uint32_t)lane_bytes[kb] * kQRep + (lane & (kQRep - 1))], 1u);
   }
-  if (++st.qover > kHotOverflowTiles) st.qmode = 1u;
+  if (++st.qover > kHotOverflowTiles) {
+    // over to the dword loop for the rest of the range: what the lanes have counted so far goes to the LDS histogram now (eight
+    // atomics per lane, once per range), because that loop's pivot counter takes over hot16[0]
+    st.qmode = 1u;
+    const uint64_t hall = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0]);
+#pragma unroll
+    for (int j = 0; j < kHot; ++j) {
+      const uint32_t c = (st.hot16[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+      const uint32_t v = (uint32_t)(hall >> (8 * j)) & 0xFFu;
+      if (c) atomicAdd(&hq[v * kQRep + (lane & (kQRep - 1))], c);
+    }
+    st.hot16[0] = st.hot16[1] = st.hot16[2] = st.hot16[3] = 0u;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -696,7 +753,7 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       // plane matching needs the quality segment of a lane to be one of its first three segments: at most two newlines
       // per lane (any read of 30+ bases); other tiles, and ranges with a large quality alphabet, take the dword loop
       if (st.qmode == 0u && __builtin_amdgcn_ballot_w64(cnt > 2u) == 0) hist_tile_planes(xa, xb, hist_lds, slot, lane, sh0 >> 3, NL, st);
-      else hist_tile_q(d, hist_lds, slot, lane, sh0 >> 3, NL, cnt, st);
+      else hist_tile_q(hist_lds, slot, lane, sh0 >> 3, NL, cnt, st);
     }
   }
 
@@ -717,12 +774,12 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   uint32_t t_gc = st.p_gc + (s_gc << sh0);
   uint32_t t_nn = st.p_nn + (s_nn << sh0);
   uint32_t t_crlf = st.p_crlf;
-  uint32_t s_st = 0, s_fat = 0, s_fpl = 0, t_st = 0, t_fat = 0, t_fpl = 0;
+  uint32_t s_fat = 0, s_fpl = 0, t_fat = 0, t_fpl = 0;
   if (STRUCT) {
     // a line start may be the newline itself (empty line): its segment includes the newline bit
     const uint64_t ls0 = LS & (NL ^ xm1);
-    s_st = popc64(ls0); s_fat = popc64(ls0 & ~WAT); s_fpl = popc64(ls0 & ~WPL);
-    t_st = st.p_st + (s_st << sh0); t_fat = st.p_fat + (s_fat << sh0); t_fpl = st.p_fpl + (s_fpl << sh0);
+    s_fat = popc64(ls0 & ~WAT); s_fpl = popc64(ls0 & ~WPL);
+    t_fat = st.p_fat + (s_fat << sh0); t_fpl = st.p_fpl + (s_fpl << sh0);
   }
 
   if (total != 0 && SCFQ_ABLATE < 2) {   // wave-uniform: some lane of this tile holds a newline
@@ -751,9 +808,9 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       if (STRUCT) {
         uint64_t lsm = LS & (x1 ^ x1m1) & ~upto0;  // the segment plus its terminating newline
         lsm = has2 ? lsm : 0;
-        const uint32_t m_st = popc64(lsm), m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
-        t_st += m_st << sh; t_fat += m_fat << sh; t_fpl += m_fpl << sh;
-        s_st += m_st; s_fat += m_fat; s_fpl += m_fpl;
+        const uint32_t m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
+        t_fat += m_fat << sh; t_fpl += m_fpl << sh;
+        s_fat += m_fat; s_fpl += m_fpl;
       }
       t_crlf += ((has2 && pb1 == '\r') ? 1u : 0u) << sh;
     }
@@ -775,9 +832,9 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       if (STRUCT) {
         uint64_t lsm = LS & (x2 ^ x2m1) & ~upto1;
         lsm = has3 ? lsm : 0;
-        const uint32_t m_st = popc64(lsm), m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
-        t_st += m_st << sh; t_fat += m_fat << sh; t_fpl += m_fpl << sh;
-        s_st += m_st; s_fat += m_fat; s_fpl += m_fpl;
+        const uint32_t m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
+        t_fat += m_fat << sh; t_fpl += m_fpl << sh;
+        s_fat += m_fat; s_fpl += m_fpl;
       }
       const int idx = lane_base + (int)popc64(below2) - 1;
       const int pb = slot[has3 ? idx : lane * 4];
@@ -791,14 +848,13 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
     t_gc += (64u - popc64(WGC) - s_gc) << shl;
     t_nn += (64u - popc64(WNN) - s_nn) << shl;
     if (STRUCT) {
-      t_st += (popc64(LS) - s_st) << shl;
       t_fat += (popc64(LS & ~WAT) - s_fat) << shl;
       t_fpl += (popc64(LS & ~WPL) - s_fpl) << shl;
     }
   }
 
   st.p_len = t_len; st.p_gc = t_gc; st.p_nn = t_nn; st.p_crlf = t_crlf;
-  if (STRUCT) { st.p_st = t_st; st.p_fat = t_fat; st.p_fpl = t_fpl; }
+  if (STRUCT) { st.p_fat = t_fat; st.p_fpl = t_fpl; }
   if (++st.pending == 3) flush_pending(st);
   st.phase = (st.phase + total) & 3u;
   st.nl_total += total;
@@ -830,7 +886,7 @@ struct ScanArgs {
 //         class h+2 (in a well-formed FASTQ only the header/separator pair can satisfy it: a sequence line never
 //         starts with '@' or '+').  Ambiguous or not found within guess_cap_tiles: kNoGuess.
 template <bool STRUCT, int HIST, int RING = kRing, bool NT = true, bool GUESS = false>
-__global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWaves : 64 * kWavesPerBlock) void fq_scan_tiles(ScanArgs a) {
+__global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWaves : 64 * kWavesPerBlock, (HIST == 2 && !GUESS) ? SCFQ_QOCC : 1) void fq_scan_tiles(ScanArgs a) {
   constexpr int WAVES = HIST == 1 ? kHistWaves : HIST == 2 ? kQWaves : kWavesPerBlock;
   static_assert(RING >= 2 && RING <= 4, "ring depth");
   static_assert(!GUESS || (STRUCT && HIST == 0), "the guess pass is the K4 accounting without partials");
@@ -894,6 +950,7 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWa
   st.prev_last = prev_param;
   if (A0 + (uint64_t)t_begin * kTile > B) st.prev_last = *reinterpret_cast<const uint8_t*>(A0 + (uint64_t)t_begin * kTile - 1);
   st.prev_last = __builtin_amdgcn_readfirstlane(st.prev_last);
+  const int32_t range_prev = st.prev_last;      // the byte in front of the range's first byte (-1: the input starts here)
 
   const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;   // LDS byte address of slot 0 (wave-uniform)
 
@@ -992,7 +1049,16 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWa
   // len excludes the '\r' of "\r\n": u64 modular (may wrap when that '\r' lies in the previous range)
   store4(W_LEN, (uint64_t)len4.x - cr4.x, (uint64_t)len4.y - cr4.y, (uint64_t)len4.z - cr4.z, (uint64_t)len4.w - cr4.w);
   if (STRUCT) {
-    const uint4 s4 = sum4(st.starts), a4 = sum4(st.fat), p4 = sum4(st.fplus);
+    const uint4 a4 = sum4(st.fat), p4 = sum4(st.fplus);
+    // Line starts per class need no per-tile work: a byte starts a line iff the byte before it is a '\n' (or it is the first byte of
+    // the input), so the j-th newline of the range (class j mod 4) is followed by a line start of class (j + 1) mod 4 — unless it is
+    // the range's last byte, whose successor is the next range's first byte (class 0 there) — and the range's own first byte starts
+    // a line iff the byte before the range says so.
+    const uint64_t last_at = ((A0 + (uint64_t)t_end * kTile < E) ? A0 + (uint64_t)t_end * kTile : E) - 1;
+    const uint32_t last_is_nl = (*reinterpret_cast<const uint8_t*>(last_at) == (uint8_t)'\n') ? 1u : 0u;
+    const uint32_t nfol = st.nl_total - last_is_nl;      // newlines of the range that are followed by a byte of the range
+    const uint32_t first_is_start = (range_prev == '\n' || range_prev == -1) ? 1u : 0u;
+    const uint4 s4 = make_uint4((nfol >> 2) + first_is_start, (nfol + 3u) >> 2, (nfol + 2u) >> 2, (nfol + 1u) >> 2);
     store4(W_STARTS, s4.x, s4.y, s4.z, s4.w);
     store4(W_FAT, a4.x, a4.y, a4.z, a4.w);
     store4(W_FPLUS, p4.x, p4.y, p4.z, p4.w);
@@ -1008,15 +1074,17 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWa
     // that '\r' lies in the previous range, like len)
     const uint32_t crq = (qcls == 0) ? cr4.x : (qcls == 1) ? cr4.y : (qcls == 2) ? cr4.z : cr4.w;
     if (lane == 0 && crq) atomicSub(&hist_lds[13 * kQRep], crq);
-    const uint32_t pivots = wave_sum(st.piv_cnt);      // dwords of four pivot bytes that were counted in registers
-    if (lane == 0 && pivots) atomicAdd(&hist_lds[(st.piv4 & 0xFFu) * kQRep], 4u * pivots);
-    {   // the plane-matching form's register counts (flush_pending has widened them)
-      const uint4 lo4 = sum4(st.hot_lo), hi4 = sum4(st.hot_hi);
-      const uint32_t tot[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    if (st.qmode != 0u) {      // (wave-uniform) the dword loop's pivot counter: dwords of four pivot bytes that were counted in a register
+      const uint32_t pivots = wave_sum(st.hot16[0]);
+      if (lane == 0 && pivots) atomicAdd(&hist_lds[(st.piv4 & 0xFFu) * kQRep], 4u * pivots);
+    } else {                   // the plane-matching form's register counts
 #pragma unroll
       for (int k = 0; k < kHot; ++k) {
-        const uint32_t v = ((k < 4 ? st.hotp[0] : st.hotp[1]) >> ((k & 3) * 8)) & 0xFFu;
-        if (lane == 0 && (uint32_t)k < st.n_hot && tot[k]) atomicAdd(&hist_lds[v * kQRep], tot[k]);
+        if ((uint32_t)k < st.n_hot) {
+          const uint32_t tot = wave_sum((st.hot16[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+          const uint32_t v = ((k < 4 ? st.hotp[0] : st.hotp[1]) >> ((k & 3) * 8)) & 0xFFu;
+          if (lane == 0 && tot) atomicAdd(&hist_lds[v * kQRep], tot);
+        }
       }
     }
   }
