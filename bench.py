@@ -73,32 +73,47 @@ def cpu_all_cores(L, host, nbytes, threads):
     return time.perf_counter() - t0, acc
 
 
-def ingest_rows(scfq, nbytes):
-    """Non-headline: BASELINE configs[3] end to end — a gzip member and a BGZF file of the same synthetic stream, written here,
-    counted (a) by a fresh `sc fq-count` process, which is how the reference is used (one call per process, sc.nim:114-116): wall
-    time of the whole process, context and buffers included, and (b) by the second call in this process (buffers in place).
-    Compressed bytes cross PCIe and are inflated on the device.  Counters must equal the generator's tallies."""
+def ingest_rows(scfq, member_bytes, bgzf_bytes):
+    """Non-headline: BASELINE configs[3] end to end — ONE gzip member of `member_bytes` of the synthetic stream (10 GB by default:
+    configs[3]'s own size; written the way pigz does it) and a BGZF file of `bgzf_bytes`, written here and counted
+    (a) by fresh `sc fq-count` processes, which is how the reference is used (one call per process, sc.nim:114-116): wall time of the
+        whole process, context and buffers included, three times over with the library's stage marks;
+    (b) by the first and second call in this process (buffers in place): compressed bytes cross PCIe, inflate on the device;
+    (c) the member once more by a process with SCFQ_GZ_DEVICE=0: the HOST inflates (the library's parallel reader) into pinned
+        buffers while a copy stream moves the chunk before to HBM and the compute stream scans the one before that — north_star's
+        "gzip_stream.nim's host-side inflate overlapped with device compute on a second HIP stream".
+    Counters must equal the generator's tallies everywhere."""
     import shutil
     import struct
     import subprocess
     import tempfile
     import zlib
     from concurrent.futures import ThreadPoolExecutor
-    plan = scfq.synth_plan(0, SEED, nbytes)
-    data, info = scfq.synth_host(0, SEED, plan.records)
-    want = (plan.records, info.gc_bases, info.n_bases, info.bases)
     tmp = tempfile.mkdtemp(prefix="scfq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
-    rows = {"inflated_bytes": int(data.size), "what": "cold = wall of a fresh `sc fq-count FILE` process; warm = second call in one process; "
-            "GB/s of inflated bytes; counters == generator tallies"}
-    try:
+    rows = {"what": "cold = wall of a fresh `sc fq-count FILE` process (median of three); warm = second call in one process; GB/s of inflated "
+                    "bytes; counters == generator tallies"}
+    sc = os.path.join(ROOT, "seq-collection_amd", "sc")
+
+    def write_member(data, path):
         step = 64 << 20
         cuts = list(range(0, data.size, step))
 
         def piece(i):
             co = zlib.compressobj(6, zlib.DEFLATED, -15)
-            chunk = data[cuts[i]:cuts[i] + step].tobytes()
-            return co.compress(chunk) + co.flush(zlib.Z_FINISH if i == len(cuts) - 1 else zlib.Z_SYNC_FLUSH)
+            chunk = data[cuts[i]:cuts[i] + step]
+            return co.compress(chunk.tobytes()) + co.flush(zlib.Z_FINISH if i == len(cuts) - 1 else zlib.Z_SYNC_FLUSH), zlib.crc32(chunk), chunk.size
+        with ThreadPoolExecutor(16) as ex:
+            parts = list(ex.map(piece, range(len(cuts))))
+        crc = 0
+        for _, c_, n_ in parts:          # the CRC-32 of the whole from the pieces' (each computed beside its compression)
+            crc = crc32_combine(crc, c_, n_)
+        with open(path, "wb") as f:
+            f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+            for b_, _, _ in parts:
+                f.write(b_)
+            f.write(struct.pack("<II", crc & 0xFFFFFFFF, data.size & 0xFFFFFFFF))
 
+    def write_bgzf(data, path):
         def block(b):
             co = zlib.compressobj(6, zlib.DEFLATED, -15)
             payload = co.compress(b) + co.flush()
@@ -108,70 +123,129 @@ def ingest_rows(scfq, nbytes):
         def span(i):
             a = data[i:i + (32 << 20)]
             return b"".join(block(a[o:o + 65280].tobytes()) for o in range(0, a.size, 65280))
-        gz = os.path.join(tmp, "member.fq.gz")
-        bg = os.path.join(tmp, "bgzf.fq.gz")
         with ThreadPoolExecutor(16) as ex:
-            parts = list(ex.map(piece, range(len(cuts))))
             spans = list(ex.map(span, range(0, data.size, 32 << 20)))
-        crc = 0
-        for c0 in cuts:
-            crc = zlib.crc32(data[c0:c0 + step], crc)
-        with open(gz, "wb") as f:
-            f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
-            for b in parts:
-                f.write(b)
-            f.write(struct.pack("<II", crc & 0xFFFFFFFF, data.size & 0xFFFFFFFF))
-        with open(bg, "wb") as f:
+        with open(path, "wb") as f:
             for s_ in spans:
                 f.write(s_)
             f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
-        del parts, spans
-        sc = os.path.join(ROOT, "seq-collection_amd", "sc")
-        for name, path, how in (("gzip_member", gz, "one gzip member, zlib level 6, 64 MiB pieces joined by sync flushes (as pigz writes it)"),
-                                ("bgzf", bg, "BGZF (bgzip layout, 65280-byte blocks, level 6)")):
-            # a fresh process three times over, each with --stats: the library's stage marks (ms since it was loaded) say where a slow
-            # one spent its time — runtime initialisation, context, allocations, first copy, first kernel, fold, exit
-            colds = []
-            for _ in range(3):
-                t = time.perf_counter()
-                r = subprocess.run([sc, "fq-count", "--stats", path], capture_output=True, text=True)
-                wall = time.perf_counter() - t
-                f_ = r.stdout.strip().split("\t")
-                assert r.returncode == 0 and (int(f_[0]), int(f_[2]), int(f_[3]), int(f_[4])) == want, ("cold row", r.stdout, r.stderr[-500:], want)
-                stages = None
-                for line in r.stderr.splitlines():
-                    if line.startswith("{") and "stages_ms" in line:
-                        try:
-                            stages = json.loads(line).get("stages_ms")
-                        except ValueError:
-                            pass
-                colds.append((wall, stages))
-            colds.sort(key=lambda x: x[0])
-            cold = colds[1][0]
 
-            def stage_row(wall, stages):
-                if not stages:
-                    return {"wall_ms": round(wall * 1e3, 1)}
-                row = {"wall_ms": round(wall * 1e3, 1), "marks": [[n, ms] for n, ms in stages]}
-                row["process_start_and_exit_ms"] = round(wall * 1e3 - stages[-1][1], 1)      # exec -> library loaded, plus row computed -> reaped
-                return row
-            walls = []
-            for _ in range(2):
-                t = time.perf_counter()
-                c = scfq.count_file(path)
-                walls.append(time.perf_counter() - t)
-                assert (c.reads, c.gc_bases, c.n_bases, c.bases) == want, ("in-process row", name)
-            rows[name] = {"layout": how, "compressed_bytes": os.path.getsize(path), "cold_process_wall_s": round(cold, 4), "cold_GBps": round(data.size / cold / 1e9, 2),
-                          "cold_process_walls_s": {"min": round(colds[0][0], 4), "median": round(colds[1][0], 4), "max": round(colds[2][0], 4),
-                                                   "what": "three fresh `sc fq-count --stats FILE` processes one after the other; cold_process_wall_s is their median"},
-                          "cold_stages_ms": {"median_run": stage_row(*colds[1]), "slowest_run": stage_row(*colds[2]),
-                                             "what": "[stage, ms since the library was loaded] (include/sc_fqcount_debug.h: scfq_debug_stages)"},
-                          "first_call_wall_s": round(walls[0], 4), "warm_wall_s": round(walls[1], 4), "warm_GBps": round(data.size / walls[1] / 1e9, 2),
-                          "counters_match_generator": True}
+    def run_sc(path, want, env=None):
+        t = time.perf_counter()
+        r = subprocess.run([sc, "fq-count", "--stats", path], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+        wall = time.perf_counter() - t
+        f_ = r.stdout.strip().split("\t")
+        assert r.returncode == 0 and (int(f_[0]), int(f_[2]), int(f_[3]), int(f_[4])) == want, ("cold row", r.stdout, r.stderr[-500:], want)
+        st = None
+        for line in r.stderr.splitlines():
+            if line.startswith("{") and "stages_ms" in line:
+                try:
+                    st = json.loads(line)
+                except ValueError:
+                    pass
+        return wall, st
+
+    def stage_row(wall, st):
+        if not st or not st.get("stages_ms"):
+            return {"wall_ms": round(wall * 1e3, 1)}
+        marks = st["stages_ms"]
+        return {"wall_ms": round(wall * 1e3, 1), "marks": [[n, ms] for n, ms in marks],
+                "process_start_and_exit_ms": round(wall * 1e3 - marks[-1][1], 1)}      # exec -> library loaded, plus row computed -> reaped
+
+    def measure(name, path, how, data_size, want):
+        # a fresh process three times over, each with --stats: the library's stage marks (ms since it was loaded) say where a slow
+        # one spent its time — runtime initialisation, context, allocations, first copy, first kernel, fold
+        colds = sorted((run_sc(path, want) for _ in range(3)), key=lambda x: x[0])
+        cold = colds[1][0]
+        walls = []
+        for _ in range(2):
+            t = time.perf_counter()
+            c = scfq.count_file(path)
+            walls.append(time.perf_counter() - t)
+            assert (c.reads, c.gc_bases, c.n_bases, c.bases) == want, ("in-process row", name)
+        rows[name] = {"layout": how, "inflated_bytes": int(data_size), "compressed_bytes": os.path.getsize(path),
+                      "cold_process_wall_s": round(cold, 4), "cold_GBps": round(data_size / cold / 1e9, 2),
+                      "cold_process_walls_s": {"min": round(colds[0][0], 4), "median": round(colds[1][0], 4), "max": round(colds[2][0], 4),
+                                               "what": "three fresh `sc fq-count --stats FILE` processes one after the other; cold_process_wall_s is their median"},
+                      "cold_stages_ms": {"median_run": stage_row(*colds[1]), "slowest_run": stage_row(*colds[2]),
+                                         "what": "[stage, ms since the library was loaded] (include/sc_fqcount_debug.h: scfq_debug_stages)"},
+                      "first_call_wall_s": round(walls[0], 4), "warm_wall_s": round(walls[1], 4), "warm_GBps": round(data_size / walls[1] / 1e9, 2),
+                      "counters_match_generator": True}
+
+    try:
+        # ---- BGZF, bgzf_bytes ----
+        plan = scfq.synth_plan(0, SEED, bgzf_bytes)
+        data, info = scfq.synth_host(0, SEED, plan.records)
+        want = (plan.records, info.gc_bases, info.n_bases, info.bases)
+        bg = os.path.join(tmp, "bgzf.fq.gz")
+        write_bgzf(data, bg)
+        # (what has just been written is dirty page cache; a process that starts while the kernel is still writing it back pays for
+        # that in its runtime initialisation — 190 ms instead of 52, scripts/measure_cold_stages.py — which says nothing about the
+        # product: the cold runs start once the files are on disk)
+        os.sync()
+        measure("bgzf", bg, "BGZF (bgzip layout, 65280-byte blocks, level 6)", data.size, want)
+        os.remove(bg)
+        # ---- one gzip member, member_bytes (configs[3]) ----
+        if member_bytes != bgzf_bytes:
+            del data
+            plan = scfq.synth_plan(0, SEED, member_bytes)
+            data, info = scfq.synth_host(0, SEED, plan.records)
+            want = (plan.records, info.gc_bases, info.n_bases, info.bases)
+        gz = os.path.join(tmp, "member.fq.gz")
+        write_member(data, gz)
+        n_inflated = int(data.size)
+        del data
+        os.sync()
+        measure("gzip_member", gz, "one gzip member, zlib level 6, 64 MiB pieces joined by sync flushes (as pigz writes it)", n_inflated, want)
+        # ---- the same member, inflated on the HOST and overlapped with copy + scan (the path behind the device inflate) ----
+        wall, st = run_sc(gz, want, {"SCFQ_GZ_DEVICE": "0"})
+        rows["gzip_member_host_inflate_overlap"] = {
+            "what": "SCFQ_GZ_DEVICE=0: the library's parallel host reader fills pinned buffers while the copy stream moves the chunk before to "
+                    "HBM and the compute stream scans the one before that; wall of a fresh process",
+            "process_wall_s": round(wall, 4), "GBps": round(n_inflated / wall / 1e9, 2),
+            "host_fill_ms": st and st.get("host_fill_ms"), "ingest_wall_ms": st and st.get("ingest_wall_ms"),
+            "scan_kernel_ms": st and st.get("scan_kernel_ms"),
+            "overlap": st and ("scan kernels took %.1f %% of the host's fill time: hidden under it" % (100.0 * st["scan_kernel_ms"] / max(st["host_fill_ms"], 1e-9))),
+            "counters_match_generator": True}
         rows["device_bytes_high_water"] = int(scfq.lib().scfq_device_bytes_high_water())
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return rows
+
+
+def crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (not exposed by Python's zlib): CRC-32 of A || B from crc(A), crc(B) and len(B)"""
+    def times(mat, vec):
+        s_ = 0
+        i = 0
+        while vec:
+            if vec & 1:
+                s_ ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s_
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+    if len2 <= 0:
+        return crc1
+    odd = [0xEDB88320] + [1 << n for n in range(31)]
+    even = square(odd)
+    odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
 
 
 def main():
@@ -195,8 +269,10 @@ def main():
                          "torch = the Python mirror over torch.distributed (--backend says over what)")
     ap.add_argument("--transport", choices=["rccl", "tcp"], default="rccl",
                     help="transport of the library communicator: rccl (default) or tcp (rehearsals with several ranks on ONE device, which RCCL refuses)")
-    ap.add_argument("--ingest-bytes", type=float, default=2e9,
-                    help="N=1 only, after the timed region: inflated size of the gzip member / BGZF file of the non-headline `ingest` object (0 = skip)")
+    ap.add_argument("--ingest-bytes", type=float, default=10e9,
+                    help="N=1 only, after the timed region: inflated size of the gzip member of the non-headline `ingest` object — 10e9 = BASELINE "
+                         "configs[3]'s own size (0 = skip the object)")
+    ap.add_argument("--ingest-bgzf-bytes", type=float, default=2e9, help="... and of its BGZF file (at most --ingest-bytes)")
     ap.add_argument("--exchange-timeout-s", type=float, default=120.0, help="deadline of one exchange: a stuck collective ends the run non-zero")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (1-GPU box, gloo backend); the number is not a scaling result")
@@ -538,8 +614,11 @@ def main():
         assert (acc[2], acc[6], acc[10]) == (oc.gc_bases, oc.n_bases, oc.bases)
         out["cpu_all_cores"] = {"value": round(oc.bases / all_s / 1e9, 3), "unit": "Gbases/s", "threads": threads,
                                 "note": "optimised CPU restatement: byte-range shards + the same ordered fold, byte-serial scan per shard"}
+        del host
     if rank == 0 and world == 1 and args.ingest_bytes > 0 and kind == 0 and args.flags == 0:
-        out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes))
+        del buf          # (the 10 GB workload: the ingest legs measure processes of their own, beside a parent that holds little)
+        torch.cuda.empty_cache()
+        out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes), int(min(args.ingest_bgzf_bytes, args.ingest_bytes)))
     if rank == 0:
         print(json.dumps(out))
     if exchange:

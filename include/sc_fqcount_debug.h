@@ -35,6 +35,15 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
  * practical read-stream ceiling on this device, reported next to the roofline by bench.py. Negative on error. */
 double scfq_debug_stream_ms(const void* device_ptr, uint64_t n, int reps);
 
+/* Host only — the two rules scfq_count_file_sharded cuts an ordinary (non-BGZF) .gz file of several members by, for the CPU tests.
+ * scfq_debug_gz_member_boundary: the first position at or after `from` where a gzip member demonstrably starts (magic, no reserved
+ * flag bit, a header that parses, deflate data that inflates cleanly for its first 64 KiB); the file's size when there is none, a
+ * negative code on error.  *first_byte: the first byte the members from there inflate to (-1: none).
+ * scfq_debug_gz_shard_fix: a shard's partial (+ histogram) that was scanned as if it began the input (prev_byte -1), put right for the
+ * byte that really lies in front of it (true_prev 0..255; -1: it does begin the input) given the shard's first byte; flags: the
+ * SCFQ_* flags of the scan (the line-start words are only touched with SCFQ_STRUCT_CHECK). */
+int64_t scfq_debug_gz_member_boundary(const char* path, uint64_t from, int* first_byte);
+int scfq_debug_gz_shard_fix(scfq_partial* p, uint64_t* hist, int true_prev, int first_byte, uint32_t flags);
 /* Diagnostic only: where this process's time went so far.  The library marks its stages (first device call returned, context up,
  * buffers allocated, first copy queued, first kernel queued, session folded ...) with the milliseconds since it was loaded;
  * scfq_debug_stages writes them as one JSON array of [name, ms] pairs and returns its length (the length needed, with nothing

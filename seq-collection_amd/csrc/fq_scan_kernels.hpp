@@ -54,20 +54,33 @@ constexpr int kHistWaves = 2;   // waves per block in the histogram variant (LDS
 // (fq_scan_tiles<.., GUESS> reads the '@' / '+' line starts of the first tiles of the range; the guess is VERIFIED
 // against the exact phases of the ordered fold afterwards and wrong / missing guesses are redone by the exact
 // HIST == 1 kernel, so results never depend on it).  With the class known only quality bytes are histogrammed, into ONE
-// workgroup-shared histogram of 256 bins x kQRep lane-keyed copies (16 KiB for 4 waves instead of 16 KiB per wave):
+// workgroup-shared histogram of kQBins bins x kQRep lane-keyed copies (16 KiB for 8 waves instead of 16 KiB per wave):
 // u32 bin[byte * kQRep + copy].
+// (r4) 128 bins x 32 copies, copy = lane & 31: bank = (byte & 1) << 5 | lane & 31, so the 32 lanes the LDS serves together never
+// meet in a bank, whatever the bytes are — with 256 x 16 the lanes l and l + 16 shared a copy and collided whenever their bytes
+// agreed modulo 4, i.e. in nearly every atomic of a long-read quality tile.  Quality bytes are ASCII; a workgroup that meets a
+// quality byte >= 128 (or cannot tell: see the callers of q_note_high) marks its histogram as not to be used, its ranges are
+// counted again by the exact kernel like those of a wrong guess (fq_hist_verify), and results never depend on the assumption.
+// SCFQ_QWINDOW=0 keeps the 256-bin layout (SCFQ_QREP copies).
+#ifndef SCFQ_QWINDOW
+#define SCFQ_QWINDOW 1
+#endif
 #ifndef SCFQ_QREP
 #define SCFQ_QREP 16
 #endif
-constexpr int kQRep = SCFQ_QREP;     // 4 | 8 | 16
-constexpr int kQShift = 2 + (kQRep == 16 ? 4 : kQRep == 8 ? 3 : 2);   // byte offset of a bin copy: byte << kQShift | copy << 2
-constexpr int kQWords = 256 * kQRep;
+constexpr bool kQWindow = SCFQ_QWINDOW != 0;
+constexpr int kQRep = kQWindow ? 32 : SCFQ_QREP;     // 4 | 8 | 16 | 32
+constexpr int kQBins = kQWindow ? 128 : 256;
+constexpr int kQShift = 2 + (kQRep == 32 ? 5 : kQRep == 16 ? 4 : kQRep == 8 ? 3 : 2);   // byte offset of a bin copy: byte << kQShift | copy << 2
+constexpr int kQWords = kQBins * kQRep;
+constexpr uint32_t kQFlagWord = 10 * kQRep;      // (window layout) the workgroup's "do not use" word: bin '\n' copy 0 — a newline is never a quality byte
+constexpr uint32_t kQPoison = 0xFFFFFFFFu;       // ... and what hist_wg[wg][255] holds for such a workgroup
 #ifndef SCFQ_QWAVES
 #define SCFQ_QWAVES 8
 #endif
 constexpr int kQWaves = SCFQ_QWAVES;   // waves (= ranges) per workgroup of the speculative form: they share one histogram
 #ifndef SCFQ_QOCC
-#define SCFQ_QOCC 5                    // waves per SIMD the speculative form is compiled for (the register budget the compiler is given)
+#define SCFQ_QOCC 1                    // waves per SIMD the speculative form is compiled for (the register budget the compiler is given; 1 = none)
 #endif
 constexpr uint32_t kNoGuess = 255u;
 
@@ -301,16 +314,18 @@ struct WaveState {
   uint32_t qcls;       // wave-uniform, HIST == 2: relative class guessed to be the quality line (4 = no guess: no histogram)
   uint32_t piv4;       // wave-uniform, HIST == 2: the range's pivot quality byte, replicated into all four bytes
   uint32_t piv_set;    // wave-uniform: piv4 is valid
+  uint32_t piv_cnt;    // per lane: quality dwords equal to piv4 (counted here instead of four LDS atomics each)
   // HIST == 2, plane-matching form (hist_tile_planes): the byte values met so far on quality lines ("hot" values, at most
   // kHot) are counted from the bit planes into per-lane registers; anything else goes to the LDS histogram
   uint32_t hotp[2];    // wave-uniform: the hot byte values in order of discovery, four per word
-  uint32_t hot16[4];   // per lane: 16-bit fields, quality bytes of the range so far equal to hot value k (k = 2 * word + field; a range
-                       // is at most kMaxTilesPerRange tiles of 64 bytes per lane: the fields cannot overflow).  Once a range has
-                       // gone over to the dword loop (qmode 1: its counts so far are moved to the LDS histogram at that moment)
-                       // hot16[0] is that loop's pivot counter: quality dwords equal to piv4, counted here instead of four LDS atomics each
+  uint32_t p_hot[2];   // per lane: 8-bit fields, quality bytes equal to hot value k of up to 3 tiles (k = 4 * word + field): the value
+                       // is a SHIFT AMOUNT here, never a register index — fields of 16 bits in four registers, picked by k, became an
+                       // array in scratch memory (r4: a load and a store per value and tile, 7 % of the kernel)
+  Acc16 hot_lo, hot_hi;// per lane: the same widened to 16-bit fields (values 0..3 / 4..7), like the class counters
   uint32_t n_hot;      // wave-uniform
   uint32_t qmode;      // wave-uniform: 0 = plane matching, 1 = the alphabet of this range is too large for it: hist_tile_q
   uint32_t qover;      // wave-uniform: tiles that held quality bytes outside a full hot set
+  uint32_t qbad;       // wave-uniform (window layout): a quality byte >= 128 may have gone to the LDS histogram: the workgroup's histogram is void
 };
 constexpr int kHot = 8;
 constexpr uint32_t kHotOverflowTiles = 2;   // after this many tiles with bytes outside a full hot set the range goes to hist_tile_q
@@ -323,7 +338,10 @@ __device__ __forceinline__ void flush_pending(WaveState& st) {
   st.crlf.add_tile8(st.p_crlf);
   st.fat.add_tile8(st.p_fat);
   st.fplus.add_tile8(st.p_fpl);
+  st.hot_lo.add_tile8(st.p_hot[0]);
+  st.hot_hi.add_tile8(st.p_hot[1]);
   st.p_gc = st.p_nn = st.p_len = st.p_crlf = st.p_fat = st.p_fpl = 0;
+  st.p_hot[0] = st.p_hot[1] = 0;
   st.pending = 0;
 }
 
@@ -377,6 +395,7 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
   }
 
   uint32_t t_gc = 0, t_nn = 0, t_len = 0, t_crlf = 0, t_fat = 0, t_fpl = 0;
+  bool q_high = false;
   const int lane_base = lane * 64;
   uint64_t x = NL;
   for (;;) {
@@ -401,7 +420,8 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
           const int k = __builtin_ctzll(s);
           s &= s - 1;
           const uint32_t byte = slot[lane_base + k];
-          atomicAdd(&hist_lds[byte * kQRep + (lane & (kQRep - 1))], 1u);
+          if (kQWindow && byte >= (uint32_t)kQBins) q_high = true;
+          atomicAdd(&hist_lds[(byte & (uint32_t)(kQBins - 1)) * kQRep + (lane & (kQRep - 1))], 1u);
         }
       }
     }
@@ -433,6 +453,7 @@ __device__ __forceinline__ void process_tile(const uint8_t* slot, int lane, uint
   }
 
   st.p_gc += t_gc; st.p_nn += t_nn; st.p_len += t_len; st.p_crlf += t_crlf;
+  if (HIST == 2 && kQWindow && __builtin_amdgcn_ballot_w64(q_high) != 0) st.qbad = 1u;
   if (STRUCT) { st.p_fat += t_fat; st.p_fpl += t_fpl; }
   if (++st.pending == 3) flush_pending(st);
   st.phase = (st.phase + total) & 3u;
@@ -469,18 +490,20 @@ __device__ __forceinline__ void hist_tile_full(const uint32_t* d, uint32_t* hist
 // first quality segment [a, b) is split into whole dwords [A, Bd) - four unpredicated atomics under one dword-level
 // exec mask, byte -> bin offset in two cheap ops - and at most 3 head + 3 tail bytes re-read from LDS.  Further quality
 // segments of the same lane (5+ newlines in 64 bytes) take a per-byte loop.
+// hi7: bit 7 of the lane's 64 bytes (the classifier's plane 7).
 __device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, int lane, uint32_t cls0,
-                                            uint64_t NL, uint32_t cnt, WaveState& st) {
+                                            uint64_t NL, uint32_t cnt, uint64_t hi7, WaveState& st) {
   const uint32_t qcls = st.qcls;
   const uint8_t* lane_bytes = slot + lane * 64;
   uint8_t* base = reinterpret_cast<uint8_t*>(hq) + ((lane & (kQRep - 1)) << 2);
-  constexpr uint32_t kMask = 0xFFu << kQShift;   // byte offset of a bin copy: byte << kQShift | copy << 2
-  static_assert(kQRep == 16 || kQRep == 8 || kQRep == 4, "bin offset arithmetic");
+  constexpr uint32_t kMask = (uint32_t)(kQBins - 1) << kQShift;   // byte offset of a bin copy: byte << kQShift | copy << 2
+  static_assert(kQRep == 32 || kQRep == 16 || kQRep == 8 || kQRep == 4, "bin offset arithmetic");
 #ifndef SCFQ_QABLATE
 #define SCFQ_QABLATE 0   // timing-only diagnostic builds: 1 = addresses computed but no LDS atomics, 2 = no histogram work at all
 #endif
   if (SCFQ_QABLATE == 2) return;
   auto bump = [&](uint32_t off) {
+    off &= kMask;
     if (SCFQ_QABLATE == 1) { uint8_t* p = base + off; asm volatile("" :: "v"(p)); return; }
     __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(base + off), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
@@ -501,6 +524,9 @@ __device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, i
   const uint32_t b = xb ? (uint32_t)__builtin_ctzll(xb) : 64u;
   // long reads: most tiles lie entirely inside a header / sequence / separator line and hold no quality byte at all
   if (__builtin_amdgcn_ballot_w64(a < b || cnt >= i0 + 4u) == 0) return;
+  // (window layout) a lane that holds quality bytes and ANY byte >= 128 voids the workgroup's histogram — conservative: the high
+  // byte may lie on another line of the lane; FASTQ text is ASCII, and a file where it is not only loses the fast form here
+  if (kQWindow && __builtin_amdgcn_ballot_w64(hi7 != 0 && (a < b || cnt >= i0 + 4u)) != 0) st.qbad = 1u;
   // The lane's 16 dwords come from LDS again (4 x ds_read_b128 of the slot the classifier read them from): kept in registers
   // from the top of the tile they were 16 VGPRs that every tile of the kernel paid for — with them gone the kernel fits
   // 5 waves per SIMD instead of 4, and occupancy is what this variant is short of.
@@ -528,10 +554,7 @@ __device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, i
   // Pivot: quality strings are dominated by one value (one byte is ~90 % of an Illumina quality line), which would
   // serialise the lanes of every atomic on one bin.  A dword made of four pivot bytes is counted in a register instead;
   // the pivot is whatever byte starts the first whole quality dword this wave meets (any choice is exact).
-  // (the pivot counter shares a register with the plane-matching form's counts: a tile that comes here while the range is still
-  // in that form — a lane with three or more newlines — sends every dword through the atomics)
-  const bool use_pivot = st.qmode != 0u;
-  if (use_pivot && !st.piv_set) {
+  if (!st.piv_set) {
     const uint64_t have = __builtin_amdgcn_ballot_w64(width != 0);
     if (have) {
       const int L = __builtin_ctzll(have);
@@ -542,7 +565,7 @@ __device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, i
     }
   }
   const uint32_t piv4 = st.piv4;
-  uint32_t pc = st.hot16[0];
+  uint32_t pc = st.piv_cnt;
   // (four dwords at a time: the loads of the next four are not issued before these are used up)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -553,7 +576,7 @@ __device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, i
       const int j = 4 * q + jj;
       const uint32_t w = w4[jj];
       const bool in = (uint32_t)j - A < width;
-      const bool is_piv = use_pivot && (w == piv4);
+      const bool is_piv = (w == piv4);
       pc += (in && is_piv) ? 1u : 0u;
       if (in && !is_piv) {
         bump_byte(w << kQShift);
@@ -564,7 +587,7 @@ __device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, i
     }
     asm volatile("" ::: "memory");
   }
-  st.hot16[0] = pc;
+  st.piv_cnt = pc;
   const uint32_t he = (b < 4u * A) ? b : 4u * A;               // head bytes [a, he)
   const uint32_t ts = (Bd > A) ? 4u * Bd : 4u * A;             // tail bytes [ts, b)
 #pragma unroll
@@ -638,79 +661,60 @@ __device__ __forceinline__ void hist_tile_planes(const uint32_t* xa, const uint3
   const uint64_t seg1 = (~x1 & x1m1) & ~(NL ^ xm1);      // above the first newline, below the second; none without a first
   const uint64_t seg2 = ~(x1 ^ x1m1);                    // above the second newline; none without a second
   const uint64_t M = (i0 == 0) ? seg0 : (i0 == 1) ? seg1 : (i0 == 2) ? seg2 : 0ull;
-  const uint32_t Ma = (uint32_t)M, Mb = (uint32_t)(M >> 32);
-  if (__builtin_amdgcn_ballot_w64((Ma | Mb) != 0) == 0) return;      // long reads: most tiles hold no quality byte at all
-  // Wave-uniform loop over the hot values — they sit in a 64-bit scalar shift register —, TWO per pass: each is matched inside M
-  // (six v_bitop3 in its stanza + two), counted (two v_bcnt), the two counts go into the 16-bit fields of one register with one
-  // shift-or and one add, and the union of the matches — what M minus it leaves is not covered by the set — grows by one 3-input OR
-  // per group: 12 vector instructions per value, and nothing to widen every third tile.
-  const uint32_t n_hot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
-  uint64_t hv = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
-                (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0]);
-  auto add_field = [&](uint32_t word, uint32_t v) {          // word is wave-uniform: scalar branches, one v_add
-    if (word == 0u) st.hot16[0] += v; else if (word == 1u) st.hot16[1] += v; else if (word == 2u) st.hot16[2] += v; else st.hot16[3] += v;
-  };
-  uint32_t ua = 0, ub = 0;
+  uint32_t ra = (uint32_t)M, rb = (uint32_t)(M >> 32);   // quality bytes not yet accounted for
+  uint64_t have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
+  if (have == 0) return;                                 // long reads: most tiles hold no quality byte at all
   uint32_t k = 0;
-  for (; k + 1u < n_hot0; k += 2u, hv >>= 16) {
-    uint32_t ma0, mb0, ma1, mb1;
-    hot_match(xa, xb, Ma, Mb, (uint32_t)hv & 0xFFu, ma0, mb0);
-    hot_match(xa, xb, Ma, Mb, (uint32_t)(hv >> 8) & 0xFFu, ma1, mb1);
-    const uint32_t c0 = (uint32_t)__builtin_popcount(ma0) + (uint32_t)__builtin_popcount(mb0);
-    const uint32_t c1 = (uint32_t)__builtin_popcount(ma1) + (uint32_t)__builtin_popcount(mb1);
-    add_field(k >> 1, (c1 << 16) | c0);
-    ua = __builtin_amdgcn_bitop3_b32(ua, ma0, ma1, 0xFE);     // a | b | c
-    ub = __builtin_amdgcn_bitop3_b32(ub, mb0, mb1, 0xFE);
-  }
-  // an odd value out, and every value that joins the set in this tile (the first tiles of a range), one at a time
-  uint32_t n_hot = n_hot0;
-  uint64_t have;
   for (;;) {
-    if (k < n_hot) {
+    const uint32_t n_hot = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
+    // wave-uniform loop, one dispatch per hot value; the values sit in a 64-bit scalar shift register, the counts go to
+    // 8-bit fields of two registers (values 0..3 / 4..7) with one shift-add each
+    uint64_t hv = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0])) >> (8u * k);
+    uint32_t p0 = st.p_hot[0], p1 = st.p_hot[1];
+    for (; k < n_hot && k < 4u; ++k, hv >>= 8) {
       uint32_t ma, mb;
-      hot_match(xa, xb, Ma, Mb, (uint32_t)hv & 0xFFu, ma, mb);
+      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);    // hot values are distinct: matching inside the rest is exact
       const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
-      add_field(k >> 1, c << (16u * (k & 1u)));
-      ua |= ma;
-      ub |= mb;
-      ++k;
+      p0 = (c << (8u * k)) + p0;
+      ra &= ~ma;
+      rb &= ~mb;
     }
-    have = __builtin_amdgcn_ballot_w64(((Ma & ~ua) | (Mb & ~ub)) != 0);
+    for (; k < n_hot; ++k, hv >>= 8) {
+      uint32_t ma, mb;
+      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);
+      const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
+      p1 = (c << (8u * (k - 4u))) + p1;
+      ra &= ~ma;
+      rb &= ~mb;
+    }
+    st.p_hot[0] = p0;
+    st.p_hot[1] = p1;
+    have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
     if (have == 0 || n_hot >= (uint32_t)kHot) break;
-    // a byte outside the hot set while the set has room: its value joins (the lines above then count it)
+    // a byte outside the hot set while the set has room: its value joins (the loop above then counts it)
     const int L = __builtin_ctzll(have);
-    const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)(Ma & ~ua), L), lb = (uint32_t)__builtin_amdgcn_readlane((int)(Mb & ~ub), L);
+    const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)ra, L), lb = (uint32_t)__builtin_amdgcn_readlane((int)rb, L);
     const uint32_t kbit = la ? (uint32_t)__builtin_ctz(la) : 32u + (uint32_t)__builtin_ctz(lb);
     const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)slot[L * 64 + kbit]);
     if (n_hot < 4u) st.hotp[0] |= v << (n_hot * 8u); else st.hotp[1] |= v << ((n_hot - 4u) * 8u);
-    hv = v;
-    k = n_hot;
-    st.n_hot = ++n_hot;
+    st.n_hot = n_hot + 1u;
   }
   if (have == 0) return;
   // the hot set is full: the rest is counted in the workgroup's LDS histogram byte by byte; a range that keeps coming
   // here has a large alphabet (unbinned qualities) and is better served by the dword loop of hist_tile_q
-  uint64_t r = (uint64_t)(Ma & ~ua) | ((uint64_t)(Mb & ~ub) << 32);
+  uint64_t r = (uint64_t)ra | ((uint64_t)rb << 32);
   const uint8_t* lane_bytes = slot + lane * 64;
+  bool q_high = false;
   while (r) {
     const int kb = __builtin_ctzll(r);
     r &= r - 1;
-    atomicAdd(&hq[(uint32_t)lane_bytes[kb] * kQRep + (lane & (kQRep - 1))], 1u);
+    const uint32_t byte = lane_bytes[kb];
+    if (kQWindow && byte >= (uint32_t)kQBins) q_high = true;
+    atomicAdd(&hq[(byte & (uint32_t)(kQBins - 1)) * kQRep + (lane & (kQRep - 1))], 1u);
   }
-  if (++st.qover > kHotOverflowTiles) {
-    // over to the dword loop for the rest of the range: what the lanes have counted so far goes to the LDS histogram now (eight
-    // atomics per lane, once per range), because that loop's pivot counter takes over hot16[0]
-    st.qmode = 1u;
-    const uint64_t hall = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0]);
-#pragma unroll
-    for (int j = 0; j < kHot; ++j) {
-      const uint32_t c = (st.hot16[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-      const uint32_t v = (uint32_t)(hall >> (8 * j)) & 0xFFu;
-      if (c) atomicAdd(&hq[v * kQRep + (lane & (kQRep - 1))], c);
-    }
-    st.hot16[0] = st.hot16[1] = st.hot16[2] = st.hot16[3] = 0u;
-  }
+  if (kQWindow && __builtin_amdgcn_ballot_w64(q_high) != 0) st.qbad = 1u;
+  if (++st.qover > kHotOverflowTiles) st.qmode = 1u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -753,7 +757,7 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       // plane matching needs the quality segment of a lane to be one of its first three segments: at most two newlines
       // per lane (any read of 30+ bases); other tiles, and ranges with a large quality alphabet, take the dword loop
       if (st.qmode == 0u && __builtin_amdgcn_ballot_w64(cnt > 2u) == 0) hist_tile_planes(xa, xb, hist_lds, slot, lane, sh0 >> 3, NL, st);
-      else hist_tile_q(hist_lds, slot, lane, sh0 >> 3, NL, cnt, st);
+      else hist_tile_q(hist_lds, slot, lane, sh0 >> 3, NL, cnt, (uint64_t)xa[7] | ((uint64_t)xb[7] << 32), st);
     }
   }
 
@@ -1074,19 +1078,22 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWa
     // that '\r' lies in the previous range, like len)
     const uint32_t crq = (qcls == 0) ? cr4.x : (qcls == 1) ? cr4.y : (qcls == 2) ? cr4.z : cr4.w;
     if (lane == 0 && crq) atomicSub(&hist_lds[13 * kQRep], crq);
-    if (st.qmode != 0u) {      // (wave-uniform) the dword loop's pivot counter: dwords of four pivot bytes that were counted in a register
-      const uint32_t pivots = wave_sum(st.hot16[0]);
-      if (lane == 0 && pivots) atomicAdd(&hist_lds[(st.piv4 & 0xFFu) * kQRep], 4u * pivots);
-    } else {                   // the plane-matching form's register counts
+    uint32_t bad = st.qbad;                            // (window layout) a count that belongs to a bin >= 128 voids the workgroup's histogram
+    const uint32_t pivots = wave_sum(st.piv_cnt);      // dwords of four pivot bytes that were counted in registers
+    const uint32_t pv = st.piv4 & 0xFFu;
+    if (kQWindow && pivots && pv >= (uint32_t)kQBins) bad = 1u;
+    if (lane == 0 && pivots) atomicAdd(&hist_lds[(pv & (uint32_t)(kQBins - 1)) * kQRep], 4u * pivots);
+    {   // the plane-matching form's register counts (flush_pending has widened them)
+      const uint4 lo4 = sum4(st.hot_lo), hi4 = sum4(st.hot_hi);
+      const uint32_t tot[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
       for (int k = 0; k < kHot; ++k) {
-        if ((uint32_t)k < st.n_hot) {
-          const uint32_t tot = wave_sum((st.hot16[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
-          const uint32_t v = ((k < 4 ? st.hotp[0] : st.hotp[1]) >> ((k & 3) * 8)) & 0xFFu;
-          if (lane == 0 && tot) atomicAdd(&hist_lds[v * kQRep], tot);
-        }
+        const uint32_t v = ((k < 4 ? st.hotp[0] : st.hotp[1]) >> ((k & 3) * 8)) & 0xFFu;
+        if (kQWindow && (uint32_t)k < st.n_hot && tot[k] && v >= (uint32_t)kQBins) bad = 1u;
+        if (lane == 0 && (uint32_t)k < st.n_hot && tot[k]) atomicAdd(&hist_lds[(v & (uint32_t)(kQBins - 1)) * kQRep], tot[k]);
       }
     }
+    if (kQWindow && bad && lane == 0) atomicOr(&hist_lds[kQFlagWord], 1u);
   }
   if (HIST == 1) {
     // per-range histogram partial [class][byte] (u32): sum the lane-keyed copies, then take back the bytes that
@@ -1108,11 +1115,15 @@ __global__ __launch_bounds__(HIST == 1 ? 64 * kHistWaves : HIST == 2 ? 64 * kQWa
   if (HIST == 2) {
     // workgroup histogram of the quality class: thread t sums the copies of byte value t
     __syncthreads();
+    const uint32_t voided = kQWindow ? hist_lds[kQFlagWord] : 0u;
     for (uint32_t t = threadIdx.x; t < 256; t += 64 * WAVES) {
-      const uint4* src = reinterpret_cast<const uint4*>(hist_lds + t * kQRep);
       uint32_t v = 0;
+      if (t < (uint32_t)kQBins && !(kQWindow && t == 10u)) {
+        const uint4* src = reinterpret_cast<const uint4*>(hist_lds + t * kQRep);
 #pragma unroll
-      for (int r = 0; r < kQRep / 4; ++r) { const uint4 q = src[r]; v += q.x + q.y + q.z + q.w; }
+        for (int r = 0; r < kQRep / 4; ++r) { const uint4 q = src[r]; v += q.x + q.y + q.z + q.w; }
+      }
+      if (kQWindow && t == 255u && voided) v = kQPoison;      // fq_hist_verify: this workgroup's ranges go to the exact kernel
       a.hist_wg[(uint64_t)blockIdx.x * 256 + t] = v;
     }
   }
@@ -1148,8 +1159,16 @@ __device__ __forceinline__ uint32_t block_rotate_sum(const uint64_t* mine /*W_BY
   rows[tid][W_NL] = mine[W_NL];
 #pragma unroll
   for (int arr = W_GC; arr < W_BYTES; arr += 4) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) rows[tid][arr + c] = mine[arr + ((c - phase) & 3u)];   // class r lands on (r + phase) & 3
+    // class r lands on (r + phase) & 3: out[c] = mine[arr + ((c - phase) & 3)].  Written as two conditional rotations — by one,
+    // by two — of four registers: indexed by a run-time value, `mine` became an array in scratch memory (208 bytes per lane;
+    // the runtime sets the device's scratch up inside the first launch of such a kernel, 35 - 50 ms of a process's first call)
+    uint64_t m0 = mine[arr], m1 = mine[arr + 1], m2 = mine[arr + 2], m3 = mine[arr + 3];
+    const bool by1 = (phase & 1u) != 0, by2 = (phase & 2u) != 0;
+    const uint64_t a0 = by1 ? m3 : m0, a1 = by1 ? m0 : m1, a2 = by1 ? m1 : m2, a3 = by1 ? m2 : m3;
+    rows[tid][arr + 0] = by2 ? a2 : a0;
+    rows[tid][arr + 1] = by2 ? a3 : a1;
+    rows[tid][arr + 2] = by2 ? a0 : a2;
+    rows[tid][arr + 3] = by2 ? a1 : a3;
   }
   __syncthreads();
   const int word = tid & 31, part = tid >> 5;          // T / 32 row groups per word
@@ -1271,7 +1290,7 @@ constexpr int kExtH = 0, kExtFast = 1, kExtRedo = 2, kExtWords = 8;
 constexpr uint64_t kFoldWgPer = 16;    // workgroup histograms summed per block of fq_fold_hist_wg
 __global__ __launch_bounds__(256) void fq_hist_verify(const uint8_t* guess, const uint8_t* rel_phase, const uint8_t* block_phase,
                                                       uint64_t n_ranges, int force_h, uint64_t* ext, uint8_t* todo,
-                                                      uint8_t* wg_ok) {
+                                                      uint8_t* wg_ok, const uint32_t* hist_wg) {
   __shared__ uint32_t s_first, s_fast, s_redo;
   const uint32_t tid = threadIdx.x;
   if (tid == 0) { s_first = 0xFFFFFFFFu; s_fast = 0; s_redo = 0; }
@@ -1293,7 +1312,8 @@ __global__ __launch_bounds__(256) void fq_hist_verify(const uint8_t* guess, cons
   const uint64_t b = (uint64_t)blockIdx.x * 256 + tid;
   if (b < n_wg) {
     const uint64_t r0 = b * kQWaves, r1 = (r0 + kQWaves < n_ranges) ? r0 + kQWaves : n_ranges;
-    bool poisoned = false;
+    // (window layout: a workgroup that met a quality byte its 128 bins cannot hold says so in bin 255)
+    bool poisoned = kQWindow && hist_wg[b * 256 + 255] == kQPoison;
     for (uint64_t r = r0; r < r1; ++r)
       if (guess[r] != kNoGuess && session_class(r) != H) poisoned = true;
     for (uint64_t r = r0; r < r1; ++r) {

@@ -141,6 +141,7 @@ struct Ctx {
   int dev = -1;
   int n_cu = 256;
   hipStream_t compute = nullptr, copy = nullptr;
+  bool copy_is_alias = false;           // `copy` IS the compute stream (no second chunk has had to move yet): want_copy_stream()
   uint64_t* d_partials = nullptr;
   uint64_t cap_ranges = 0;
   uint32_t* d_hist_partials = nullptr;
@@ -211,7 +212,7 @@ thread_local scfq_timing g_last_timing{};
 thread_local uint64_t g_hist_stats[2] = {0, 0};   // ranges of the last session taken from the fast K3 form / redone exactly
 
 int new_ctx(int dev, std::unique_ptr<Ctx>* out);
-
+int want_copy_stream(Ctx* c);
 std::map<int, int> g_ctx_creating;      // (under g_mu) contexts of a device being created right now
 std::condition_variable g_ctx_cv;       // a context joined a pool, or a creation ended (with or without one)
 
@@ -267,9 +268,15 @@ int new_ctx(int dev, std::unique_ptr<Ctx>* out) {
   HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   c->n_cu = n_cu > 0 ? n_cu : 256;
   trace("  device attributes read");
+  // ONE stream to begin with: a stream costs 8 - 16 ms to create, and an input of one chunk (a gzip file of one batch, a BGZF or
+  // plain file of one chunk) is a chain — its copy and its kernels have nothing to overlap with.  `copy` is the compute stream
+  // under another name until a path has a second chunk to move (want_copy_stream()).
+  // (r4, measured and dropped: the second stream and the pinned ring created on helper threads beside the first stream — the
+  // runtime serialises the three, the context came up in 64 ms instead of 56; profiles/r04/cold_stages_parallel_bringup.jsonl)
   HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
-  trace("  streams created");
+  c->copy = c->compute;
+  c->copy_is_alias = true;
+  trace("  compute stream created");
   HIPCHK(hipMalloc(&c->d_state, kStateWords * sizeof(uint64_t) + 64));
   c->d_ticket = reinterpret_cast<uint32_t*>(c->d_state + kStateWords);      // (the fold's arrival counter lives behind the state words)
   HIPCHK(hipHostMalloc(&c->h_state, kStateWords * sizeof(uint64_t), hipHostMallocDefault));
@@ -281,6 +288,18 @@ int new_ctx(int dev, std::unique_ptr<Ctx>* out) {
   }
   *out = std::move(c);
   trace("context up");
+  return SCFQ_OK;
+}
+
+// a copy stream of its own, from now on (idempotent).  What was queued on the alias stays ordered: it is on the compute stream,
+// and every consumer of a copy waits for the event recorded behind it, whichever stream that was.
+int want_copy_stream(Ctx* c) {
+  if (!c->copy_is_alias) return SCFQ_OK;
+  hipStream_t st = nullptr;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  c->copy = st;
+  c->copy_is_alias = false;
+  trace("copy stream created (a second chunk to move)");
   return SCFQ_OK;
 }
 
@@ -325,19 +344,21 @@ int ensure_staging(Ctx* c, uint64_t chunk, bool pinned) {
     HIPCHK(hipStreamSynchronize(c->copy));
     for (int b = 0; b < 2; ++b) {
       if (c->d_stage[b]) HIPCHK(hipFree(c->d_stage[b]));
-      if (c->h_pin[b]) HIPCHK(hipHostFree(c->h_pin[b]));
       c->d_stage[b] = nullptr;
-      c->h_pin[b] = nullptr;
     }
+    if (c->h_pin[0]) HIPCHK(hipHostFree(c->h_pin[0]));      // (both halves are one allocation)
+    c->h_pin[0] = c->h_pin[1] = nullptr;
     note_dev_bytes(-(int64_t)(2 * c->stage_cap));      // (what was freed above)
     c->stage_cap = 0;
     for (int b = 0; b < 2; ++b) HIPCHK(hipMalloc(&c->d_stage[b], chunk));
     note_dev_bytes((int64_t)(2 * chunk));
     c->stage_cap = chunk;
   }
-  if (pinned) {
-    for (int b = 0; b < 2; ++b)
-      if (!c->h_pin[b]) { HIPCHK(hipHostMalloc(&c->h_pin[b], c->stage_cap, hipHostMallocDefault)); if (b) trace("pinned staging ring allocated"); }
+  if (pinned && !c->h_pin[0]) {
+    // (ONE allocation for the two halves: a pinned allocation costs milliseconds before its first byte)
+    HIPCHK(hipHostMalloc(&c->h_pin[0], 2 * c->stage_cap, hipHostMallocDefault));
+    c->h_pin[1] = c->h_pin[0] + c->stage_cap;
+    trace("pinned staging ring allocated");
   }
   return SCFQ_OK;
 }
@@ -448,7 +469,7 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
       uint64_t* ext = c->d_state + kExtAt;
       const uint64_t n_wg = (n_ranges + scfq::kQWaves - 1) / scfq::kQWaves;
       hipLaunchKernelGGL(scfq::fq_hist_verify, dim3((unsigned)((n_wg + 255) / 256)), dim3(256), 0, c->compute, c->d_guess, rel_phase, block_phase, n_ranges,
-                         c->from_start ? 0 : -1, ext, c->d_todo, c->d_wg_ok);
+                         c->from_start ? 0 : -1, ext, c->d_todo, c->d_wg_ok, c->d_hist_wg);
       HIPCHK(hipGetLastError());
       a.todo = c->d_todo;
       if (strct) launch_scan<true, 1, 2, true>(a, blocks, c->compute);
@@ -657,6 +678,8 @@ int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_part
 
 #include "scfq_sources.hpp"   // Source, MemSource, FdSource, GzSource, FastGzSource, BgzfSource, open_gz_source
 
+// (r4, measured and dropped: filling in the page tables of the mapped file on a helper thread — MADV_POPULATE_READ — while the runtime
+// comes up.  The copies into the pinned ring ran no faster: 10.7 against 11.7 ms for a 121 MB file, profiles/r04/cold_stages_*.jsonl.)
 // `n` bytes of host (pageable: a mapped file) memory to device memory through the context's pinned ring, in pieces: a piece
 // crosses PCIe while the next one is copied into the other pinned buffer, so the bytes are on the device one piece after the last
 // of them reached pinned memory — and the ring is 2 x 16 MiB, not two buffers of the size of a chunk (pinning memory costs
@@ -696,6 +719,7 @@ int ingest(Ctx* c, Source& src, int prev_byte, uint32_t flags, uint64_t chunk, b
     if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));   // pinned buffer b is free again
     const auto tf = clk::now();
     int64_t got = src.fill(c->h_pin[b], chunk);
+    if (it == 1 && got > 0 && (rc = want_copy_stream(c))) return rc;      // a second chunk: its copy runs under the first one's scan
     fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     if (got < 0) return (int)got;
     if (got == 0) break;
@@ -912,6 +936,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
       }
     }
     const bool first = it == 0;
+    if (it == 1 && (rc = want_copy_stream(c))) return rc;      // a second chunk: its copy runs under the first one's inflate and scan
     const uint64_t chunk = first ? c->inf_first_cap : c->inf_cap, comp_chunk = first ? c->comp_first_cap : c->comp_cap;
     uint8_t* const d_comp = first ? c->d_comp_first : c->d_comp[b];
     uint8_t* const d_inf = first ? c->d_inf_first : c->d_inf[b];
@@ -1173,6 +1198,11 @@ static int count_file_partial(const char* path, const scfq_opts* opts, scfq_part
       struct stat bsb;
       if (bfd >= 0 && fstat(bfd, &bsb) == 0 && S_ISREG(bsb.st_mode) && !std::getenv("SCFQ_NO_BGZF") && scfq_bgzf::probe(bfd)) {
         if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) { close(bfd); return SCFQ_EHIP; }
+        void* m = MAP_FAILED;
+        if (bgzf_device_enabled() && bsb.st_size > 0) {
+          m = mmap(nullptr, (size_t)bsb.st_size, PROT_READ, MAP_PRIVATE, bfd, 0);
+          if (m != MAP_FAILED) (void)madvise(m, (size_t)bsb.st_size, MADV_SEQUENTIAL);
+        }
         Ctx* c = nullptr;
         SessionLock sl;
         rc = get_ctx(&c, sl);
@@ -1180,18 +1210,16 @@ static int count_file_partial(const char* path, const scfq_opts* opts, scfq_part
         bool on_device = false;
         if (!rc && bgzf_device_enabled() && bsb.st_size > 0) {
           // pure BGZF (every member <= 64 KiB with its size in the header): compressed bytes over PCIe, inflate on the device
-          void* m = mmap(nullptr, (size_t)bsb.st_size, PROT_READ, MAP_PRIVATE, bfd, 0);
           if (m != MAP_FAILED) {
-            (void)madvise(m, (size_t)bsb.st_size, MADV_SEQUENTIAL);
             // (no purity walk up front: touching every member header of a mapped 1 GB file costs 15 ms of page faults;
             // the chunk planner walks them anyway, under the device's work, and reports what it cannot take)
             rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing);
             on_device = (rc != kFallbackToHost && rc != kNotPureBgzf);
             if (rc == kNotPureBgzf) rc = begin_session(c, true);      // drop what the device path accumulated
             else if (!on_device) rc = SCFQ_OK;
-            munmap(m, (size_t)bsb.st_size);
           }
         }
+        if (m != MAP_FAILED) munmap(m, (size_t)bsb.st_size);
         if (!rc && !on_device) {
           BgzfSource src(bfd, (uint64_t)bsb.st_size);
           rc = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
@@ -1366,6 +1394,72 @@ bool bgzf_cut(const uint8_t* img, uint64_t n, uint64_t from, uint64_t* cut, int*
   *cut = n;
   return true;
 }
+// ---- ordinary gzip shards: a file of SEVERAL members is cut where members start ------------------------------------------------
+// (`cat a.fq.gz b.fq.gz`, `pigz -i`, per-lane or per-tile members of a sequencer's writer.)  Unlike BGZF a member does not say how long
+// it is, so a rank that starts in the middle of the file can only LOOK for a member start: the three magic bytes with no reserved flag
+// bit set, a header that parses, and deflate data that inflates cleanly for its first 64 KiB — a block header made of chance bits
+// survives the Huffman-code tests about once in 4000 tries and then dies within a few hundred symbols.  That makes a false start
+// unlikely, not impossible; what PROVES a cut is the rank before it: its members must end — trailer, CRC-32 and ISIZE checked —
+// exactly where the next rank began (gz_shard_fold below), or every rank falls back to rank 0 reading the whole file.
+//
+// gz_member_here: true when a member demonstrably starts at p.  *first_byte: the first byte it (or, when it is empty, a member
+// behind it, inside [p, stop)) inflates to; -1 when there is none in that stretch.
+bool gz_member_here(const uint8_t* img, uint64_t n, uint64_t p, uint64_t stop, int* first_byte) {
+  *first_byte = -1;
+  std::vector<uint8_t> buf;
+  bool first = true;
+  while (p < n && (first || p < stop)) {
+    if (n - p < 18 || img[p] != 0x1f || img[p + 1] != 0x8b || img[p + 2] != 8 || (img[p + 3] & 0xE0)) return !first;
+    const long h = scfq_gzfast::member_header(img + p, (size_t)(n - p));
+    if (h <= 0) return !first;
+    const uint64_t sample = std::min<uint64_t>(n - (p + (uint64_t)h), 64u << 10);
+    if (buf.empty()) buf.resize(scfq_gzfast::kWindow + (2u << 20));
+    auto dec = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
+    dec->begin(img + p + h, img + p + h + sample);
+    uint8_t* o = buf.data() + scfq_gzfast::kWindow;
+    const int r = dec->run(o, buf.data() + buf.size());
+    const uint64_t got = (uint64_t)(o - (buf.data() + scfq_gzfast::kWindow));
+    if (r == scfq_inflate::kErrData) return !first;
+    if (r == scfq_inflate::kErrTruncated && sample == n - (p + (uint64_t)h)) return !first;      // (the FILE ends inside the member: damaged)
+    if (got) { *first_byte = buf[scfq_gzfast::kWindow]; return true; }
+    if (r != scfq_inflate::kStreamEnd) return true;            // (no byte yet and no end either: a long run of empty stored blocks; rare, harmless)
+    // an empty member: the first byte is a later member's
+    const uint8_t* t = dec->end_of_stream();
+    first = false;
+    p = (uint64_t)(t - img) + 8;
+  }
+  return true;
+}
+// the first demonstrable member start at or after `from`; n when there is none.  *first_byte as above (stop: the end of the rank's stretch)
+uint64_t gz_member_boundary(const uint8_t* img, uint64_t n, uint64_t from, uint64_t stop, int* first_byte) {
+  *first_byte = -1;
+  for (uint64_t p = from; p + 18 <= n;) {
+    const void* hit = std::memchr(img + p, 0x1f, (size_t)(n - 17 - p));
+    if (!hit) break;
+    p = (uint64_t)(static_cast<const uint8_t*>(hit) - img);
+    if (img[p + 1] == 0x8b && img[p + 2] == 8 && !(img[p + 3] & 0xE0) && gz_member_here(img, n, p, std::max(stop, p + 1), first_byte)) return p;
+    ++p;
+  }
+  return n;
+}
+
+// A shard that was scanned as if it began the input (no byte before it is known when its scan starts: that byte is the LAST one the
+// member before inflates to), put right once that byte is known.  Two things depend on it: a '\n' at the shard's first position ends
+// a line whose '\r' — if the byte before is one — is not part of that line (len, and the quality histogram's '\r' bin, are taken back
+// exactly as a range of the device path takes back a '\r' that lies in the range before it: u64 modular); and the shard's first byte
+// starts a line only when the byte before is a '\n' (K4's line starts, and what they begin with).
+void gz_shard_fix(scfq_partial* p, uint64_t* hist, int true_prev, int first_byte, uint32_t flags) {
+  if (p->bytes == 0 || true_prev < 0 || first_byte < 0) return;
+  if (first_byte == '\n' && true_prev == '\r') {
+    p->len[0] -= 1;
+    if (hist && (p->hist_class == 0 || p->hist_class == 1)) hist[0 * 256 + 13] -= 1;
+  }
+  if ((flags & SCFQ_STRUCT_CHECK) && true_prev != '\n') {
+    p->starts[0] -= 1;
+    if (first_byte == '@') p->first_at[0] -= 1;
+    if (first_byte == '+') p->first_plus[0] -= 1;
+  }
+}
 }  // namespace
 extern "C" {
 
@@ -1412,16 +1506,112 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
         mine_ok = ok ? 1 : 0;
       }
     }
+    // An ordinary gzip file (bit 1 of the word the ranks exchange): rank r's members are those that start in [g_lo, g_hi), where a cut is
+    // the first demonstrable member start at or after size * r / world (gz_member_boundary; both neighbours find the same one from the
+    // bytes alone).  A file of ONE member gives every cut but rank 0's as "none": rank 0 has all of it, as before.
+    static const bool shard_gz = env_int("SCFQ_SHARD_GZ", 1) != 0;
+    uint64_t g_lo = 0, g_hi = 0;
+    int g_first = -1;
+    if (!mine_ok && !img && fd >= 0 && shard_gz && gz_device_enabled() && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 64) {
+      void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m != MAP_FAILED) {
+        img = static_cast<const uint8_t*>(m);
+        size = (uint64_t)sb.st_size;
+        int f_hi = -1;
+        const uint64_t nom_lo = size / (uint64_t)world * (uint64_t)rank, nom_hi = size / (uint64_t)world * (uint64_t)(rank + 1);
+        g_hi = rank + 1 < world ? gz_member_boundary(img, size, nom_hi, nom_hi, &f_hi) : size;
+        if (rank == 0) g_lo = gz_member_here(img, size, 0, std::max<uint64_t>(g_hi, 1), &g_first) ? 0 : size + 1;      // (size + 1: not a gzip file at all)
+        else g_lo = gz_member_boundary(img, size, nom_lo, g_hi, &g_first);
+        if (g_lo <= size) { if (g_hi < g_lo) g_hi = g_lo; mine_ok = 2; }
+      }
+    }
     std::vector<uint64_t> oks((size_t)world, 0);
-    bool sharded = false;
+    bool sharded = false, sharded_gz = false;
     if (world > 1 && shard_bgzf) {
       // (every rank takes part in this all-gather whatever it found: a rank that cannot even open the file says 0)
       rc = scfq_comm_allgather_u64(comm, &mine_ok, 1, oks.data(), 0);
       if (rc) { if (img) munmap(const_cast<uint8_t*>(img), (size_t)size); if (fd >= 0) close(fd); std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return rc; }
-      sharded = true;
-      for (int r = 0; r < world; ++r) sharded = sharded && oks[(size_t)r] == 1;
+      sharded = sharded_gz = true;
+      for (int r = 0; r < world; ++r) { sharded = sharded && oks[(size_t)r] == 1; sharded_gz = sharded_gz && oks[(size_t)r] == 2; }
     }
-    if (sharded) {
+    if (sharded_gz) {
+      // every rank inflates and scans the members of its stretch as if they were a file of their own (device path; the host's decoder
+      // when that declines), scanned as if they began the input; the partials — with each stretch's first byte and whether its members
+      // ended exactly where the next rank's begin — are gathered and folded here, in rank order, with the byte before each stretch
+      // (the last byte of the stretch before it) put right first: gz_shard_fix.
+      if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) local = SCFQ_EHIP;
+      uint64_t end_off = 0;
+      if (!local && g_hi > g_lo) {
+        Ctx* c = nullptr;
+        SessionLock sl;
+        local = get_ctx(&c, sl);
+        if (!local) local = begin_session(c, rank == 0);
+        if (!local) {
+          const uint64_t len = g_hi - g_lo;
+          static const uint64_t min_bytes = (uint64_t)std::max(0, env_int("SCFQ_GZ_DEVICE_MIN_MB", 4)) << 20;
+          local = len >= std::max<uint64_t>(min_bytes, 64) ? ingest_gz_device(c, img + g_lo, len, o.flags, timing, &end_off) : kFallbackToHost;
+          if (local == kFallbackToHost) {
+            // (small stretches, and whatever the device path declines: the host's decoder over the same bytes — Resume from the first
+            // block of the stretch's first member, an empty window, no prefix)
+            (void)hipStreamSynchronize(c->compute);
+            (void)hipStreamSynchronize(c->copy);
+            local = begin_session(c, rank == 0);
+            const long h = scfq_gzfast::member_header(img + g_lo, (size_t)len);
+            if (!local && h <= 0) local = SCFQ_EGZ;
+            if (!local) {
+              struct RangeSource : Source {
+                scfq_gzfast::Resume rs;
+                int64_t fill(uint8_t* dst, uint64_t cap) override { const int64_t r = rs.next_chunk(dst, cap); return r < 0 ? (int64_t)SCFQ_EGZ : r; }
+              } src;
+              const std::vector<uint8_t> no_window(scfq_gzfast::kWindow, 0);
+              src.rs.open(img + g_lo, (size_t)len, (uint64_t)h * 8, no_window.data(), 0, 0, 0);
+              local = ingest(c, src, -1, o.flags, opt_chunk(&o), timing);
+              end_off = src.rs.end_offset();
+            }
+          }
+          // the stretch must be members and nothing else, up to the very byte the next stretch starts at (only the file's last stretch may
+          // have the trailing bytes gzread ignores behind it)
+          if (!local && end_off != len && g_hi < size) { local = SCFQ_EGZ; std::snprintf(g_err, sizeof g_err, "shard %d: its members end at byte %llu, the next shard begins at %llu", rank, (unsigned long long)(g_lo + end_off), (unsigned long long)g_hi); }
+        }
+        if (!local) local = end_session(c, want_hist, &mine, want_hist ? hist.data() : nullptr);
+      }
+      if (img) munmap(const_cast<uint8_t*>(img), (size_t)size);
+      if (fd >= 0) close(fd);
+      if (local) scfq_partial_identity(&mine, want_hist ? hist.data() : nullptr);
+      mine.reserved[0] = (uint64_t)(int64_t)local;
+      mine.reserved[1] = (uint64_t)(g_first + 1);          // 0: this stretch holds no byte
+      const uint32_t words = SCFQ_PARTIAL_WORDS + (want_hist ? SCFQ_HIST_WORDS : 0);
+      std::vector<uint64_t> row(words), rows((size_t)world * words);
+      std::memcpy(row.data(), &mine, sizeof mine);
+      if (want_hist) std::memcpy(row.data() + SCFQ_PARTIAL_WORDS, hist.data(), SCFQ_HIST_WORDS * sizeof(uint64_t));
+      rc = scfq_comm_allgather_u64(comm, row.data(), words, rows.data(), 0);
+      if (rc) { std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return local ? local : rc; }
+      bool all_ok = true;
+      for (int r = 0; r < world; ++r) all_ok = all_ok && rows[(size_t)r * words + offsetof(scfq_partial, reserved) / 8] == 0;
+      if (all_ok) {
+        scfq_partial_identity(&all, want_hist ? hist_all.data() : nullptr);
+        int before = -1;      // the last byte in front of the stretch being added (-1: nothing yet)
+        for (int r = 0; r < world; ++r) {
+          scfq_partial pr;
+          std::memcpy(&pr, rows.data() + (size_t)r * words, sizeof pr);
+          uint64_t* hr = want_hist ? rows.data() + (size_t)r * words + SCFQ_PARTIAL_WORDS : nullptr;
+          gz_shard_fix(&pr, hr, before, (int)pr.reserved[1] - 1, o.flags);
+          pr.reserved[1] = 0;
+          if ((rc = scfq_partial_combine(&all, &pr, want_hist ? hist_all.data() : nullptr, hr))) return rc;
+          if (pr.bytes) before = (int)(pr.last_byte & 0xFF);
+        }
+        return scfq_partial_finalize(&all, want_hist ? hist_all.data() : nullptr, out);
+      }
+      // a cut that was no member start after all (or a damaged file): every rank knows, rank 0 reads the whole file the ordinary way —
+      // its readers are gzread byte for byte, error text included — and the others contribute the identity to the exchange below
+      local = SCFQ_OK;
+      scfq_partial_identity(&mine, want_hist ? hist.data() : nullptr);
+      if (rank == 0) {
+        scfq_opts o1 = o;
+        o1.n_devices = std::min(o.n_devices, 1);
+        local = count_file_partial(path, &o1, &mine, want_hist ? hist.data() : nullptr);
+      }
+    } else if (sharded) {
       if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) local = SCFQ_EHIP;
       if (!local && b_hi > b_lo) {
         Ctx* c = nullptr;
@@ -1444,8 +1634,10 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
       o1.n_devices = std::min(o.n_devices, 1);
       local = count_file_partial(path, &o1, &mine, want_hist ? hist.data() : nullptr);
     }
-    if (img) munmap(const_cast<uint8_t*>(img), (size_t)size);
-    if (fd >= 0) close(fd);
+    if (!sharded_gz) {
+      if (img) munmap(const_cast<uint8_t*>(img), (size_t)size);
+      if (fd >= 0) close(fd);
+    }
   } else {
     const int fd = open(path, O_RDONLY);
     struct stat sb;
@@ -1482,6 +1674,26 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
   return scfq_partial_finalize(&all, want_hist ? hist_all.data() : nullptr, out);
 }
 
+// host only (include/sc_fqcount_debug.h): the two rules of the gzip-member shards, for the CPU tests
+int64_t scfq_debug_gz_member_boundary(const char* path, uint64_t from, int* first_byte) {
+  if (!path || !first_byte) return SCFQ_EARG;
+  const int fd = open(path, O_RDONLY);
+  struct stat sb;
+  if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size == 0) { if (fd >= 0) close(fd); return SCFQ_EOPEN; }
+  void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return SCFQ_EIO;
+  const uint64_t n = (uint64_t)sb.st_size;
+  const uint64_t at = gz_member_boundary(static_cast<const uint8_t*>(m), n, std::min(from, n), n, first_byte);
+  munmap(m, (size_t)n);
+  return (int64_t)at;
+}
+int scfq_debug_gz_shard_fix(scfq_partial* p, uint64_t* hist, int true_prev, int first_byte, uint32_t flags) {
+  if (!p) return SCFQ_EARG;
+  gz_shard_fix(p, hist, true_prev, first_byte, flags);
+  return SCFQ_OK;
+}
+
 int scfq_prepare(const scfq_opts* opts) {
   int rc = check_opts(opts);
   if (rc) return rc;
@@ -1495,6 +1707,7 @@ int scfq_prepare(const scfq_opts* opts) {
     SessionLock sl;
     rc = get_ctx(&c, sl);
     if (!rc) rc = ensure_staging(c, kDefaultChunk, true);
+    if (!rc) rc = want_copy_stream(c);
   }
   (void)hipSetDevice(prev);
   if (!rc && o.n_devices > 1 && !exchange_on_host(o.device_ids, o.n_devices)) {
@@ -1514,9 +1727,9 @@ int scfq_shutdown(void) {
     (void)hipSetDevice(c->dev);
     if (c->compute) (void)hipStreamSynchronize(c->compute);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
+    if (c->h_pin[0]) (void)hipHostFree(c->h_pin[0]);
     for (int b = 0; b < 2; ++b) {
       if (c->d_stage[b]) (void)hipFree(c->d_stage[b]);
-      if (c->h_pin[b]) (void)hipHostFree(c->h_pin[b]);
       if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]);
       if (c->ev_scanned[b]) (void)hipEventDestroy(c->ev_scanned[b]);
     }
@@ -1546,7 +1759,7 @@ int scfq_shutdown(void) {
     for (hipEvent_t e : c->cp_pool) (void)hipEventDestroy(e);
     if (c->ev_caller) (void)hipEventDestroy(c->ev_caller);
     if (c->compute) (void)hipStreamDestroy(c->compute);
-    if (c->copy) (void)hipStreamDestroy(c->copy);
+    if (c->copy && !c->copy_is_alias) (void)hipStreamDestroy(c->copy);
   }
   scfq_dedup_release_pools();     // fq-dedup keeps its scratch in library-owned stream-ordered pools: give them back
   release_comms();                // communicators of the single-process multi-device path
@@ -1591,6 +1804,7 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
           SessionLock sl;
           rc = get_ctx(&c, sl);
           if (rc) return rc;
+          if ((rc = want_copy_stream(c))) return rc;      // (staging a whole file: chunk k + 1 crosses PCIe under chunk k's work)
           rc = ensure_bgzf_device_buffers(c, fsize);
           if (rc == SCFQ_OK) {
             uint8_t* d_buf = nullptr;
@@ -1664,6 +1878,7 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
   SessionLock sl;
   rc = get_ctx(&c, sl);
   if (rc) return rc;
+  if ((rc = want_copy_stream(c))) return rc;      // (staging a whole file: chunk k + 1 crosses PCIe under chunk k's work)
   const uint64_t chunk = opt_chunk(opts);
   rc = ensure_staging(c, chunk, true);
   if (rc) return rc;

@@ -17,6 +17,13 @@
 // gzread's behaviour for it byte by byte (partial output, SCFQ_EGZ).  CRC-32 and ISIZE of every member are checked before
 // the result is handed out.
 
+// one half of the pinned ring the compressed bytes of a file cross in (see ingest_gz_device_batches: "the pinned ring")
+inline uint64_t gz_ring_piece(uint64_t comp_bytes) {
+  static const int ring_env = env_int("SCFQ_GZ_DEVICE_RING_MB", 0);
+  return ring_env > 0 ? ((uint64_t)std::min(256, std::max(4, ring_env)) << 20)
+                      : comp_bytes > (1ull << 30) ? (128ull << 20) : comp_bytes > (256ull << 20) ? (64ull << 20) : (16ull << 20);
+}
+
 inline bool gz_device_enabled() {
   static const bool v = [] { const char* e = std::getenv("SCFQ_GZ_DEVICE"); return e ? e[0] != '0' : true; }();
   return v;
@@ -129,7 +136,7 @@ struct GzPart {            // the bytes of one member inside one batch: a run of
 };
 struct GzMemberEnd { uint32_t member; uint32_t crc, isize; };
 
-int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing) {
+int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off) {
   using namespace scfq_dinflate;
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
@@ -221,6 +228,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // streams (copy + search on one, decode and everything behind it on the other): creating a stream costs 10 - 15 ms, and an
   // engine's three were half of what a small file's first call paid.  Files of several batches get the engine's own streams: the
   // search of batch k + 1, the decodes of two batches and the post-processing of a third overlap.
+  if (nb > 1 && (rc = want_copy_stream(c))) return rc;      // (a file of one batch is a chain: the context's one stream carries all of it)
   hipStream_t s_search = c->copy, s_dec[2] = {c->compute, c->compute};
   if (nb > 1) {
     if (!g.s_search) {
@@ -348,9 +356,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // decode waves of two batches on the device a piece crosses PCIe at 26 - 30 GB/s instead of 55, every piece costs the copier a
   // round of eight memcpy threads, and the orchestrating thread waited for the copier 94 / 75 / 39 ms of a 10 GB file's 187 / 169 /
   // 156 ms with pieces of 16 / 64 / 128 MiB (profiles/r03/gz_device_variants.txt); pinning 2 x 128 MiB costs a process 40 ms.
-  static const int ring_env = env_int("SCFQ_GZ_DEVICE_RING_MB", 0);
-  const uint64_t want_piece = ring_env > 0 ? ((uint64_t)std::min(256, std::max(4, ring_env)) << 20)
-                                           : comp > (1ull << 30) ? (128ull << 20) : comp > (256ull << 20) ? (64ull << 20) : (16ull << 20);
+  const uint64_t want_piece = gz_ring_piece(comp);
   rc = ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
   if (rc) return rc;
   trace("gzip engine: pinned ring ready");
@@ -369,6 +375,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // ---- state that travels from batch to batch ------------------------------------------------------------------------------
   uint64_t pos = data0 * 8;              // the exact bit the chain has reached
   bool finished = false;                 // the last member's final block has been walked and no further member follows
+  uint64_t end_byte = 0;                 // ... and where that was: the offset just behind its trailer
   uint32_t member_no = 0;                // running member that `pos` lies in
   uint32_t valid = 0;                    // bytes of that member's history in front of pos (<= 32768)
   int wcarry = 0;                        // which of the two carried windows is the current one
@@ -587,6 +594,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     uint64_t pos_end = pos;
     uint32_t member_end_no = member_no;
     bool finished_end = false;
+    uint64_t end_byte_here = 0;
     std::vector<GzMemberEnd> ends_here;
     for (int round = 0;; ++round) {
       std::map<uint64_t, uint32_t> by_start;
@@ -655,7 +663,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
           ends_here.push_back(me);
           const long h = scfq_gzfast::member_header(img + q + 8, (size_t)(fsize - (q + 8)));
           if (h < 0) return SCFQ_GZ_DECLINE;                   // a damaged further header: the host path decides
-          if (h == 0) { finished_end = true; done = true; break; }   // end of file, or trailing garbage (ignored, as gzread does)
+          if (h == 0) { finished_end = true; end_byte_here = q + 8; done = true; break; }   // end of file, or trailing garbage (ignored, as gzread does)
           p = (q + 8 + (uint64_t)h) * 8;
           ++mno;      // (any number of members: the parts of a member, its trailer and the window state travel from batch to batch)
         } else {
@@ -892,6 +900,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     member_no = member_end_no;
     valid = valid_end;
     finished = finished_end;
+    if (finished_end) end_byte = end_byte_here;
     release_comp(k);
     if (k == 0) trace("gzip engine: first batch walked, its windows / bytes / CRC / scan queued");
     return SCFQ_OK;
@@ -981,12 +990,14 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     rest.rs.open(img, (size_t)fsize, pos, window.data(), valid, crc_prefix, prefix_len);
     rc = ingest(c, rest, prev, flags, 64ull << 20, timing);
     if (rc) return rc;
+    end_byte = rest.rs.end_offset();
     resumed = true;
   } else if ((rc = check_members())) {
     return rc;
   } else if (parts_checked != parts.size()) {
     return SCFQ_GZ_DECLINE;
   }
+  if (end_off) *end_off = end_byte;
   fill_ms += cp.fill_ms;
   c->timing.h2d_bytes += cp.bytes;
   for (const Span& sp : cp.spans) sp_copy.push_back(sp);
@@ -1019,7 +1030,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
 // An engine of the device's pool for the length of the call (GzShared, scfq_api.hip); every stream of the path is idle when this
 // returns, whatever the outcome — the scan of the last batch included, which reads the engine's output buffer: the buffers belong to
 // the next caller.
-int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing) {
+// end_off (optional): the offset just behind the last member's trailer — fsize unless bytes that are not a gzip member follow it
+int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off = nullptr) {
   GzShared& gs = gz_shared(c->dev);
   static const int n_engines = std::min((int)GzShared::kMax, std::max(1, env_int("SCFQ_GZ_DEVICE_ENGINES", 4)));
   const bool big = fsize > (1ull << 30);
@@ -1037,7 +1049,7 @@ int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags,
     gs.big_running = big;
   }
   GzDevBuffers& g = gs.buf[e];
-  const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing);
+  const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing, end_off);
   if (c->copy) (void)hipStreamSynchronize(c->copy);
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
   if (g.s_gap) (void)hipStreamSynchronize(g.s_gap);

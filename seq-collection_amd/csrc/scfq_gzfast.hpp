@@ -269,7 +269,7 @@ class Resume {
       crc_ = 0; len_ = 0;
       t += 8;
       const long nh = member_header(t, (size_t)(end - t));
-      if (nh == 0) { last = true; break; }
+      if (nh == 0) { last = true; end_off_ = (size_t)(t - img_); break; }
       if (nh < 0) { bad = true; break; }
       dec_->begin(t + nh, end);
     }
@@ -296,6 +296,12 @@ class Resume {
   uint32_t crc_ = 0;
   uint64_t len_ = 0;
   bool finished_ = false, failed_ = false;
+  size_t end_off_ = 0;
+
+ public:
+  // once next_chunk() has returned 0: the offset just behind the last member's trailer (the end of the image, or where trailing
+  // bytes that are not a gzip member begin)
+  size_t end_offset() const { return end_off_; }
 };
 
 }  // namespace scfq_gzfast

@@ -40,6 +40,7 @@ EXPORTS = [
     "scfq_comm_unique_id", "scfq_comm_init_rank", "scfq_comm_init_rendezvous", "scfq_comm_init_all", "scfq_comm_world",
     "scfq_comm_rank", "scfq_comm_is_broken", "scfq_prepare", "scfq_comm_transport", "scfq_comm_exchange", "scfq_comm_exchange_start", "scfq_comm_exchange_finish",
     "scfq_comm_allgather_u64", "scfq_comm_destroy", "scfq_comm_error_detail", "scfq_debug_stages", "scfq_debug_stage_mark",
+    "scfq_debug_gz_member_boundary", "scfq_debug_gz_shard_fix",
 ]
 
 

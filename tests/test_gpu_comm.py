@@ -213,6 +213,110 @@ def test_bench_ingest_object(gpu):
     j = _bench(["--gpus", "1", "--bytes-per-gpu", "3e8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--ingest-bytes", "4e8"])
     ing = j["ingest"]
     for k in ("gzip_member", "bgzf"):
-        assert ing[k]["counters_match_generator"] is True and ing[k]["compressed_bytes"] < ing["inflated_bytes"] // 2
+        assert ing[k]["counters_match_generator"] is True and ing[k]["compressed_bytes"] < ing[k]["inflated_bytes"] // 2
         assert 0 < ing[k]["warm_wall_s"] <= ing[k]["cold_process_wall_s"]
+        marks = [m[0] for m in ing[k]["cold_stages_ms"]["median_run"]["marks"]]      # where a fresh process's time went
+        assert "runtime initialised (hipGetDevice returned)" in marks and "context up" in marks and "session folded" in marks
+        w = ing[k]["cold_process_walls_s"]
+        assert w["min"] <= w["median"] <= w["max"]
+    ho = ing["gzip_member_host_inflate_overlap"]          # the same member inflated on the host, overlapped with copy + scan
+    assert ho["counters_match_generator"] is True and ho["scan_kernel_ms"] < 0.5 * ho["host_fill_ms"]
     assert ing["device_bytes_high_water"] > 0
+
+
+def _gz_members(data, cuts, level=6):
+    import zlib
+    out = []
+    for a, b in zip([0] + cuts, cuts + [len(data)]):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31)
+        out.append(co.compress(data[a:b]) + co.flush())
+    return out
+
+
+def _run_ranks(sc, world, path, extra=(), env=None):
+    port = _free_port()
+    procs = [subprocess.Popen([sc, "fq-count", "--shard-rank=%d" % r, "--shard-world=%d" % world, "--rendezvous=127.0.0.1:%d" % port,
+                               "--transport=tcp", "--devices=0", "--stats"] + list(extra) + [str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=dict(os.environ, **(env or {}))) for r in reversed(range(world))]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, outs
+    stats = []
+    for so, se in outs:
+        st = [json.loads(ln) for ln in se.splitlines() if ln.startswith("{")]
+        stats.append(st[-1] if st else None)
+    return outs, stats
+
+
+def test_gzip_members_shard_across_ranks(gpu, scfq, oracle, tmp_path):
+    """an ordinary gzip file of 30 members (`cat a.gz b.gz ...`, pigz -i, a sequencer's writer) is cut where members START: 2 and 3
+    `sc fq-count --shard-rank` processes over the TCP transport, each inflating and scanning the members that begin in its byte
+    range (device path, and the host's decoder for small stretches), row == oracle.  The members are cut at arbitrary bytes of a CRLF
+    record stream — some between a '\\r' and its '\\n', one member is empty — with the structure check on: the byte in front of a rank's
+    first inflated byte is only known once the rank before it is through, and is put right at the fold (gz_shard_fix)."""
+    # (random bases and qualities: a file that compresses like FASTQ — 3 to 4 times —, so that a rank's stretch is megabytes of
+    # deflate data and goes through the device path; sequence and separator lines end in "\r\n", the others in "\n")
+    data = fastq_bytes(30_000_000, seed=21).replace(b"\n+\n", b"\r\n+\r\n") + b"@tail\nACGT"
+    rng = np.random.default_rng(5)
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(data) - 1, 27)))
+    # two cuts that fall between a '\r' and its '\n', and one in front of a line start
+    k = data.index(b"\r\n", len(data) // 3)
+    cuts.append(k + 1)
+    k = data.index(b"\r\n", 2 * len(data) // 3)
+    cuts.append(k + 1)
+    cuts.append(data.index(b"\n@r", len(data) // 2) + 1)
+    cuts = sorted(set(cuts))
+    members = _gz_members(data, cuts)
+    members.insert(11, gzip_empty())
+    f = tmp_path / "members.fq.gz"
+    f.write_bytes(b"".join(members) + b"\0\0trailing bytes that are not a member")
+    oc = oracle.count(np.frombuffer(data, dtype=np.uint8))
+    sc = os.path.join(PKG, "sc")
+    for world, env in ((2, {}), (3, {}), (3, {"SCFQ_GZ_DEVICE_MIN_MB": "1"})):
+        outs, stats = _run_ranks(sc, world, f, ["--struct-check"], env)
+        assert outs[-1][0] == oracle.tsv(oc) + "\n", (world, env, outs[-1])
+        assert "bad_at=%d\tbad_plus=%d" % (oc.bad_at, oc.bad_plus) in outs[-1][1]
+        shares = [st["h2d_bytes"] for st in stats]
+        assert all(s > 0 for s in shares) and max(shares) < 0.75 * sum(shares), shares      # every rank inflated and scanned members of its own
+    # the quality histogram over the same shards (the '\r' of a "\r\n" cut in two is taken back from the right bin)
+    outs, stats = _run_ranks(sc, 3, f, ["--qual-hist"])
+    assert outs[-1][0] == oracle.tsv(oc) + "\n"
+    want = "\t".join("%d:%d" % (v, oc.qual_hist[v]) for v in range(256) if oc.qual_hist[v])
+    assert want in outs[-1][1], (want, outs[-1][1][-600:])
+    # SCFQ_SHARD_GZ=0: rank 0 alone, same row
+    outs, stats = _run_ranks(sc, 2, f, ["--struct-check"], {"SCFQ_SHARD_GZ": "0"})
+    assert outs[-1][0] == oracle.tsv(oc) + "\n" and stats[0]["h2d_bytes"] == 0
+
+
+def gzip_empty():
+    import zlib
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    return co.compress(b"") + co.flush()
+
+
+def test_gzip_shard_cut_that_is_no_member_start(gpu, scfq, oracle, tmp_path):
+    """what looks like a member start to the rank that begins there — magic, header, deflate data that inflates — but lies INSIDE
+    another member's stored block: the rank before it decodes straight through it, the stretch that begins there ends in bytes that
+    are no member; every rank learns it from the gathered rows and rank 0 reads the whole file: the row is still the oracle's"""
+    import zlib
+    rec = b"@r x\nACGTNNGCGC\n+\nIIII#III@+\n"
+    inner = gzip_empty()[:-8]                    # header + an empty final block: a "member" whose trailer never comes
+    inner_full = _gz_members(b"@in\nAC\n+\n!!\n" * 50, [])[0]
+    part1 = rec * 150_000
+    part2 = rec * 120_000 + b"@bin " + inner_full + b" x\nACGT\n+\nIIII\n" + rec * 30_000
+    assert inner  # (kept for clarity: the embedded member is a complete one, so the rank that starts there decodes it cleanly)
+    m1 = _gz_members(part1, [], 6)[0]
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)          # level 0: stored blocks, the embedded bytes appear verbatim
+    m2 = co.compress(part2) + co.flush()
+    blob = m1 + m2
+    at = blob.find(inner_full)
+    if at < 0:
+        pytest.skip("the embedded member straddles a stored-block boundary in this zlib build")
+    f = tmp_path / "embedded.fq.gz"
+    f.write_bytes(blob)
+    data = part1 + part2
+    oc = oracle.count(np.frombuffer(data, dtype=np.uint8))
+    # two ranks: the nominal cut must lie inside m2 but in front of the embedded member, with no true member start in between
+    assert len(m1) < len(blob) // 2 < at, (len(m1), len(blob) // 2, at)
+    sc = os.path.join(PKG, "sc")
+    outs, stats = _run_ranks(sc, 2, f, [], {"SCFQ_VERBOSE": "1"})
+    assert outs[-1][0] == oracle.tsv(oc) + "\n", outs[-1]
