@@ -628,7 +628,7 @@ __device__ __attribute__((noinline)) void symbol_loop_lanes(SymState* stp, const
 // its period.  The last store of a sub-group waits for its load only when the next sub-group begins.
 // LDS scratch (256 dwords: the table builder's work area): positions [0, 192), a chunk's start flags [192, 256).
 #ifndef SCFQ_DENSE_EMIT2
-#define SCFQ_DENSE_EMIT2 0      // 1: the output chunks of a sub-group go out two at a time (not yet the default: measured on BGZF only)
+#define SCFQ_DENSE_EMIT2 1      // 1 (r4: the default): the output chunks of a sub-group go out two at a time; 0 keeps one at a time
 #endif
 template <bool SYM16>
 __device__ __attribute__((noinline)) void symbol_loop_dense(SymState* stp, const uint8_t* in_aligned, uint32_t in_off, uint32_t ip_end, void* out_base,

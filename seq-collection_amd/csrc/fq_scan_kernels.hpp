@@ -63,7 +63,8 @@ constexpr int kHistWaves = 2;   // waves per block in the histogram variant (LDS
 // counted again by the exact kernel like those of a wrong guess (fq_hist_verify), and results never depend on the assumption.
 // SCFQ_QWINDOW=0 keeps the 256-bin layout (SCFQ_QREP copies).
 #ifndef SCFQ_QWINDOW
-#define SCFQ_QWINDOW 1
+#define SCFQ_QWINDOW 0      // (r4: built, bit-exact, and measured at +1 % on long reads, -0.5 % on Illumina: LDS atomics cost a CU 4 - 5 cycles per
+                            // wave instruction with or without bank conflicts — profiles/r04/hist_ab.txt.  Not the default.)
 #endif
 #ifndef SCFQ_QREP
 #define SCFQ_QREP 16

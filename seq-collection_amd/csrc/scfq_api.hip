@@ -684,7 +684,7 @@ int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_part
 // crosses PCIe while the next one is copied into the other pinned buffer, so the bytes are on the device one piece after the last
 // of them reached pinned memory — and the ring is 2 x 16 MiB, not two buffers of the size of a chunk (pinning memory costs
 // 160 ms per GB: 170 of the 310 ms of a cold `sc fq-count` over a 2 GB BGZF file went into two pinned buffers of 0.5 GB).
-int copy_through_ring(Ctx* c, uint8_t* dst_device, const uint8_t* src_host, uint64_t n) {
+int copy_through_ring(Ctx* c, uint8_t* dst_device, const FileBytes& src, uint64_t src_off, uint64_t n) {
   int rc = ensure_staging(c, c->stage_cap ? c->stage_cap : (16ull << 20), true);
   if (rc) return rc;
   const uint64_t piece = std::min<uint64_t>(c->stage_cap, 64ull << 20);
@@ -693,7 +693,7 @@ int copy_through_ring(Ctx* c, uint8_t* dst_device, const uint8_t* src_host, uint
     const int pb = (int)(c->piece_it & 1);
     const uint64_t len = std::min(piece, n - o);
     if (c->piece_it >= 2) HIPCHK(hipEventSynchronize(c->ev_piece[pb]));
-    parallel_pieces(len, [&](uint64_t q, uint64_t l) { std::memcpy(c->h_pin[pb] + q, src_host + o + q, l); return 0; });
+    copy_file_bytes(src, src_off + o, c->h_pin[pb], len);
     HIPCHK(hipMemcpyAsync(dst_device + o, c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
     HIPCHK(hipEventRecord(c->ev_piece[pb], c->copy));
   }
@@ -886,7 +886,9 @@ static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, int launch = 3)
 
 // first_prev: the byte in front of the first inflated byte (0..255), or -1 when the members start the input (a rank of a sharded
 // BGZF file starts in the middle of the inflated stream: scfq_count_file_sharded)
-int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1) {
+int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1, int fd = -1, uint64_t fd_off = 0) {
+  FileBytes fbytes;
+  fbytes.img = img; fbytes.fd = fd; fbytes.fd_off = fd_off;
   // (bgzf_inflate keeps 72 bytes of scratch per lane and the runtime sets the device's scratch up inside the first launch of such
   // a kernel — 35 - 50 ms on the launching thread: an empty launch on a helper thread, under the buffers' allocation and the first copy)
   struct Helper { std::thread th; ~Helper() { if (th.joinable()) th.join(); } };
@@ -959,14 +961,13 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
         alloc_rc = ensure_bgzf_device_buffers(c, fsize, true);
       });
     }
-    const uint8_t* src = img + pos;
     c->timing.h2d_bytes += (uint64_t)used;
     if (it >= 3) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));       // device buffers b were consumed (chunk 0 had its own)
     if (timing) {
       while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
       HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
     }
-    if ((rc = copy_through_ring(c, d_comp, src, (uint64_t)used))) return rc;
+    if ((rc = copy_through_ring(c, d_comp, fbytes, pos, (uint64_t)used))) return rc;
     fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
     if (timing) { HIPCHK(hipEventRecord(c->cp_pool[c->cp_used + 1], c->copy)); c->cp_used += 2; }
@@ -1213,7 +1214,7 @@ static int count_file_partial(const char* path, const scfq_opts* opts, scfq_part
           if (m != MAP_FAILED) {
             // (no purity walk up front: touching every member header of a mapped 1 GB file costs 15 ms of page faults;
             // the chunk planner walks them anyway, under the device's work, and reports what it cannot take)
-            rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing);
+            rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing, -1, bfd, 0);
             on_device = (rc != kFallbackToHost && rc != kNotPureBgzf);
             if (rc == kNotPureBgzf) rc = begin_session(c, true);      // drop what the device path accumulated
             else if (!on_device) rc = SCFQ_OK;
@@ -1248,7 +1249,7 @@ static int count_file_partial(const char* path, const scfq_opts* opts, scfq_part
           SessionLock sl;
           rc = get_ctx(&c, sl);
           if (!rc) rc = begin_session(c, true);
-          if (!rc) rc = ingest_gz_device(c, static_cast<const uint8_t*>(m), (uint64_t)gsb.st_size, o.flags, timing);
+          if (!rc) rc = ingest_gz_device(c, static_cast<const uint8_t*>(m), (uint64_t)gsb.st_size, o.flags, timing, nullptr, gfd, 0);
           if (rc == SCFQ_OK) return end_session(c, want_hist, &p, want_hist ? hist.data() : nullptr);
           if (rc != kFallbackToHost) return rc;
           (void)hipStreamSynchronize(c->compute);
@@ -1549,7 +1550,7 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
         if (!local) {
           const uint64_t len = g_hi - g_lo;
           static const uint64_t min_bytes = (uint64_t)std::max(0, env_int("SCFQ_GZ_DEVICE_MIN_MB", 4)) << 20;
-          local = len >= std::max<uint64_t>(min_bytes, 64) ? ingest_gz_device(c, img + g_lo, len, o.flags, timing, &end_off) : kFallbackToHost;
+          local = len >= std::max<uint64_t>(min_bytes, 64) ? ingest_gz_device(c, img + g_lo, len, o.flags, timing, &end_off, fd, g_lo) : kFallbackToHost;
           if (local == kFallbackToHost) {
             // (small stretches, and whatever the device path declines: the host's decoder over the same bytes — Resume from the first
             // block of the stretch's first member, an empty window, no prefix)
@@ -1619,7 +1620,7 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
         local = get_ctx(&c, sl);
         if (!local) local = begin_session(c, rank == 0);
         if (!local) {
-          local = ingest_bgzf_device(c, img + b_lo, b_hi - b_lo, o.flags, opt_chunk(&o), timing, prev);
+          local = ingest_bgzf_device(c, img + b_lo, b_hi - b_lo, o.flags, opt_chunk(&o), timing, prev, fd, b_lo);
           if (local == kFallbackToHost || local == kNotPureBgzf) {
             // no room for the device path's buffers (kNotPureBgzf cannot happen: the range was walked): the host's block-parallel
             // inflate over the same members
@@ -1820,9 +1821,8 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
               const int64_t used = bgzf_plan(img, fsize, pos, c->inf_cap, c->comp_cap, bgzf_members_per_launch(c->inf_cap), c->h_blk[b], &nb, &ob);
               if (used < 0) return SCFQ_EGZ;
               if (used == 0) break;
-              const uint8_t* src = img + pos;
               if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));
-              if ((rc = copy_through_ring(c, c->d_comp[b], src, (uint64_t)used))) return rc;
+              { FileBytes fb; fb.img = img; fb.fd = bfd; if ((rc = copy_through_ring(c, c->d_comp[b], fb, pos, (uint64_t)used))) return rc; }
               HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
               HIPCHK(hipEventRecord(c->ev_copied[b], c->copy));
               HIPCHK(hipStreamWaitEvent(c->compute, c->ev_copied[b], 0));

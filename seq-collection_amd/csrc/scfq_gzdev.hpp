@@ -20,8 +20,10 @@
 // one half of the pinned ring the compressed bytes of a file cross in (see ingest_gz_device_batches: "the pinned ring")
 inline uint64_t gz_ring_piece(uint64_t comp_bytes) {
   static const int ring_env = env_int("SCFQ_GZ_DEVICE_RING_MB", 0);
+  // (r4: no 64 MiB step any more.  Pinning 2 x 64 MiB costs a process 26 ms, 2 x 16 MiB 5 ms — for a 0.5 GB file that saved 6 ms of
+  // copying: profiles/r04/cold_stages.jsonl.  A context whose ring is bigger already — a long-running host — uses what it has.)
   return ring_env > 0 ? ((uint64_t)std::min(256, std::max(4, ring_env)) << 20)
-                      : comp_bytes > (1ull << 30) ? (128ull << 20) : comp_bytes > (256ull << 20) ? (64ull << 20) : (16ull << 20);
+                      : comp_bytes > (1ull << 30) ? (128ull << 20) : (16ull << 20);
 }
 
 inline bool gz_device_enabled() {
@@ -136,7 +138,9 @@ struct GzPart {            // the bytes of one member inside one batch: a run of
 };
 struct GzMemberEnd { uint32_t member; uint32_t crc, isize; };
 
-int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off) {
+int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off, int fd, uint64_t fd_off) {
+  FileBytes fbytes;
+  fbytes.img = img; fbytes.fd = fd; fbytes.fd_off = fd_off;
   using namespace scfq_dinflate;
   using clk = std::chrono::steady_clock;
   const auto t_begin = clk::now();
@@ -360,7 +364,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   rc = ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
   if (rc) return rc;
   trace("gzip engine: pinned ring ready");
-  const uint64_t pin_chunk = want_piece;
+  const uint64_t pin_chunk = std::max<uint64_t>(want_piece, comp > (256ull << 20) ? std::min<uint64_t>(c->stage_cap, 64ull << 20) : 0);
 
   // ---- measurement aid (SCFQ_VERBOSE): device time of the stages, summed over the batches ---------------------------------------
   struct Span { hipEvent_t a = nullptr, b = nullptr; };
@@ -427,8 +431,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       auto t0 = clk::now();
       if (pin_it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[pb]));
       auto t1 = clk::now();
-      const uint8_t* src = img + off;
-      parallel_pieces(len, [&](uint64_t o, uint64_t l) { std::memcpy(c->h_pin[pb] + o, src + o, l); return 0; });
+      copy_file_bytes(fbytes, off, c->h_pin[pb], len);
       auto t2 = clk::now();
       HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
       HIPCHK(hipEventRecord(c->ev_copied[pb], c->copy));
@@ -542,7 +545,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     sl.sym.rewind();
     for (uint32_t q = 0; q < n_seg; ++q) {
       const uint64_t cap = seg_cap(h_segs[q].start_bit, h_segs[q].stop_bit, 1.0);
-      if (int r = gz_take(sl.sym, kGzWindow + cap, &h_segs[q].sym_off)) return r;
+      if (gz_take(sl.sym, kGzWindow + cap, &h_segs[q].sym_off)) { why = "no device memory for a batch's symbols"; return gz_decline(__LINE__, kFallbackRest); }      // (the batches that are through stay)
       h_segs[q].cap = (uint32_t)cap;     // better compression than assumed: overflow status, and the walk has that segment decoded again
       h_segs[q].reserved = 0;
       pool_used += kGzWindow + cap;
@@ -617,7 +620,11 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
           // at a false sync and the one before ran over it): decode [p, next known start) in the next round
           auto nx = by_start.upper_bound(p);
           uint64_t stop = nx != by_start.end() ? nx->first : (last_batch ? end_bit : std::min(territory_end + 8 * seg_bytes, limit - 4096));
-          if (stop <= p || stop - p > 64 * 8 * seg_bytes) return SCFQ_GZ_DECLINE;     // (one wave would decode a gap that long for seconds)
+          if (stop <= p) return SCFQ_GZ_DECLINE;
+          // (one wave would decode a gap that long for seconds — a run of stored blocks, a block of megabytes: nothing the search
+          // looks for starts in it.  Nothing suspect about the data: the host's decoder takes the file from the chain's position,
+          // what the batches before folded stays)
+          if (stop - p > 64 * 8 * seg_bytes) { why = "a stretch of more than 64 segments without a block start the search accepts"; return gz_decline(__LINE__, kFallbackRest); }
           gaps.push_back(Gap{p, stop, 1.0});
           if (verbose) std::fprintf(stderr, "scfq gzdev:   batch %u: gap at bit %llu (%.1f %% of the file) up to %llu\n", k, (unsigned long long)p,
                                     100.0 * (double)p / (double)end_bit, (unsigned long long)stop);
@@ -1031,7 +1038,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
 // returns, whatever the outcome — the scan of the last batch included, which reads the engine's output buffer: the buffers belong to
 // the next caller.
 // end_off (optional): the offset just behind the last member's trailer — fsize unless bytes that are not a gzip member follow it
-int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off = nullptr) {
+// fd / fd_off (optional): the file img is mapped from, img[0] being its byte fd_off — the copies into the pinned ring then pread
+int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off = nullptr, int fd = -1, uint64_t fd_off = 0) {
   GzShared& gs = gz_shared(c->dev);
   static const int n_engines = std::min((int)GzShared::kMax, std::max(1, env_int("SCFQ_GZ_DEVICE_ENGINES", 4)));
   const bool big = fsize > (1ull << 30);
@@ -1049,7 +1057,7 @@ int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags,
     gs.big_running = big;
   }
   GzDevBuffers& g = gs.buf[e];
-  const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing, end_off);
+  const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing, end_off, fd, fd_off);
   if (c->copy) (void)hipStreamSynchronize(c->copy);
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
   if (g.s_gap) (void)hipStreamSynchronize(g.s_gap);

@@ -21,9 +21,8 @@ int io_threads() {
 }
 
 template <typename F>
-int parallel_pieces(uint64_t total, F&& piece /* int(uint64_t off, uint64_t len) */) {
-  const uint64_t kMinPiece = 4ull << 20;
-  int nt = (int)std::min<uint64_t>((uint64_t)io_threads(), (total + kMinPiece - 1) / kMinPiece);
+int parallel_pieces(uint64_t total, F&& piece /* int(uint64_t off, uint64_t len) */, int max_threads = 0, uint64_t kMinPiece = 4ull << 20) {
+  int nt = (int)std::min<uint64_t>((uint64_t)(max_threads > 0 ? max_threads : io_threads()), (total + kMinPiece - 1) / kMinPiece);
   if (nt <= 1) return piece(0, total);
   std::vector<int> rcs(nt, 0);
   std::vector<std::thread> th;
@@ -34,6 +33,36 @@ int parallel_pieces(uint64_t total, F&& piece /* int(uint64_t off, uint64_t len)
   for (auto& x : th) x.join();
   for (int r : rcs) if (r) return r;
   return 0;
+}
+
+// Compressed bytes of a file into a pinned buffer, for the device inflate paths (nothing else for the host's cores to do meanwhile:
+// SCFQ_COPY_THREADS, default 12).  With the file's descriptor: pread — the kernel copies out of the page cache without a page fault per
+// 4 KiB, which is what a memcpy out of the mapping pays (r3: 30 GB/s through the ring with 8 memcpy threads, against 42 GB/s for the
+// plain-file path's preads); without one (a caller that only has the bytes): memcpy.
+int copy_threads() {
+  static const int n = std::max(1, std::min(64, env_int("SCFQ_COPY_THREADS", 12)));
+  return n;
+}
+struct FileBytes {
+  const uint8_t* img = nullptr;      // the bytes, mapped
+  int fd = -1;                       // ... and, when there is one, the file they are mapped from,
+  uint64_t fd_off = 0;               // img[0] being the byte at this offset of it
+};
+inline int copy_file_bytes(const FileBytes& fb, uint64_t off, uint8_t* dst, uint64_t len) {
+  static const bool use_pread = env_int("SCFQ_COPY_PREAD", 1) != 0;
+  return parallel_pieces(len, [&](uint64_t o, uint64_t l) {
+    if (fb.fd >= 0 && use_pread) {
+      uint64_t got = 0;
+      while (got < l) {
+        const ssize_t r = pread(fb.fd, dst + o + got, (size_t)(l - got), (off_t)(fb.fd_off + off + o + got));
+        if (r <= 0) break;          // (the file shrank under the mapping: the mapped bytes decide, below)
+        got += (uint64_t)r;
+      }
+      if (got == l) return 0;
+    }
+    std::memcpy(dst + o, fb.img + off + o, l);
+    return 0;
+  }, copy_threads(), 1ull << 20);
 }
 
 struct MemSource : Source {

@@ -97,6 +97,24 @@ def test_batch_without_room_hands_the_rest_to_the_host(gpu, oracle, tmp_path):
     assert host.returncode != 0 and (dev.returncode, dev.stdout, strip(dev.stderr)) == (host.returncode, host.stdout, strip(host.stderr)), dev.stderr[-2000:]
 
 
+def test_a_stretch_without_block_starts_hands_the_rest_to_the_host(gpu, oracle, tmp_path):
+    """a member of nothing but STORED blocks (6 MiB of them: the block-start search looks for dynamic-Huffman headers and finds none)
+    between two ordinary members: the walk reaches its first block with the next known start more than 64 segments away — too long
+    for one wave — and, r4, hands the REST of the file to the host's decoder from there instead of starting the whole file again:
+    the batches in front of it stay folded (`the rest on the host`), the row is the oracle's"""
+    a = fastq_bytes(30_000_000, seed=91)
+    b = fastq_bytes(6_400_000, seed=92)
+    c = fastq_bytes(6_000_000, seed=93)
+    f = tmp_path / "stored_middle.fq.gz"
+    f.write_bytes(member(a) + member(b, level=0) + member(c))
+    want = oracle.tsv(oracle.count(np.frombuffer(a + b + c, dtype=np.uint8))) + "\n"
+    r = run(f, **dict(DEV_ENV, SCFQ_GZ_DEVICE_BATCH_SEGMENTS="256"))
+    assert r.returncode == 0 and r.stdout == want, r.stderr[-3000:]
+    assert "without a block start the search accepts" in r.stderr and "the rest on the host" in r.stderr, r.stderr[-3000:]
+    host = run(f, SCFQ_GZ_DEVICE="0")
+    assert host.returncode == 0 and host.stdout == want
+
+
 def test_more_than_1024_members(gpu, scfq, tmp_path):
     plan = scfq.synth_plan(0, 20260105, 170_000_000)
     data, info = scfq.synth_host(0, 20260105, plan.records)
