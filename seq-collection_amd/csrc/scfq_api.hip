@@ -141,6 +141,7 @@ struct Ctx {
   int dev = -1;
   int n_cu = 256;
   hipStream_t compute = nullptr, copy = nullptr;
+  uint64_t n_sessions = 0;              // sessions begun on this context so far
   bool copy_is_alias = false;           // `copy` IS the compute stream (no second chunk has had to move yet): want_copy_stream()
   uint64_t* d_partials = nullptr;
   uint64_t cap_ranges = 0;
@@ -491,6 +492,7 @@ int scan_async(Ctx* c, const uint8_t* dptr, uint64_t n, int prev_byte, uint32_t 
 }
 
 int begin_session(Ctx* c, bool from_start) {
+  ++c->n_sessions;
   c->from_start = from_start;
   c->timing = scfq_timing{};
   c->timing.struct_size = sizeof(scfq_timing);

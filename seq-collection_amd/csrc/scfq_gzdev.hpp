@@ -18,12 +18,15 @@
 // the result is handed out.
 
 // one half of the pinned ring the compressed bytes of a file cross in (see ingest_gz_device_batches: "the pinned ring")
-inline uint64_t gz_ring_piece(uint64_t comp_bytes) {
+inline uint64_t gz_ring_piece(uint64_t comp_bytes, bool context_is_new) {
   static const int ring_env = env_int("SCFQ_GZ_DEVICE_RING_MB", 0);
-  // (r4: no 64 MiB step any more.  Pinning 2 x 64 MiB costs a process 26 ms, 2 x 16 MiB 5 ms — for a 0.5 GB file that saved 6 ms of
-  // copying: profiles/r04/cold_stages.jsonl.  A context whose ring is bigger already — a long-running host — uses what it has.)
+  // (r4: files of up to 1 GiB compressed cross in 16 MiB pieces.  Pinning 2 x 64 MiB costs a process 26 ms, 2 x 16 MiB 5 ms — for a
+  // 0.5 GB file the bigger pieces saved 6 ms of copying.  Beyond 1 GiB: 64 MiB pieces in a context's FIRST session — a process's
+  // only one: 2 x 128 MiB were 62 of a 10 GB file's 510 ms — and 128 MiB from its second session on, which is a long-running host,
+  // for which the pieces' size is worth 13 ms per 10 GB: profiles/r04/cold_stages*.jsonl, profiles/r03/gz_device_variants.txt.
+  // A context whose ring is bigger already uses what it has.)
   return ring_env > 0 ? ((uint64_t)std::min(256, std::max(4, ring_env)) << 20)
-                      : comp_bytes > (1ull << 30) ? (128ull << 20) : (16ull << 20);
+                      : comp_bytes > (1ull << 30) ? (context_is_new ? (64ull << 20) : (128ull << 20)) : (16ull << 20);
 }
 
 inline bool gz_device_enabled() {
@@ -330,6 +333,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   const uint64_t res_crc = 4 * (16 + (comp * kMaxRatio) / kCrcTile + 2ull * n_plan + 4ull * nb + 8192);      // tiles of the whole file + a part per member and batch
   for (uint32_t b = 0; b < std::min(nb, 4u); ++b) if ((rc = gz_buf(g, g.comp[b], batch_comp_max + comp_pad + 4096))) return rc;
   if ((rc = gz_buf(g, g.win, (uint64_t)kGzWindow * max_seg)) || (rc = gz_buf(g, g.crc, res_crc))) return rc;
+  trace("gzip engine: compressed-byte, window and CRC buffers allocated");
   {
     // the tables of both slots: ONE device and ONE pinned allocation (a pinned allocation costs milliseconds whatever its size)
     const uint32_t ns = std::min(nb, n_slots), nq = std::min(nb, 4u);
@@ -360,7 +364,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // decode waves of two batches on the device a piece crosses PCIe at 26 - 30 GB/s instead of 55, every piece costs the copier a
   // round of eight memcpy threads, and the orchestrating thread waited for the copier 94 / 75 / 39 ms of a 10 GB file's 187 / 169 /
   // 156 ms with pieces of 16 / 64 / 128 MiB (profiles/r03/gz_device_variants.txt); pinning 2 x 128 MiB costs a process 40 ms.
-  const uint64_t want_piece = gz_ring_piece(comp);
+  const uint64_t want_piece = gz_ring_piece(comp, c->n_sessions <= 1);
   rc = ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
   if (rc) return rc;
   trace("gzip engine: pinned ring ready");
