@@ -565,6 +565,32 @@ __global__ __launch_bounds__(1024) void gz_window_maps(const GzChain* __restrict
   for (uint32_t i = tid; i < kGzWindow / 8; i += 1024) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(W)[i];
 }
 
+// The maps of consecutive groups folded into ONE: run <- M_{n-1} o ... o M_0 o run (maps[(g + 1) * 32768 ..] = M_g, as gz_window_maps
+// writes them; run: 32768 symbols, the identity 0x8000 | i to begin with).  What a whole STRETCH of a member does to the window —
+// the thing the ranks of a sharded count exchange (scfq_gzdev.hpp: GzStretch).  One workgroup; the running map goes back and forth
+// between two 64 KiB arrays in global memory (the L2 holds them; no LDS: this kernel must not wait for the decode kernels' LDS).
+__global__ __launch_bounds__(1024) void gz_map_fold(const uint16_t* __restrict__ maps, uint32_t n_groups, uint16_t* run_a, uint16_t* run_b) {
+  const uint32_t tid = threadIdx.x;
+  uint16_t* cur = run_a;
+  uint16_t* nxt = run_b;
+  for (uint32_t g = 0; g < n_groups; ++g) {
+    const uint16_t* m = maps + (uint64_t)(g + 1) * kGzWindow;
+    for (uint32_t i = tid; i < kGzWindow; i += 1024) {
+      const uint32_t sy = m[i];
+      // (agent-scope load: served by the L2 — the array was written by other waves of this workgroup one step ago, and this CU's L1
+      // may still hold the line from two steps ago)
+      nxt[i] = (sy & 0x8000u) ? __hip_atomic_load(&cur[sy & 0x7FFFu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint16_t)sy;
+    }
+    __threadfence();
+    __syncthreads();
+    uint16_t* t = cur; cur = nxt; nxt = t;
+  }
+  // the result is wanted in run_a
+  if (cur != run_a) {
+    for (uint32_t i = tid; i < kGzWindow; i += 1024) run_a[i] = __hip_atomic_load(&cur[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- G4 ----------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kResolveTile = 1u << 17;                  // symbols per workgroup: the 32 KiB window load is a quarter of the tile's traffic
 // work item w: chain entry entry[w], symbols [tile[w] * kResolveTile, ...) of it

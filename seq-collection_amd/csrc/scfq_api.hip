@@ -1463,6 +1463,21 @@ void gz_shard_fix(scfq_partial* p, uint64_t* hist, int true_prev, int first_byte
     if (first_byte == '+') p->first_plus[0] -= 1;
   }
 }
+// ---- ONE member over several ranks: the deflate stream is cut where BLOCKS start -----------------------------------------------------
+// gz_block_boundary: the first bit at or after byte `from` where a dynamic-Huffman block demonstrably starts (scfq_pgz.hpp's test: a
+// header that parses — complete code-length, literal/length and distance codes — and 4096 symbols that decode cleanly); 0 when there is
+// none within `span` bytes.  Both neighbours of a cut compute it from the same bytes.  What proves it is the rank before: its chain must
+// arrive at exactly this bit (GzStretch: stop_bit), or every rank falls back to rank 0 reading the whole file.
+uint64_t gz_block_boundary(const uint8_t* img, uint64_t n, uint64_t from, uint64_t span) {
+  const uint64_t to = std::min<uint64_t>(from + span, n > 16 ? n - 16 : 0);
+  if (from >= to) return 0;
+  auto d = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
+  std::vector<uint16_t> scratch(scfq_pgz::kWindow + scfq_pgz::kTrialSymbols + 2 * scfq_inflate::kOutSlack);
+  for (uint32_t i = 0; i < scfq_pgz::kWindow; ++i) scratch[i] = (uint16_t)(0x8000u | i);
+  for (uint64_t b = from * 8; b < to * 8; ++b)
+    if (scfq_pgz::plausible_block(*d, img, img + n, b, scratch)) return b;
+  return 0;
+}
 }  // namespace
 extern "C" {
 
@@ -1526,16 +1541,24 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
         if (rank == 0) g_lo = gz_member_here(img, size, 0, std::max<uint64_t>(g_hi, 1), &g_first) ? 0 : size + 1;      // (size + 1: not a gzip file at all)
         else g_lo = gz_member_boundary(img, size, nom_lo, g_hi, &g_first);
         if (g_lo <= size) { if (g_hi < g_lo) g_hi = g_lo; mine_ok = 2; }
+        // (bit 2: no member starts at or behind this rank's cut — when every rank says so the file is ONE member, or as good as: the
+        // ranks cut its deflate stream where blocks start instead)
+        static const bool shard_blocks = env_int("SCFQ_SHARD_GZ_BLOCKS", 1) != 0;
+        if (mine_ok == 2 && shard_blocks && size >= (uint64_t)world * (8ull << 20) && (rank == 0 ? g_hi == size : g_lo == size)) mine_ok = 6;
       }
     }
     std::vector<uint64_t> oks((size_t)world, 0);
-    bool sharded = false, sharded_gz = false;
+    bool sharded = false, sharded_gz = false, sharded_blk = false;
     if (world > 1 && shard_bgzf) {
       // (every rank takes part in this all-gather whatever it found: a rank that cannot even open the file says 0)
       rc = scfq_comm_allgather_u64(comm, &mine_ok, 1, oks.data(), 0);
       if (rc) { if (img) munmap(const_cast<uint8_t*>(img), (size_t)size); if (fd >= 0) close(fd); std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return rc; }
-      sharded = sharded_gz = true;
-      for (int r = 0; r < world; ++r) { sharded = sharded && oks[(size_t)r] == 1; sharded_gz = sharded_gz && oks[(size_t)r] == 2; }
+      sharded = sharded_gz = sharded_blk = true;
+      for (int r = 0; r < world; ++r) {
+        sharded = sharded && oks[(size_t)r] == 1;
+        sharded_gz = sharded_gz && (oks[(size_t)r] & 2) != 0;
+        sharded_blk = sharded_blk && oks[(size_t)r] == 6;
+      }
     }
     if (sharded_gz) {
       // every rank inflates and scans the members of its stretch as if they were a file of their own (device path; the host's decoder
@@ -1544,7 +1567,71 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
       // (the last byte of the stretch before it) put right first: gz_shard_fix.
       if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) local = SCFQ_EHIP;
       uint64_t end_off = 0;
-      if (!local && g_hi > g_lo) {
+      uint64_t blk_crc_raw = 0, blk_len = 0, blk_end_byte = 0;      // block scheme: this stretch's raw CRC-32 and length; where the member ended
+      if (sharded_blk) {
+        // ---- ONE member: rank r's stretch is [s_r, s_{r+1}), s_r the first block start at or behind its share of the deflate data ----
+        const long h0 = scfq_gzfast::member_header(img, (size_t)size);
+        const uint64_t data0 = h0 > 0 ? (uint64_t)h0 : 0, comp = size - data0;
+        auto cut_bit = [&](int r) -> uint64_t { return r == 0 ? 0 : (r >= world ? 0 : gz_block_boundary(img, size, data0 + comp / (uint64_t)world * (uint64_t)r, 16ull << 20)); };
+        GzStretch sx1;
+        sx1.start_bit = cut_bit(rank);
+        sx1.stop_bit = cut_bit(rank + 1);
+        sx1.map_only = true;
+        uint64_t ok1 = (h0 > 0 && (rank == 0 || sx1.start_bit) && (rank + 1 == world || sx1.stop_bit)) ? 1 : 0;
+        Ctx* c = nullptr;
+        SessionLock sl;
+        if (!local) local = get_ctx(&c, sl);
+        if (!local && ok1) {
+          // pass 1: the stretch's window map, its length, and the proof that its chain runs from s_r to s_{r+1} exactly
+          const int r1 = ingest_gz_device(c, img, size, o.flags, false, nullptr, fd, 0, &sx1);
+          if (r1 == kFallbackToHost) ok1 = 0; else if (r1) local = r1;
+          if (ok1 && (sx1.map.size() != scfq_gzfast::kWindow || sx1.member_ended != (rank + 1 == world))) ok1 = 0;
+        }
+        // every rank learns every stretch: [ok, start, stop, bytes, where the member ended, the map]
+        const uint32_t kMapWords = (uint32_t)(scfq_gzfast::kWindow / 4), w1 = 5 + kMapWords;
+        std::vector<uint64_t> row1(w1, 0), rows1((size_t)world * w1, 0);
+        row1[0] = (ok1 && !local) ? 1 : 0;
+        row1[1] = sx1.start_bit; row1[2] = sx1.stop_bit; row1[3] = sx1.out_bytes; row1[4] = sx1.end_byte;
+        if (row1[0]) std::memcpy(row1.data() + 5, sx1.map.data(), 2 * scfq_gzfast::kWindow);
+        rc = scfq_comm_allgather_u64(comm, row1.data(), w1, rows1.data(), 0);
+        if (rc) { if (img) munmap(const_cast<uint8_t*>(img), (size_t)size); if (fd >= 0) close(fd); std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return local ? local : rc; }
+        bool agree = true;
+        for (int r = 0; r < world; ++r) {
+          const uint64_t* rr = rows1.data() + (size_t)r * w1;
+          agree = agree && rr[0] == 1 && (r + 1 == world ? rr[2] == 0 : rr[2] == rows1[(size_t)(r + 1) * w1 + 1]);      // a stretch ends where the next begins
+        }
+        if (agree) {
+          // the window in front of this rank's stretch: the maps of the stretches before it, applied in order to the member's (empty) start
+          std::vector<uint8_t> window(scfq_gzfast::kWindow, 0), next(scfq_gzfast::kWindow, 0);
+          uint64_t before_bytes = 0;
+          for (int r = 0; r < rank; ++r) {
+            const uint16_t* m = reinterpret_cast<const uint16_t*>(rows1.data() + (size_t)r * w1 + 5);
+            for (uint32_t i = 0; i < scfq_gzfast::kWindow; ++i) next[i] = (m[i] & 0x8000u) ? window[m[i] & 0x7FFFu] : (uint8_t)m[i];
+            window.swap(next);
+            before_bytes += rows1[(size_t)r * w1 + 3];
+          }
+          blk_end_byte = rows1[(size_t)(world - 1) * w1 + 4];
+          GzStretch sx2;
+          sx2.start_bit = sx1.start_bit;
+          sx2.stop_bit = sx1.stop_bit;
+          sx2.window = window.data();
+          sx2.valid = (uint32_t)std::min<uint64_t>(scfq_gzfast::kWindow, before_bytes);
+          if (!local) local = begin_session(c, rank == 0);
+          if (!local) {
+            // pass 2: windows, bytes, CRC tiles, scan — begun with the window the ranks before handed over
+            const int r2 = ingest_gz_device(c, img, size, o.flags, timing, nullptr, fd, 0, &sx2);
+            local = r2 == kFallbackToHost ? SCFQ_EGZ : r2;
+            if (!local && sx2.out_bytes != sx1.out_bytes) local = SCFQ_EGZ;
+          }
+          if (!local) local = end_session(c, want_hist, &mine, want_hist ? hist.data() : nullptr);
+          g_first = sx2.first_byte;
+          blk_crc_raw = sx2.crc_raw;
+          blk_len = sx2.out_bytes;
+        } else {
+          local = SCFQ_EGZ;      // (not an error of this rank: the rows below send every rank to the fall-back)
+          std::snprintf(g_err, sizeof g_err, "the block cuts of a one-member file did not join up");
+        }
+      } else if (!local && g_hi > g_lo) {
         Ctx* c = nullptr;
         SessionLock sl;
         local = get_ctx(&c, sl);
@@ -1583,6 +1670,8 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
       if (local) scfq_partial_identity(&mine, want_hist ? hist.data() : nullptr);
       mine.reserved[0] = (uint64_t)(int64_t)local;
       mine.reserved[1] = (uint64_t)(g_first + 1);          // 0: this stretch holds no byte
+      mine.reserved[2] = blk_crc_raw;                      // (block scheme) raw CRC-32 and length of this stretch of the one member
+      mine.reserved[3] = blk_len;
       const uint32_t words = SCFQ_PARTIAL_WORDS + (want_hist ? SCFQ_HIST_WORDS : 0);
       std::vector<uint64_t> row(words), rows((size_t)world * words);
       std::memcpy(row.data(), &mine, sizeof mine);
@@ -1591,6 +1680,26 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
       if (rc) { std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return local ? local : rc; }
       bool all_ok = true;
       for (int r = 0; r < world; ++r) all_ok = all_ok && rows[(size_t)r * words + offsetof(scfq_partial, reserved) / 8] == 0;
+      if (all_ok && sharded_blk) {
+        // the member's CRC-32 and ISIZE against the join of the stretches' (x^(8 |part|), as between the batches of one stretch)
+        uint32_t raw = 0;
+        uint64_t len = 0;
+        for (int r = 0; r < world; ++r) {
+          const uint64_t* rr = rows.data() + (size_t)r * words + offsetof(scfq_partial, reserved) / 8;
+          raw = gz_mulmod(gz_xpow8n(rr[3]), raw) ^ (uint32_t)rr[2];
+          len += rr[3];
+        }
+        const uint32_t crc = raw ^ gz_mulmod(gz_xpow8n(len), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+        uint8_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool have_trailer = false;
+        if (blk_end_byte >= 8) {
+          const int tfd = open(path, O_RDONLY);
+          if (tfd >= 0) { have_trailer = pread(tfd, t, 8, (off_t)(blk_end_byte - 8)) == 8; close(tfd); }
+        }
+        const uint32_t t_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t t_len = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (!have_trailer || t_crc != crc || t_len != (uint32_t)(len & 0xFFFFFFFFull)) all_ok = false;      // damaged: gzread's verdict, from rank 0's readers
+      }
       if (all_ok) {
         scfq_partial_identity(&all, want_hist ? hist_all.data() : nullptr);
         int before = -1;      // the last byte in front of the stretch being added (-1: nothing yet)
@@ -1599,7 +1708,7 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
           std::memcpy(&pr, rows.data() + (size_t)r * words, sizeof pr);
           uint64_t* hr = want_hist ? rows.data() + (size_t)r * words + SCFQ_PARTIAL_WORDS : nullptr;
           gz_shard_fix(&pr, hr, before, (int)pr.reserved[1] - 1, o.flags);
-          pr.reserved[1] = 0;
+          pr.reserved[1] = pr.reserved[2] = pr.reserved[3] = 0;
           if ((rc = scfq_partial_combine(&all, &pr, want_hist ? hist_all.data() : nullptr, hr))) return rc;
           if (pr.bytes) before = (int)(pr.last_byte & 0xFF);
         }

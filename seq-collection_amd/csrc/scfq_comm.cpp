@@ -260,7 +260,7 @@ struct Star {
   }
 };
 
-constexpr uint32_t kMaxWords = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;   // 1056: partial | hist[4][256]
+constexpr uint32_t kMaxWords = 8448;   // a partial with its histogram (1056 words), or a stretch's window map with its header (8197: scfq_count_file_sharded)
 
 // A caller waits a little longer than the worker's own deadline, so that the worker's message (which says WHY) normally wins.
 // SCFQ_COMM_TAKE_SLACK_MS / SCFQ_COMM_TEST_DELAY_MS (the worker sleeps before every gather) exist for the test of the case

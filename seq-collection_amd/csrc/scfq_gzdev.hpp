@@ -141,7 +141,32 @@ struct GzPart {            // the bytes of one member inside one batch: a run of
 };
 struct GzMemberEnd { uint32_t member; uint32_t crc, isize; };
 
-int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off, int fd, uint64_t fd_off) {
+// A STRETCH of one member's deflate stream, from one block boundary to another: what one rank of a sharded count works on when the
+// file is a single member (scfq_count_file_sharded).  The member's bytes in front of the stretch are not known when the rank starts,
+// so it goes over its stretch twice:
+//   pass 1 (map_only)  search, decode to symbols, prove the chain from start_bit to stop_bit exactly — and fold what the stretch does
+//                      to the 32 KiB window into ONE map (gz_window_maps per group of chain entries, gz_map_fold over the groups).
+//                      The ranks exchange their maps; composed in rank order from the member's start they give every rank the window
+//                      in front of its stretch.
+//   pass 2             the ordinary pipeline — windows, bytes, CRC tiles, scan — begun at start_bit with that window.
+// The member's CRC-32 and length are the join of the stretches' (x^(8 |part|) as between batches), checked by the caller.
+struct GzStretch {
+  uint64_t start_bit = 0;          // the stretch's first block (0: it begins the member, behind its header)
+  uint64_t stop_bit = 0;           // the block boundary it ends at (0: it ends with the member)
+  bool map_only = false;
+  const uint8_t* window = nullptr; // pass 2: the 32 KiB in front of start_bit ...
+  uint32_t valid = 0;              // ... of which the last `valid` bytes exist (32768 once the member is that long)
+  // results
+  uint64_t out_bytes = 0;          // bytes the stretch inflates to
+  bool member_ended = false;       // the member's final block lies in the stretch (stop_bit == 0 only)
+  uint32_t trailer_crc = 0, trailer_isize = 0;      // ... and its trailer
+  uint64_t end_byte = 0;           // ... and the offset just behind it
+  std::vector<uint16_t> map;       // pass 1: 32768 symbols — a literal, or 0x8000 | j = byte j of the window in front of the stretch
+  uint32_t crc_raw = 0;            // pass 2: raw CRC-32 (zero initial value, no final inversion) of the stretch's bytes
+  int first_byte = -1;             // pass 2
+};
+
+int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off, int fd, uint64_t fd_off, GzStretch* sx) {
   FileBytes fbytes;
   fbytes.img = img; fbytes.fd = fd; fbytes.fd_off = fd_off;
   using namespace scfq_dinflate;
@@ -150,8 +175,13 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   gz_alloc_ms() = 0;
   double stage_ms[3] = {0, 0, 0};
   static const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
-  const long h0 = scfq_gzfast::member_header(img, (size_t)fsize);
+  const bool stretch_from = sx && sx->start_bit != 0, stretch_to = sx && sx->stop_bit != 0, map_only = sx && sx->map_only;
+  const long h0 = stretch_from ? (long)(sx->start_bit >> 3) : scfq_gzfast::member_header(img, (size_t)fsize);
   if (h0 <= 0 || fsize < 64) return SCFQ_GZ_DECLINE;
+  if (sx && ((stretch_to && (sx->stop_bit <= sx->start_bit || (sx->stop_bit >> 3) >= fsize)) || (uint64_t)h0 + 64 > fsize)) return SCFQ_GZ_DECLINE;
+  // (a stretch that ends at a block boundary: the planner sees the file end there; the copies still reach a margin further, so that
+  // the last segment's block is whole)
+  const uint64_t lim_byte = stretch_to ? std::min<uint64_t>(fsize, (sx->stop_bit >> 3) + 1) : fsize;
   int rc;
   for (int b = 0; b < 4; ++b) {
     if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
@@ -170,7 +200,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
 
   // ---- plan ----------------------------------------------------------------------------------------------------------------
   const uint64_t data0 = (uint64_t)h0;
-  const uint64_t comp = fsize - data0;
+  const uint64_t first_bit = stretch_from ? sx->start_bit : data0 * 8;      // the chain's first block
+  const uint64_t comp = lim_byte - data0;
   // Segments of 48 to 320 KiB of compressed data (below); batches of about 4096 segments — the decode kernel's resident
   // waves — of equal size.  Two batches in flight is what pays (10 GB of FASTQ, 2.4 GB
   // compressed: one batch 199 ms, two 165 ms, five 217 ms): the second half of the file crosses PCIe while the first is decoded,
@@ -201,10 +232,11 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     const uint64_t sample_in = std::min<uint64_t>(fsize - data0, 192u << 10);
     std::vector<uint8_t> sample_out((size_t)kGzWindow + (8u << 20));
     auto dec = std::unique_ptr<scfq_inflate::Decoder>(new scfq_inflate::Decoder());
-    dec->begin(img + data0, img + data0 + sample_in);
+    if (stretch_from) { dec->begin_at_bit(img, img + data0 + sample_in, first_bit); dec->total_out = kGzWindow; }      // (back-references reach into a window of zeros: the ratio is what is wanted)
+    else dec->begin(img + data0, img + data0 + sample_in);
     uint8_t* o = sample_out.data() + kGzWindow;
     (void)dec->run(o, sample_out.data() + sample_out.size());      // (ends with "truncated" at the end of the sample: what came out counts)
-    const uint64_t got_out = (uint64_t)(o - (sample_out.data() + kGzWindow)), got_in = std::max<uint64_t>(1, dec->bitpos() / 8);
+    const uint64_t got_out = (uint64_t)(o - (sample_out.data() + kGzWindow)), got_in = std::max<uint64_t>(1, (dec->bitpos() - (stretch_from ? first_bit : 0)) / 8);
     // (long runs — zeros, one record repeated: ratios in the hundreds — are the host decoder's home ground, gigabytes per second,
     // and the lane-parallel loop's worst case, one symbol per round: such a file is declined here, before anything is queued)
     if (ratio_env <= 0 && got_in >= 1024 && (double)got_out / (double)got_in > 24.0) return SCFQ_GZ_DECLINE;
@@ -299,14 +331,14 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   }
   const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
   const uint64_t comp_pad = 256;
-  const uint64_t end_bit = fsize * 8;
+  const uint64_t end_bit = stretch_to ? sx->stop_bit : fsize * 8;
   // geometry of batch k: bytes [byte0, copy_end) of the file are on the device, its territory ends at byte1
   auto p0_of = [&](uint32_t k) { return bstart[k]; };
   auto p1_of = [&](uint32_t k) { return bstart[k + 1]; };
-  auto byte0_of = [&](uint32_t k) { return k == 0 ? 0ull : ((data0 + p0_of(k) * seg_bytes) & ~4095ull); };
-  auto byte1_of = [&](uint32_t k) { return p1_of(k) == n_plan ? fsize : data0 + p1_of(k) * seg_bytes; };
+  auto byte0_of = [&](uint32_t k) { return k == 0 ? (stretch_from ? (data0 & ~4095ull) : 0ull) : ((data0 + p0_of(k) * seg_bytes) & ~4095ull); };
+  auto byte1_of = [&](uint32_t k) { return p1_of(k) == n_plan ? lim_byte : data0 + p1_of(k) * seg_bytes; };
   auto copy_end_of = [&](uint32_t k) { return std::min<uint64_t>(fsize, byte1_of(k) + margin); };
-  const uint64_t batch_comp_max = std::min<uint64_t>(fsize, (uint64_t)std::min<uint64_t>(batch_segs, n_plan) * seg_bytes + margin + 8192);
+  const uint64_t batch_comp_max = std::min<uint64_t>(fsize, (uint64_t)std::min<uint64_t>(batch_segs, n_plan) * seg_bytes + margin + 8192 + (stretch_from ? 4096 : 0));
   const uint32_t spare = 64 + batch_segs / 16;         // gap segments of later rounds
   const uint32_t max_seg = batch_segs + spare;
   const uint64_t kSegSlack = 98304;       // (zlib's level-6 blocks inflate to ~60 KB, memLevel 9's to ~130 KB: those overflow now and then and are decoded again)
@@ -381,12 +413,13 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   auto span_end = [&](std::vector<Span>& v, hipStream_t st) { if (!verbose) return; (void)hipEventRecord(v.back().b, st); };
 
   // ---- state that travels from batch to batch ------------------------------------------------------------------------------
-  uint64_t pos = data0 * 8;              // the exact bit the chain has reached
+  uint64_t pos = first_bit;              // the exact bit the chain has reached
   bool finished = false;                 // the last member's final block has been walked and no further member follows
   uint64_t end_byte = 0;                 // ... and where that was: the offset just behind its trailer
   uint32_t member_no = 0;                // running member that `pos` lies in
-  uint32_t valid = 0;                    // bytes of that member's history in front of pos (<= 32768)
+  uint32_t valid = sx ? (map_only ? (uint32_t)kGzWindow : sx->valid) : 0;      // bytes of that member's history in front of pos (<= 32768; pass 1 of a stretch: taken as full, the map tells)
   int wcarry = 0;                        // which of the two carried windows is the current one
+  int stretch_first_byte = -1;
   uint64_t total_out = 0;
   bool have_prev_out = false;
   uint64_t prev_out_bytes = 0;           // size of the previous batch's output (its last byte is the next batch's look-behind)
@@ -401,6 +434,18 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   std::vector<uint32_t> n_seg_of(nb + 1, 0);
   std::vector<uint64_t> pool_used_of(nb + 1, 0);
   HIPCHK(hipMemsetAsync(g.crc.p, 0, 64, c->compute));          // word 0: the resolve kernels' error status for the whole file
+  std::vector<uint16_t> identity_map;
+  if (map_only) {
+    if ((rc = gz_buf(g, g.gwin, 4ull * kGzWindow))) return rc;      // the stretch's running map and its double (2 x 32768 symbols)
+    identity_map.resize(kGzWindow);
+    for (uint32_t i = 0; i < kGzWindow; ++i) identity_map[i] = (uint16_t)(0x8000u | i);
+    HIPCHK(hipMemcpyAsync(g.gwin.p, identity_map.data(), 2ull * kGzWindow, hipMemcpyHostToDevice, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));      // (pageable source)
+  } else if (sx && sx->valid) {
+    // pass 2 of a stretch: the window in front of it is the carried window of "batch -1"
+    HIPCHK(hipMemcpyAsync(g.d_wcarry, sx->window, kGzWindow, hipMemcpyHostToDevice, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+  }
 
   // ---- the COPIER: a thread of its own moves the compressed bytes — file mapping -> pinned ring -> comp[k % 4] — batch after batch,
   // up to four batches ahead of the walk.  On the orchestrating thread (round 2, and this round until the last day) the copies
@@ -496,7 +541,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     const uint32_t np = (uint32_t)(p1_of(k) - p0);
     for (uint32_t s = 0; s < np; ++s) { h_from[s] = (data0 + (p0 + s) * seg_bytes) * 8; h_found[s] = ~0ull; }
     const uint32_t s0 = (k == 0) ? 1u : 0u;
-    if (k == 0) h_found[0] = data0 * 8;
+    if (k == 0) h_found[0] = first_bit;
     HIPCHK(hipStreamWaitEvent(s_search, g.ev_copy[cb], 0));
     if (np > s0) {
       const uint8_t* vbase = g.comp[cb].p - b0;          // virtual base: byte i of the file is vbase[i] for i in [b0, b1 + pad)
@@ -618,6 +663,14 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       uint32_t mno = member_no;
       while (!done) {
         if (!last_batch && p >= territory_end) { done = true; break; }          // the next batch carries on from here
+        if (stretch_to && p >= end_bit) {
+          // the stretch ends at a block boundary the next rank begins at: the chain must arrive there EXACTLY (a boundary that was
+          // no block start after all is the caller's to deal with: every rank falls back)
+          if (p != end_bit) return SCFQ_GZ_DECLINE;
+          finished_end = true;
+          done = true;
+          break;
+        }
         auto it = by_start.find(p);
         if (it == by_start.end()) {
           // nothing was decoded from this exact bit (the first block of a further member, or the segment planned here started
@@ -665,6 +718,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
         if (r.end_bit <= p) return SCFQ_GZ_DECLINE;
         chain.push_back(Entry{it->second, mno});
         if (r.status == kGzMemberEnd) {
+          if (stretch_to) return SCFQ_GZ_DECLINE;              // (a stretch that was to end at a block boundary: the file is not ONE member after all)
           const uint64_t q = (r.end_bit + 7) >> 3;             // the trailer starts on the next byte boundary
           if (q + 8 > fsize) return SCFQ_GZ_DECLINE;           // truncated trailer: gzread's error, from the host path
           GzMemberEnd me;
@@ -675,11 +729,12 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
           const long h = scfq_gzfast::member_header(img + q + 8, (size_t)(fsize - (q + 8)));
           if (h < 0) return SCFQ_GZ_DECLINE;                   // a damaged further header: the host path decides
           if (h == 0) { finished_end = true; end_byte_here = q + 8; done = true; break; }   // end of file, or trailing garbage (ignored, as gzread does)
+          if (sx) return SCFQ_GZ_DECLINE;                      // (a further member behind a stretch: not ONE member)
           p = (q + 8 + (uint64_t)h) * 8;
           ++mno;      // (any number of members: the parts of a member, its trailer and the window state travel from batch to batch)
         } else {
           p = r.end_bit;
-          if (p + 8 >= end_bit) return SCFQ_GZ_DECLINE;        // the data ends inside a member: truncated file
+          if (!stretch_to && p + 8 >= end_bit) return SCFQ_GZ_DECLINE;        // the data ends inside a member: truncated file
         }
       }
       if (done && !tentative) { pos_end = p; member_end_no = mno; break; }
@@ -807,6 +862,40 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       if (4 * (16 + tiles_used + nt_all) > res_crc) { why = "more CRC tiles than the reserved range holds"; return gz_decline(__LINE__, kFallbackRest); }
     }
     walk_ms += std::chrono::duration<double, std::milli>(clk::now() - tw).count();
+    if (map_only) {
+      // pass 1 of a stretch: no windows, no bytes — what this batch's chain does to the window, folded into the stretch's running map
+      if (n_chain) {
+        if (n_chains != 1) return SCFQ_GZ_DECLINE;
+        GzChain* h_gchain = reinterpret_cast<GzChain*>(g.h_pmeta[pp] + offp_gchain);      // (unused by the kernels below; kept zero)
+        uint32_t* h_gfirst = reinterpret_cast<uint32_t*>(g.h_pmeta[pp] + offp_gfirst);
+        uint32_t n_groups = 0;
+        for (uint32_t q = 0; q < n_chain; q += group) {
+          if (n_groups >= max_groups) return SCFQ_GZ_DECLINE;
+          h_gfirst[n_groups] = q;
+          h_gchain[n_groups] = GzChain{};
+          ++n_groups;
+        }
+        h_gfirst[n_groups] = n_chain;
+        if (int r = gz_buf(g, g.maps, 2ull * kGzWindow * (n_groups + 1))) return r;
+        HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_chain, g.h_pmeta[pp] + offp_chain, sizeof(GzChain) * n_chain, hipMemcpyHostToDevice, c->compute));
+        HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gfirst, h_gfirst, 4ull * (n_groups + 1), hipMemcpyHostToDevice, c->compute));
+        span_begin(sp_chain, c->compute);
+        hipLaunchKernelGGL(gz_window_maps, dim3(n_groups), dim3(1024), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_chain),
+                           reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_gfirst), sl.sym.base(), reinterpret_cast<uint16_t*>(g.maps.p));
+        hipLaunchKernelGGL(gz_map_fold, dim3(1), dim3(1024), 0, c->compute, reinterpret_cast<const uint16_t*>(g.maps.p), n_groups,
+                           reinterpret_cast<uint16_t*>(g.gwin.p), reinterpret_cast<uint16_t*>(g.gwin.p) + kGzWindow);
+        HIPCHK(hipGetLastError());
+        span_end(sp_chain, c->compute);
+      }
+      HIPCHK(hipEventRecord(g.ev_post[pp], c->compute));
+      total_out += batch_out;
+      pos = pos_end;
+      member_no = member_end_no;
+      finished = finished_end;
+      if (finished_end && !stretch_to) { end_byte = end_byte_here; for (const GzMemberEnd& me : ends_here) member_ends.push_back(me); }
+      release_comp(k);
+      return SCFQ_OK;
+    }
     if (n_chain) {
       // room for what this batch turned out to need.  A bigger buffer than the last batch's is a NEW buffer (the old one, which the
       // last batch's scan may still be reading, is freed when the call ends): that batch's last byte — this batch's look-behind —
@@ -895,6 +984,13 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
         tiles_used += nt;
       }
       span_end(sp_crc, c->compute);
+      if (sx && !have_prev_out && batch_out) {
+        // (the byte a shard of a sharded count begins with: what the byte in front of it — known to the rank before — decides at the fold)
+        uint8_t fb = 0;
+        HIPCHK(hipMemcpyAsync(&fb, d_out, 1, hipMemcpyDeviceToHost, c->compute));
+        HIPCHK(hipStreamSynchronize(c->compute));
+        stretch_first_byte = fb;
+      }
       if (batch_out) {
         span_begin(sp_scan, c->compute);
         rc = scan_async(c, d_out, batch_out, have_prev_out ? -2 : -1, flags & ~SCFQ_PREV_IN_MEMORY, timing);
@@ -938,6 +1034,16 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       uint32_t raw = 0;
       uint64_t len = 0;       // (64 bits: ISIZE is the length modulo 2^32, a member may be longer)
       for (; parts_checked < parts.size() && parts[parts_checked].member == me.member; ++parts_checked) fold_part(parts[parts_checked], &raw, &len);
+      if (sx) {
+        // a stretch of a member that other ranks hold the rest of: its raw CRC-32 and length go to the caller, who joins the
+        // stretches' and checks them against this trailer
+        sx->crc_raw = raw;
+        sx->out_bytes = len;
+        sx->member_ended = true;
+        sx->trailer_crc = me.crc;
+        sx->trailer_isize = me.isize;
+        continue;
+      }
       const uint32_t crc = raw ^ gz_mulmod(gz_xpow8n(len), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
       if ((uint32_t)(len & 0xFFFFFFFFull) != me.isize || crc != me.crc) {
         if (verbose) std::fprintf(stderr, "scfq gzdev: member %u: %llu bytes, CRC-32 %08x; its trailer says %u, %08x: host path\n", me.member,
@@ -984,7 +1090,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     // batch is through, and for anything that smells of damaged data, the whole file is still the host's: its readers are
     // gzread byte for byte, error text included.)
     static const bool resume_on = env_int("SCFQ_GZ_DEVICE_RESUME", 1) != 0;
-    if (fail != kFallbackRest || total_out == 0 || !resume_on) return SCFQ_GZ_DECLINE;
+    if (fail != kFallbackRest || total_out == 0 || !resume_on || sx) return SCFQ_GZ_DECLINE;
     for (hipStream_t st : {c->copy, s_search, s_dec[0], s_dec[1], c->compute}) HIPCHK(hipStreamSynchronize(st));
     if ((rc = check_members())) return rc;
     std::vector<uint8_t> window(kGzWindow, 0);
@@ -1003,10 +1109,26 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     if (rc) return rc;
     end_byte = rest.rs.end_offset();
     resumed = true;
+  } else if (map_only) {
+    // (pass 1 of a stretch: no bytes, no CRC)
   } else if ((rc = check_members())) {
     return rc;
-  } else if (parts_checked != parts.size()) {
+  } else if (parts_checked != parts.size() && !stretch_to) {
     return SCFQ_GZ_DECLINE;
+  }
+  if (sx) {
+    sx->end_byte = end_byte;
+    if (map_only) {
+      sx->out_bytes = total_out;
+      sx->member_ended = !stretch_to;
+      sx->map.resize(kGzWindow);
+      HIPCHK(hipStreamSynchronize(c->compute));
+      HIPCHK(hipMemcpy(sx->map.data(), g.gwin.p, 2ull * kGzWindow, hipMemcpyDeviceToHost));
+    } else {
+      if (stretch_to) { sx->crc_raw = prefix_raw; sx->out_bytes = prefix_len; }      // (a stretch that ends with the member: set by check_members)
+      if (sx->out_bytes != total_out) return SCFQ_GZ_DECLINE;
+      sx->first_byte = stretch_first_byte;
+    }
   }
   if (end_off) *end_off = end_byte;
   fill_ms += cp.fill_ms;
@@ -1043,7 +1165,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
 // the next caller.
 // end_off (optional): the offset just behind the last member's trailer — fsize unless bytes that are not a gzip member follow it
 // fd / fd_off (optional): the file img is mapped from, img[0] being its byte fd_off — the copies into the pinned ring then pread
-int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off = nullptr, int fd = -1, uint64_t fd_off = 0) {
+int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off = nullptr, int fd = -1, uint64_t fd_off = 0, GzStretch* sx = nullptr) {
   GzShared& gs = gz_shared(c->dev);
   static const int n_engines = std::min((int)GzShared::kMax, std::max(1, env_int("SCFQ_GZ_DEVICE_ENGINES", 4)));
   const bool big = fsize > (1ull << 30);
@@ -1061,7 +1183,7 @@ int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags,
     gs.big_running = big;
   }
   GzDevBuffers& g = gs.buf[e];
-  const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing, end_off, fd, fd_off);
+  const int rc = ingest_gz_device_batches(c, g, img, fsize, flags, timing, end_off, fd, fd_off, sx);
   if (c->copy) (void)hipStreamSynchronize(c->copy);
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
   if (g.s_gap) (void)hipStreamSynchronize(g.s_gap);

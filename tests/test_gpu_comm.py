@@ -320,3 +320,41 @@ def test_gzip_shard_cut_that_is_no_member_start(gpu, scfq, oracle, tmp_path):
     sc = os.path.join(PKG, "sc")
     outs, stats = _run_ranks(sc, 2, f, [], {"SCFQ_VERBOSE": "1"})
     assert outs[-1][0] == oracle.tsv(oc) + "\n", outs[-1]
+
+
+def test_one_gzip_member_shards_across_ranks(gpu, scfq, oracle, tmp_path):
+    """the common case — ONE gzip member (gzip / pigz output) — over 2 and 3 ranks: the deflate stream is cut where blocks start; every
+    rank goes over its stretch twice (pass 1: search, decode, the stretch's window MAP; the maps cross the communicator; pass 2: windows,
+    bytes, CRC tiles, scan with the window the ranks before handed over), the member's CRC-32 / ISIZE are checked against the join of
+    the stretches', and the partials fold with the byte in front of each stretch put right.  CRLF records, structure check and quality
+    histogram on: row, bad_at / bad_plus and the histogram are the oracle's; every rank moved compressed bytes and scanned."""
+    import gzip
+    data = fastq_bytes(90_000_000, seed=33).replace(b"\n+\n", b"\r\n+\r\n") + b"@tail\nACGT"
+    f = tmp_path / "one_member.fq.gz"
+    f.write_bytes(gzip.compress(data, 6) + b"\0\0 trailing bytes")
+    oc = oracle.count(np.frombuffer(data, dtype=np.uint8))
+    sc = os.path.join(PKG, "sc")
+    want_hist = "\t".join("%d:%d" % (v, oc.qual_hist[v]) for v in range(256) if oc.qual_hist[v])
+    for world in (2, 3):
+        outs, stats = _run_ranks(sc, world, f, ["--struct-check", "--qual-hist"], {"SCFQ_VERBOSE": "1"})
+        assert outs[-1][0] == oracle.tsv(oc) + "\n", (world, outs[-1][0], outs[-1][1][-2500:])
+        assert "bad_at=%d\tbad_plus=%d" % (oc.bad_at, oc.bad_plus) in outs[-1][1] and want_hist in outs[-1][1]
+        shares = [st["h2d_bytes"] for st in stats]
+        assert all(s > 0 for s in shares) and max(shares) < 0.75 * sum(shares), shares
+        assert "the block cuts of a one-member file did not join up" not in outs[-1][1]
+    # SCFQ_SHARD_GZ_BLOCKS=0: rank 0 alone (the member scheme finds no second member), same row
+    outs, stats = _run_ranks(sc, 2, f, ["--struct-check"], {"SCFQ_SHARD_GZ_BLOCKS": "0"})
+    assert outs[-1][0] == oracle.tsv(oc) + "\n" and stats[0]["h2d_bytes"] == 0
+    # a damaged member (one bit flipped in the second half): the joined CRC-32 does not match, rank 0 reads the whole file and
+    # reports what gzread reports; nobody prints a row
+    blob = bytearray(f.read_bytes())
+    blob[len(blob) * 2 // 3] ^= 0x10
+    bad = tmp_path / "damaged.fq.gz"
+    bad.write_bytes(bytes(blob))
+    port = _free_port()
+    procs = [subprocess.Popen([sc, "fq-count", "--shard-rank=%d" % r, "--shard-world=2", "--rendezvous=127.0.0.1:%d" % port, "--transport=tcp", "--devices=0", str(bad)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    single = subprocess.run([sc, "fq-count", str(bad)], capture_output=True, text=True, timeout=300)
+    assert single.returncode != 0 and procs[1].returncode == single.returncode and outs[1][0] == single.stdout == ""
+    assert procs[0].returncode != 0 and outs[0][0] == ""
