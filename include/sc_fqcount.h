@@ -106,7 +106,8 @@ typedef struct scfq_partial {
   uint64_t hist_class;    /* K3 side array: 0 = all four class histograms are complete; k+1 (k = 0..3) = only class k is
                              (the speculative form histograms just the lines it verified to be quality lines);
                              5 = none (shards that disagree were combined: finalize returns SCFQ_ESPEC) */
-  uint64_t reserved[4];   /* [0]: status word, OR-ed by the combine (scfq_count_file_sharded: a rank whose shard failed); rest 0 */
+  uint64_t reserved[4];   /* [0]: status word, OR-ed by the combine (scfq_count_file_sharded: a rank whose shard failed); the rest 0
+                             (scfq_count_file_sharded carries a gzip shard's first byte, raw CRC-32 and length in them between its ranks) */
 } scfq_partial;
 
 #define SCFQ_HIST_WORDS (4 * 256)  /* optional K3 side array: uint64_t hist[4][256], class-major */
@@ -209,8 +210,18 @@ int scfq_prepare(const scfq_opts* opts);
  * ".gz" input: a BGZF (bgzip) file shards where its members are — rank r takes the members that start in its byte range (the
  * first cut at or after size*r/world where eight members follow one another; the byte in front of a rank's first inflated byte
  * comes from the member before the cut, inflated on the host), inflates them on its device and scans them; the ranks agree on
- * that with one extra all-gather of a word, and fall back together when any of them saw something else in its range. Every other
- * gzip layout (a deflate stream has no shards): rank 0 inflates and scans all of it, the other ranks contribute the identity.
+ * that with one extra all-gather of a word, and fall back together when any of them saw something else in its range.
+ * An ordinary gzip file of SEVERAL members (cat a.gz b.gz, pigz -i, a sequencer's writer) shards where members start: a rank's
+ * cut is the first position at or after size*r/world with the magic bytes, a header that parses and deflate data that inflates
+ * cleanly; it inflates and scans the members of its stretch as if they began the input, and the byte in front of its first
+ * inflated byte — the last byte of the rank before it — is put right when the gathered partials are folded.  A file of ONE member
+ * (gzip, pigz) is cut where deflate BLOCKS start: every rank goes over its stretch twice — once for what the stretch does to the
+ * 32 KiB window (a map: the ranks exchange their maps and compose them in rank order, which gives each the window in front of
+ * its stretch), once to inflate, checksum and scan it; the member's CRC-32 and ISIZE are checked against the join of the
+ * stretches'.  What proves a cut, in both schemes, is the rank before it: its members (its chain of blocks) must end exactly where
+ * the next rank began.  Whenever the ranks' findings do not join up — and for damaged files — rank 0 inflates and scans the whole
+ * file with the readers scfq_count_file() uses (zlib gzread's bytes and errors), the other ranks contribute the identity.
+ * Knobs: SCFQ_SHARD_BGZF / SCFQ_SHARD_GZ / SCFQ_SHARD_GZ_BLOCKS = 0 switch the three schemes off.
  * Collective: every rank must call it. */
 int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* comm, scfq_counts* out);
 
