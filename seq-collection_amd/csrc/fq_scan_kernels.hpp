@@ -661,6 +661,8 @@ __device__ __forceinline__ void hist_tile_planes(const uint32_t* xa, const uint3
   const uint64_t seg0 = ~NL & xm1;                       // below the first newline (everything when there is none)
   const uint64_t seg1 = (~x1 & x1m1) & ~(NL ^ xm1);      // above the first newline, below the second; none without a first
   const uint64_t seg2 = ~(x1 ^ x1m1);                    // above the second newline; none without a second
+  // (r4, measured: the same selection with masks instead of ?: — 12 instructions where the compiler's nested exec-mask regions are ~25 —
+  // ran no faster, 0.664–0.671 against 0.674; and the dword loop without its pivot ran 2.7 % SLOWER on long reads: profiles/r04/hist_ab.txt)
   const uint64_t M = (i0 == 0) ? seg0 : (i0 == 1) ? seg1 : (i0 == 2) ? seg2 : 0ull;
   uint32_t ra = (uint32_t)M, rb = (uint32_t)(M >> 32);   // quality bytes not yet accounted for
   uint64_t have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
