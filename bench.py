@@ -621,7 +621,13 @@ def main():
     if rank == 0 and world == 1 and args.ingest_bytes > 0 and kind == 0 and args.flags == 0:
         del buf          # (the 10 GB workload: the ingest legs measure processes of their own, beside a parent that holds little)
         torch.cuda.empty_cache()
-        out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes), int(min(args.ingest_bgzf_bytes, args.ingest_bytes)))
+        # (non-headline: a failure here — no room for the files, a host short of memory — is reported in the object, never allowed to take
+        # the headline line with it)
+        try:
+            out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes), int(min(args.ingest_bgzf_bytes, args.ingest_bytes)))
+        except BaseException as e:      # noqa: BLE001
+            import traceback
+            out["ingest"] = {"error": "%s: %s" % (type(e).__name__, e), "traceback_tail": traceback.format_exc()[-1500:]}
     if rank == 0:
         print(json.dumps(out))
     if exchange:
