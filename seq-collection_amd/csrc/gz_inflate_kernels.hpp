@@ -591,6 +591,17 @@ __global__ __launch_bounds__(1024) void gz_map_fold(const uint16_t* __restrict__
   }
 }
 
+// The output symbols of proven chain entries, copied out of a batch's symbol pool into a store that outlives the batch (GzStretch with an
+// exchange: the symbols wait for the window the other ranks' maps give, instead of being decoded a second time).  tab[e] = {source offset
+// (the entry's first OUTPUT symbol, behind its markers), destination offset, symbols}; offsets in symbols from the two bases, multiples of 8.
+__global__ __launch_bounds__(256) void gz_pack_symbols(const uint16_t* __restrict__ src_base, uint16_t* __restrict__ dst_base, const uint64_t* __restrict__ tab) {
+  const uint64_t so = tab[3ull * blockIdx.x], dof = tab[3ull * blockIdx.x + 1], n = tab[3ull * blockIdx.x + 2];
+  const uint4* s = reinterpret_cast<const uint4*>(src_base + so);
+  uint4* d = reinterpret_cast<uint4*>(dst_base + dof);
+  const uint64_t n8 = (n + 7) / 8;           // (the room of both is a multiple of 8 symbols)
+  for (uint64_t i = threadIdx.x; i < n8; i += 256) d[i] = s[i];
+}
+
 // ---- G4 ----------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kResolveTile = 1u << 17;                  // symbols per workgroup: the 32 KiB window load is a quarter of the tile's traffic
 // work item w: chain entry entry[w], symbols [tile[w] * kResolveTile, ...) of it

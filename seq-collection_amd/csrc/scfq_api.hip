@@ -19,6 +19,7 @@
 #include "scfq_arena.hpp"
 
 #include <fcntl.h>
+#include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -1573,36 +1574,32 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
         const long h0 = scfq_gzfast::member_header(img, (size_t)size);
         const uint64_t data0 = h0 > 0 ? (uint64_t)h0 : 0, comp = size - data0;
         auto cut_bit = [&](int r) -> uint64_t { return r == 0 ? 0 : (r >= world ? 0 : gz_block_boundary(img, size, data0 + comp / (uint64_t)world * (uint64_t)r, 16ull << 20)); };
-        GzStretch sx1;
-        sx1.start_bit = cut_bit(rank);
-        sx1.stop_bit = cut_bit(rank + 1);
-        sx1.map_only = true;
-        uint64_t ok1 = (h0 > 0 && (rank == 0 || sx1.start_bit) && (rank + 1 == world || sx1.stop_bit)) ? 1 : 0;
-        Ctx* c = nullptr;
-        SessionLock sl;
-        if (!local) local = get_ctx(&c, sl);
-        if (!local && ok1) {
-          // pass 1: the stretch's window map, its length, and the proof that its chain runs from s_r to s_{r+1} exactly
-          const int r1 = ingest_gz_device(c, img, size, o.flags, false, nullptr, fd, 0, &sx1);
-          if (r1 == kFallbackToHost) ok1 = 0; else if (r1) local = r1;
-          if (ok1 && (sx1.map.size() != scfq_gzfast::kWindow || sx1.member_ended != (rank + 1 == world))) ok1 = 0;
-        }
-        // every rank learns every stretch: [ok, start, stop, bytes, where the member ended, the map]
+        GzStretch sx;
+        sx.start_bit = cut_bit(rank);
+        sx.stop_bit = cut_bit(rank + 1);
+        const bool cuts_ok = h0 > 0 && (rank == 0 || sx.start_bit) && (rank + 1 == world || sx.stop_bit);
+        // What every rank learns of every stretch — [proven, start, stop, bytes, where the member ended, the map] — and what it makes of
+        // it: the window in front of its own stretch = the maps of the stretches before it, applied in order to the member's (empty) start.
         const uint32_t kMapWords = (uint32_t)(scfq_gzfast::kWindow / 4), w1 = 5 + kMapWords;
-        std::vector<uint64_t> row1(w1, 0), rows1((size_t)world * w1, 0);
-        row1[0] = (ok1 && !local) ? 1 : 0;
-        row1[1] = sx1.start_bit; row1[2] = sx1.stop_bit; row1[3] = sx1.out_bytes; row1[4] = sx1.end_byte;
-        if (row1[0]) std::memcpy(row1.data() + 5, sx1.map.data(), 2 * scfq_gzfast::kWindow);
-        rc = scfq_comm_allgather_u64(comm, row1.data(), w1, rows1.data(), 0);
-        if (rc) { if (img) munmap(const_cast<uint8_t*>(img), (size_t)size); if (fd >= 0) close(fd); std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return local ? local : rc; }
-        bool agree = true;
-        for (int r = 0; r < world; ++r) {
-          const uint64_t* rr = rows1.data() + (size_t)r * w1;
-          agree = agree && rr[0] == 1 && (r + 1 == world ? rr[2] == 0 : rr[2] == rows1[(size_t)(r + 1) * w1 + 1]);      // a stretch ends where the next begins
-        }
-        if (agree) {
-          // the window in front of this rank's stretch: the maps of the stretches before it, applied in order to the member's (empty) start
-          std::vector<uint8_t> window(scfq_gzfast::kWindow, 0), next(scfq_gzfast::kWindow, 0);
+        std::vector<uint8_t> window(scfq_gzfast::kWindow, 0);
+        bool exchanged = false, agree = false;
+        int comm_rc = SCFQ_OK;
+        auto exchange_fn = [&](GzStretch& x, bool proven) -> int {
+          exchanged = true;
+          std::vector<uint64_t> row1(w1, 0), rows1((size_t)world * w1, 0);
+          proven = proven && cuts_ok && !local && x.map.size() == scfq_gzfast::kWindow && x.member_ended == (rank + 1 == world);
+          row1[0] = proven ? 1 : 0;
+          row1[1] = x.start_bit; row1[2] = x.stop_bit; row1[3] = x.out_bytes; row1[4] = x.end_byte;
+          if (proven) std::memcpy(row1.data() + 5, x.map.data(), 2 * scfq_gzfast::kWindow);
+          comm_rc = scfq_comm_allgather_u64(comm, row1.data(), w1, rows1.data(), 0);
+          if (comm_rc) return 1;
+          agree = true;
+          for (int r = 0; r < world; ++r) {
+            const uint64_t* rr = rows1.data() + (size_t)r * w1;
+            agree = agree && rr[0] == 1 && (r + 1 == world ? rr[2] == 0 : rr[2] == rows1[(size_t)(r + 1) * w1 + 1]);      // a stretch ends where the next begins
+          }
+          if (!agree) return 1;
+          std::vector<uint8_t> next(scfq_gzfast::kWindow, 0);
           uint64_t before_bytes = 0;
           for (int r = 0; r < rank; ++r) {
             const uint16_t* m = reinterpret_cast<const uint16_t*>(rows1.data() + (size_t)r * w1 + 5);
@@ -1611,22 +1608,54 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
             before_bytes += rows1[(size_t)r * w1 + 3];
           }
           blk_end_byte = rows1[(size_t)(world - 1) * w1 + 4];
-          GzStretch sx2;
-          sx2.start_bit = sx1.start_bit;
-          sx2.stop_bit = sx1.stop_bit;
-          sx2.window = window.data();
-          sx2.valid = (uint32_t)std::min<uint64_t>(scfq_gzfast::kWindow, before_bytes);
-          if (!local) local = begin_session(c, rank == 0);
-          if (!local) {
-            // pass 2: windows, bytes, CRC tiles, scan — begun with the window the ranks before handed over
-            const int r2 = ingest_gz_device(c, img, size, o.flags, timing, nullptr, fd, 0, &sx2);
-            local = r2 == kFallbackToHost ? SCFQ_EGZ : r2;
-            if (!local && sx2.out_bytes != sx1.out_bytes) local = SCFQ_EGZ;
+          x.window = window.data();
+          x.valid = (uint32_t)std::min<uint64_t>(scfq_gzfast::kWindow, before_bytes);
+          return 0;
+        };
+        Ctx* c = nullptr;
+        SessionLock sl;
+        if (!local) local = get_ctx(&c, sl);
+        // ONE pass (the default): the stretch's proven symbols are kept — two bytes per inflated byte — while its map goes out and the window
+        // comes back (GzStretch::exchange), then they become bytes.  SCFQ_SHARD_GZ_KEEP=0: two passes, the second decoding again (what a
+        // device short of memory would want: nothing is kept between them).
+        static const bool keep_on = env_int("SCFQ_SHARD_GZ_KEEP", 1) != 0;
+        uint64_t out1 = 0;
+        if (keep_on) {
+          if (!local && cuts_ok) local = begin_session(c, rank == 0);
+          if (!local && cuts_ok) {
+            sx.exchange = exchange_fn;
+            const int r1 = ingest_gz_device(c, img, size, o.flags, timing, nullptr, fd, 0, &sx);
+            if (r1 == kFallbackToHost) { if (agree) local = SCFQ_EGZ; } else if (r1) local = r1;
           }
+          if (!exchanged) (void)exchange_fn(sx, false);
+          out1 = sx.out_bytes;
+        } else {
+          GzStretch sx1 = sx;
+          sx1.map_only = true;
+          bool proven = false;
+          if (!local && cuts_ok) {
+            const int r1 = ingest_gz_device(c, img, size, o.flags, false, nullptr, fd, 0, &sx1);
+            if (r1 == SCFQ_OK) proven = true; else if (r1 != kFallbackToHost) local = r1;
+          }
+          (void)exchange_fn(sx1, proven);
+          out1 = sx1.out_bytes;
+          if (agree) {
+            sx.window = sx1.window;
+            sx.valid = sx1.valid;
+            if (!local) local = begin_session(c, rank == 0);
+            if (!local) {
+              const int r2 = ingest_gz_device(c, img, size, o.flags, timing, nullptr, fd, 0, &sx);
+              local = r2 == kFallbackToHost ? SCFQ_EGZ : r2;
+            }
+          }
+        }
+        if (comm_rc) { if (img) munmap(const_cast<uint8_t*>(img), (size_t)size); if (fd >= 0) close(fd); std::snprintf(g_err, sizeof g_err, "%s", scfq_comm_error_detail()); return local ? local : comm_rc; }
+        if (agree) {
+          if (!local && sx.out_bytes != out1) local = SCFQ_EGZ;
           if (!local) local = end_session(c, want_hist, &mine, want_hist ? hist.data() : nullptr);
-          g_first = sx2.first_byte;
-          blk_crc_raw = sx2.crc_raw;
-          blk_len = sx2.out_bytes;
+          g_first = sx.first_byte;
+          blk_crc_raw = sx.crc_raw;
+          blk_len = sx.out_bytes;
         } else {
           local = SCFQ_EGZ;      // (not an error of this rank: the rows below send every rank to the fall-back)
           std::snprintf(g_err, sizeof g_err, "the block cuts of a one-member file did not join up");

@@ -164,6 +164,10 @@ struct GzStretch {
   std::vector<uint16_t> map;       // pass 1: 32768 symbols — a literal, or 0x8000 | j = byte j of the window in front of the stretch
   uint32_t crc_raw = 0;            // pass 2: raw CRC-32 (zero initial value, no final inversion) of the stretch's bytes
   int first_byte = -1;             // pass 2
+  // ONE pass instead of two: with `exchange` set the call keeps the stretch's proven symbols (packed: two bytes per inflated byte), and when
+  // its map is known calls exchange(*this, ok) — ok false when the stretch could not be proven: the callback is a collective, every rank
+  // must make it —, which fills `window` / `valid` from the other ranks' maps (0: go on; else give up); then the symbols become bytes.
+  std::function<int(GzStretch&, bool)> exchange;
 };
 
 int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off, int fd, uint64_t fd_off, GzStretch* sx) {
@@ -175,7 +179,10 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   gz_alloc_ms() = 0;
   double stage_ms[3] = {0, 0, 0};
   static const bool verbose = std::getenv("SCFQ_VERBOSE") != nullptr;
-  const bool stretch_from = sx && sx->start_bit != 0, stretch_to = sx && sx->stop_bit != 0, map_only = sx && sx->map_only;
+  const bool keep = sx && (bool)sx->exchange;      // one pass: the symbols are kept until the other ranks' maps have given the window
+  const bool stretch_from = sx && sx->start_bit != 0, stretch_to = sx && sx->stop_bit != 0, map_only = sx && (sx->map_only || keep);
+  // (every way out of this function in front of the exchange makes it, with "not proven": the exchange is a collective)
+  struct ExchangeGuard { GzStretch* sx; bool made = false; ~ExchangeGuard() { if (sx && !made) (void)sx->exchange(*sx, false); } } exchange_guard{keep ? sx : nullptr};
   const long h0 = stretch_from ? (long)(sx->start_bit >> 3) : scfq_gzfast::member_header(img, (size_t)fsize);
   if (h0 <= 0 || fsize < 64) return SCFQ_GZ_DECLINE;
   if (sx && ((stretch_to && (sx->stop_bit <= sx->start_bit || (sx->stop_bit >> 3) >= fsize)) || (uint64_t)h0 + 64 > fsize)) return SCFQ_GZ_DECLINE;
@@ -622,6 +629,134 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     return SCFQ_OK;
   };
 
+  // ---- a stretch in ONE pass (GzStretch::exchange): what the first half of every batch leaves for later -----------------------------
+  struct PartHere { uint32_t member; uint64_t off, len; };
+  struct BatchKept {
+    uint32_t k = 0, n_chain = 0, n_chains = 0;
+    uint64_t n_work = 0, batch_out = 0;
+    std::vector<PartHere> parts_here;
+    std::vector<GzChain> chain;                  // sym_off: into the store of kept symbols
+    std::vector<uint32_t> first, we, wt;
+  };
+  std::vector<BatchKept> kept;
+  SymPool keep_store;                            // the proven chain entries' output symbols, packed: 2 bytes per inflated byte of the stretch
+  struct KeepFree { SymPool& p; ~KeepFree() { note_dev_bytes(-(int64_t)p.bytes()); p.release(); } } keep_free{keep_store};
+  DevBuf pack_tab;                               // gz_pack_symbols' tables, a slice per batch
+  struct PackFree { DevBuf& b; ~PackFree() { b.release(); } } pack_free{pack_tab};
+  if (keep) {
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&pack_tab.p), 24ull * max_seg * nb);
+    if (e != hipSuccess) { (void)hipGetLastError(); pack_tab.p = nullptr; return SCFQ_GZ_DECLINE; }
+    pack_tab.cap = 24ull * max_seg * nb;
+  }
+
+  // ---- the second half of a batch: its part of the chain becomes windows, bytes, CRC tiles and a scan.  The chain's tables are in
+  // g.h_pmeta[pp] (chain | first | work entry | work tile); d_sym: where the entries' sym_off count from.  carry_in / carry_out: the
+  // first chain goes on inside a member begun earlier / the last chain's member goes on in the next batch.
+  auto post_process = [&](uint32_t k, int pp, uint16_t* d_sym, uint32_t n_chain, uint32_t n_chains, uint64_t n_work, uint64_t batch_out,
+                          const std::vector<PartHere>& parts_here, bool carry_in, bool carry_out) -> int {
+    const uint32_t* h_first = reinterpret_cast<const uint32_t*>(g.h_pmeta[pp] + offp_first);
+    // room for what this batch turned out to need.  A bigger buffer than the last batch's is a NEW buffer (the old one, which the
+    // last batch's scan may still be reading, is freed when the call ends): that batch's last byte — this batch's look-behind —
+    // moves over with a one-byte copy
+    uint8_t* const old_out = d_out;
+    bool parked = false;
+    if (int r = gz_buf(g, g.out, std::max<uint64_t>(batch_out, (uint64_t)((double)(copy_end_of(k) - byte0_of(k)) * ratio_est * 0.8)) + 2 * kStagePad)) return r;
+    d_out = g.out.p + kStagePad;
+    if (have_prev_out && old_out != d_out) {
+      HIPCHK(hipMemcpyAsync(d_out - 1, old_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToDevice, c->compute));
+      parked = true;
+    }
+        uint8_t* const d_win = g.win.p;
+    // the byte in front of this batch's output is the last byte of the batch before it: parked below the buffer before that is overwritten
+    if (have_prev_out && !parked) HIPCHK(hipMemcpyAsync(d_out - 1, d_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToDevice, c->compute));
+    HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_chain, g.h_pmeta[pp] + offp_chain, sizeof(GzChain) * n_chain, hipMemcpyHostToDevice, c->compute));
+    HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_first, g.h_pmeta[pp] + offp_first, 4ull * (n_chains + 1), hipMemcpyHostToDevice, c->compute));
+    if (n_work) {
+      HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_we, g.h_pmeta[pp] + offp_we, 4ull * n_work, hipMemcpyHostToDevice, c->compute));
+      HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_wt, g.h_pmeta[pp] + offp_wt, 4ull * n_work, hipMemcpyHostToDevice, c->compute));
+    }
+    const uint8_t* w_in = carry_in ? g.d_wcarry + (uint64_t)wcarry * kGzWindow : nullptr;
+    uint8_t* w_out = carry_out ? g.d_wcarry + (uint64_t)(wcarry ^ 1) * kGzWindow : nullptr;
+    const GzChain* d_chain = reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_chain);
+    span_begin(sp_chain, c->compute);
+    if (n_chain <= n_chains + group) {
+      // short chains: one walk per member
+      hipLaunchKernelGGL(gz_window_chain, dim3(n_chains), dim3(1024), 0, c->compute, d_chain, reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_first),
+                         d_sym, d_win, w_in, w_out, (const uint8_t*)nullptr);
+    } else {
+      // groups of `group` entries inside every member's chain: maps, windows in front of the groups, windows in front of the entries
+      GzChain* h_gchain = reinterpret_cast<GzChain*>(g.h_pmeta[pp] + offp_gchain);
+      uint32_t* h_gfirst = reinterpret_cast<uint32_t*>(g.h_pmeta[pp] + offp_gfirst);
+      uint32_t* h_mfirst = reinterpret_cast<uint32_t*>(g.h_pmeta[pp] + offp_mfirst);
+      uint32_t n_groups = 0;
+      for (uint32_t ch = 0; ch < n_chains; ++ch) {
+        h_mfirst[ch] = n_groups;
+        for (uint32_t q = h_first[ch]; q < h_first[ch + 1]; q += group) {
+          if (n_groups >= max_groups) return SCFQ_GZ_DECLINE;      // (cannot happen: max_groups covers a group per member and per 64 entries)
+          h_gfirst[n_groups] = q;
+          h_gchain[n_groups] = GzChain{};
+          h_gchain[n_groups].sym_off = (uint64_t)n_groups * kGzWindow;       // (map g lies one window further: the form of a segment's symbols)
+          h_gchain[n_groups].n_sym = kGzWindow;
+          ++n_groups;
+        }
+      }
+      h_mfirst[n_chains] = n_groups;
+      h_gfirst[n_groups] = n_chain;
+      // (a bigger map buffer than the last batch's is a new one: that batch's window kernels are behind this batch's on the same stream)
+      if (int r = gz_buf(g, g.maps, 2ull * kGzWindow * (n_groups + 1))) return r;
+      if (int r = gz_buf(g, g.gwin, (uint64_t)kGzWindow * n_groups)) return r;
+      HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gchain, h_gchain, sizeof(GzChain) * n_groups, hipMemcpyHostToDevice, c->compute));
+      HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gfirst, h_gfirst, 4ull * (n_groups + 1), hipMemcpyHostToDevice, c->compute));
+      HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_mfirst, h_mfirst, 4ull * (n_chains + 1), hipMemcpyHostToDevice, c->compute));
+      const uint32_t* d_gfirst = reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_gfirst);
+      hipLaunchKernelGGL(gz_window_maps, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, d_sym, reinterpret_cast<uint16_t*>(g.maps.p));
+      hipLaunchKernelGGL(gz_window_chain, dim3(n_chains), dim3(1024), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_gchain),
+                         reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_mfirst), reinterpret_cast<const uint16_t*>(g.maps.p), g.gwin.p, w_in, w_out,
+                         (const uint8_t*)nullptr);
+      hipLaunchKernelGGL(gz_window_chain, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, d_sym, d_win, (const uint8_t*)nullptr,
+                         (uint8_t*)nullptr, (const uint8_t*)g.gwin.p);
+    }
+    HIPCHK(hipGetLastError());
+    span_end(sp_chain, c->compute);
+    if (carry_out) wcarry ^= 1;
+    if (n_work) {
+      span_begin(sp_resolve, c->compute);
+      hipLaunchKernelGGL(gz_resolve, dim3((unsigned)n_work), dim3(256), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_chain),
+                         reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_we), reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_wt), d_sym,
+                         d_win, d_out, reinterpret_cast<uint32_t*>(g.crc.p));
+      HIPCHK(hipGetLastError());
+      span_end(sp_resolve, c->compute);
+    }
+    span_begin(sp_crc, c->compute);
+    for (const PartHere& ph : parts_here) {
+      const uint64_t nt = (ph.len + kCrcTile - 1) / kCrcTile;
+      if (nt) {
+        hipLaunchKernelGGL(gz_crc32_tiles, dim3((unsigned)nt), dim3(256), 0, c->compute, d_out + ph.off, ph.len, nt * kCrcTile - ph.len,
+                           reinterpret_cast<uint32_t*>(g.crc.p) + 16 + tiles_used);
+        HIPCHK(hipGetLastError());
+      }
+      parts.push_back(GzPart{ph.member, ph.len, tiles_used, nt});
+      tiles_used += nt;
+    }
+    span_end(sp_crc, c->compute);
+    if (sx && !have_prev_out && batch_out) {
+      // (the byte a shard of a sharded count begins with: what the byte in front of it — known to the rank before — decides at the fold)
+      uint8_t fb = 0;
+      HIPCHK(hipMemcpyAsync(&fb, d_out, 1, hipMemcpyDeviceToHost, c->compute));
+      HIPCHK(hipStreamSynchronize(c->compute));
+      stretch_first_byte = fb;
+    }
+    if (batch_out) {
+      span_begin(sp_scan, c->compute);
+      rc = scan_async(c, d_out, batch_out, have_prev_out ? -2 : -1, flags & ~SCFQ_PREV_IN_MEMORY, timing);
+      if (rc) return rc;
+      span_end(sp_scan, c->compute);
+      have_prev_out = true;
+      prev_out_bytes = batch_out;
+    }
+      return SCFQ_OK;
+  };
+
   // ---- stage C(k): walk, windows, bytes, CRC tiles, scan -----------------------------------------------------------------------
   auto stage_c = [&](uint32_t k) -> int {
     GzSlot& sl = g.slot[k % n_slots];
@@ -826,7 +961,6 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     uint32_t* h_wt = reinterpret_cast<uint32_t*>(g.h_pmeta[pp] + offp_wt);
     uint64_t batch_out = 0, n_work = 0;
     uint32_t n_chains = 0, valid_end = valid;
-    struct PartHere { uint32_t member; uint64_t off, len; };
     std::vector<PartHere> parts_here;
     {
       uint32_t v = valid, cur_m = 0xFFFFFFFFu;
@@ -886,6 +1020,30 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
                            reinterpret_cast<uint16_t*>(g.gwin.p), reinterpret_cast<uint16_t*>(g.gwin.p) + kGzWindow);
         HIPCHK(hipGetLastError());
         span_end(sp_chain, c->compute);
+        if (keep) {
+          // the entries' output symbols move to the store (this batch's pool is the batch after next's), the tables wait on the host
+          BatchKept bk;
+          bk.k = k; bk.n_chain = n_chain; bk.n_chains = n_chains; bk.n_work = n_work; bk.batch_out = batch_out;
+          bk.parts_here = parts_here;
+          bk.chain.assign(h_chain, h_chain + n_chain);
+          bk.first.assign(h_first, h_first + n_chains + 1);
+          bk.we.assign(h_we, h_we + n_work);
+          bk.wt.assign(h_wt, h_wt + n_work);
+          std::vector<uint64_t> tab(3ull * n_chain);
+          for (uint32_t q = 0; q < n_chain; ++q) {
+            uint64_t off = 0;
+            if (gz_take(keep_store, std::max<uint64_t>(8, ((uint64_t)h_chain[q].n_sym + 7) & ~7ull), &off)) return SCFQ_GZ_DECLINE;
+            tab[3ull * q] = h_chain[q].sym_off + kGzWindow;
+            tab[3ull * q + 1] = off;
+            tab[3ull * q + 2] = h_chain[q].n_sym;
+            bk.chain[q].sym_off = off - kGzWindow;       // (the kernels add the marker prefix's length back: 64-bit wrap-around)
+          }
+          uint64_t* d_tab = reinterpret_cast<uint64_t*>(pack_tab.p) + 3ull * max_seg * k;
+          HIPCHK(hipMemcpy(d_tab, tab.data(), 24ull * n_chain, hipMemcpyHostToDevice));
+          hipLaunchKernelGGL(gz_pack_symbols, dim3(n_chain), dim3(256), 0, c->compute, sl.sym.base(), keep_store.base(), d_tab);
+          HIPCHK(hipGetLastError());
+          kept.push_back(std::move(bk));
+        }
       }
       HIPCHK(hipEventRecord(g.ev_post[pp], c->compute));
       total_out += batch_out;
@@ -897,108 +1055,9 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       return SCFQ_OK;
     }
     if (n_chain) {
-      // room for what this batch turned out to need.  A bigger buffer than the last batch's is a NEW buffer (the old one, which the
-      // last batch's scan may still be reading, is freed when the call ends): that batch's last byte — this batch's look-behind —
-      // moves over with a one-byte copy
-      uint8_t* const old_out = d_out;
-      bool parked = false;
-      if (int r = gz_buf(g, g.out, std::max<uint64_t>(batch_out, (uint64_t)((double)(copy_end_of(k) - byte0_of(k)) * ratio_est * 0.8)) + 2 * kStagePad)) return r;
-      d_out = g.out.p + kStagePad;
-      if (have_prev_out && old_out != d_out) {
-        HIPCHK(hipMemcpyAsync(d_out - 1, old_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToDevice, c->compute));
-        parked = true;
-      }
-      uint16_t* const d_sym = sl.sym.base();
-      uint8_t* const d_win = g.win.p;
       const bool carry_in = chain[0].member == member_no && valid > 0;                                     // the first chain goes on inside a member begun earlier
       const bool carry_out = !finished_end && chain[n_chain - 1].member == member_end_no;               // the last chain's member goes on in the next batch
-      // the byte in front of this batch's output is the last byte of the batch before it: parked below the buffer before that is overwritten
-      if (have_prev_out && !parked) HIPCHK(hipMemcpyAsync(d_out - 1, d_out + prev_out_bytes - 1, 1, hipMemcpyDeviceToDevice, c->compute));
-      HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_chain, g.h_pmeta[pp] + offp_chain, sizeof(GzChain) * n_chain, hipMemcpyHostToDevice, c->compute));
-      HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_first, g.h_pmeta[pp] + offp_first, 4ull * (n_chains + 1), hipMemcpyHostToDevice, c->compute));
-      if (n_work) {
-        HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_we, g.h_pmeta[pp] + offp_we, 4ull * n_work, hipMemcpyHostToDevice, c->compute));
-        HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_wt, g.h_pmeta[pp] + offp_wt, 4ull * n_work, hipMemcpyHostToDevice, c->compute));
-      }
-      const uint8_t* w_in = carry_in ? g.d_wcarry + (uint64_t)wcarry * kGzWindow : nullptr;
-      uint8_t* w_out = carry_out ? g.d_wcarry + (uint64_t)(wcarry ^ 1) * kGzWindow : nullptr;
-      const GzChain* d_chain = reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_chain);
-      span_begin(sp_chain, c->compute);
-      if (n_chain <= n_chains + group) {
-        // short chains: one walk per member
-        hipLaunchKernelGGL(gz_window_chain, dim3(n_chains), dim3(1024), 0, c->compute, d_chain, reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_first),
-                           d_sym, d_win, w_in, w_out, (const uint8_t*)nullptr);
-      } else {
-        // groups of `group` entries inside every member's chain: maps, windows in front of the groups, windows in front of the entries
-        GzChain* h_gchain = reinterpret_cast<GzChain*>(g.h_pmeta[pp] + offp_gchain);
-        uint32_t* h_gfirst = reinterpret_cast<uint32_t*>(g.h_pmeta[pp] + offp_gfirst);
-        uint32_t* h_mfirst = reinterpret_cast<uint32_t*>(g.h_pmeta[pp] + offp_mfirst);
-        uint32_t n_groups = 0;
-        for (uint32_t ch = 0; ch < n_chains; ++ch) {
-          h_mfirst[ch] = n_groups;
-          for (uint32_t q = h_first[ch]; q < h_first[ch + 1]; q += group) {
-            if (n_groups >= max_groups) return SCFQ_GZ_DECLINE;      // (cannot happen: max_groups covers a group per member and per 64 entries)
-            h_gfirst[n_groups] = q;
-            h_gchain[n_groups] = GzChain{};
-            h_gchain[n_groups].sym_off = (uint64_t)n_groups * kGzWindow;       // (map g lies one window further: the form of a segment's symbols)
-            h_gchain[n_groups].n_sym = kGzWindow;
-            ++n_groups;
-          }
-        }
-        h_mfirst[n_chains] = n_groups;
-        h_gfirst[n_groups] = n_chain;
-        // (a bigger map buffer than the last batch's is a new one: that batch's window kernels are behind this batch's on the same stream)
-        if (int r = gz_buf(g, g.maps, 2ull * kGzWindow * (n_groups + 1))) return r;
-        if (int r = gz_buf(g, g.gwin, (uint64_t)kGzWindow * n_groups)) return r;
-        HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gchain, h_gchain, sizeof(GzChain) * n_groups, hipMemcpyHostToDevice, c->compute));
-        HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_gfirst, h_gfirst, 4ull * (n_groups + 1), hipMemcpyHostToDevice, c->compute));
-        HIPCHK(hipMemcpyAsync(g.d_pmeta[pp] + offp_mfirst, h_mfirst, 4ull * (n_chains + 1), hipMemcpyHostToDevice, c->compute));
-        const uint32_t* d_gfirst = reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_gfirst);
-        hipLaunchKernelGGL(gz_window_maps, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, d_sym, reinterpret_cast<uint16_t*>(g.maps.p));
-        hipLaunchKernelGGL(gz_window_chain, dim3(n_chains), dim3(1024), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_gchain),
-                           reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_mfirst), reinterpret_cast<const uint16_t*>(g.maps.p), g.gwin.p, w_in, w_out,
-                           (const uint8_t*)nullptr);
-        hipLaunchKernelGGL(gz_window_chain, dim3(n_groups), dim3(1024), 0, c->compute, d_chain, d_gfirst, d_sym, d_win, (const uint8_t*)nullptr,
-                           (uint8_t*)nullptr, (const uint8_t*)g.gwin.p);
-      }
-      HIPCHK(hipGetLastError());
-      span_end(sp_chain, c->compute);
-      if (carry_out) wcarry ^= 1;
-      if (n_work) {
-        span_begin(sp_resolve, c->compute);
-        hipLaunchKernelGGL(gz_resolve, dim3((unsigned)n_work), dim3(256), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_chain),
-                           reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_we), reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_wt), d_sym,
-                           d_win, d_out, reinterpret_cast<uint32_t*>(g.crc.p));
-        HIPCHK(hipGetLastError());
-        span_end(sp_resolve, c->compute);
-      }
-      span_begin(sp_crc, c->compute);
-      for (const PartHere& ph : parts_here) {
-        const uint64_t nt = (ph.len + kCrcTile - 1) / kCrcTile;
-        if (nt) {
-          hipLaunchKernelGGL(gz_crc32_tiles, dim3((unsigned)nt), dim3(256), 0, c->compute, d_out + ph.off, ph.len, nt * kCrcTile - ph.len,
-                             reinterpret_cast<uint32_t*>(g.crc.p) + 16 + tiles_used);
-          HIPCHK(hipGetLastError());
-        }
-        parts.push_back(GzPart{ph.member, ph.len, tiles_used, nt});
-        tiles_used += nt;
-      }
-      span_end(sp_crc, c->compute);
-      if (sx && !have_prev_out && batch_out) {
-        // (the byte a shard of a sharded count begins with: what the byte in front of it — known to the rank before — decides at the fold)
-        uint8_t fb = 0;
-        HIPCHK(hipMemcpyAsync(&fb, d_out, 1, hipMemcpyDeviceToHost, c->compute));
-        HIPCHK(hipStreamSynchronize(c->compute));
-        stretch_first_byte = fb;
-      }
-      if (batch_out) {
-        span_begin(sp_scan, c->compute);
-        rc = scan_async(c, d_out, batch_out, have_prev_out ? -2 : -1, flags & ~SCFQ_PREV_IN_MEMORY, timing);
-        if (rc) return rc;
-        span_end(sp_scan, c->compute);
-        have_prev_out = true;
-        prev_out_bytes = batch_out;
-      }
+      if (int r = post_process(k, pp, sl.sym.base(), n_chain, n_chains, n_work, batch_out, parts_here, carry_in, carry_out)) return r;
     }
     HIPCHK(hipEventRecord(g.ev_post[pp], c->compute));
     for (const GzMemberEnd& me : ends_here) member_ends.push_back(me);
@@ -1109,6 +1168,38 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     if (rc) return rc;
     end_byte = rest.rs.end_offset();
     resumed = true;
+  } else if (keep) {
+    // ---- the stretch's map goes out, the window in front of it comes back, and the kept symbols become bytes ------------------------
+    sx->out_bytes = total_out;
+    sx->member_ended = !stretch_to;
+    sx->end_byte = end_byte;
+    sx->map.resize(kGzWindow);
+    HIPCHK(hipStreamSynchronize(c->compute));
+    HIPCHK(hipMemcpy(sx->map.data(), g.gwin.p, 2ull * kGzWindow, hipMemcpyDeviceToHost));
+    exchange_guard.made = true;
+    if (sx->exchange(*sx, true)) return SCFQ_GZ_DECLINE;
+    valid = sx->valid;
+    wcarry = 0;
+    if (valid) HIPCHK(hipMemcpy(g.d_wcarry, sx->window, kGzWindow, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < kept.size(); ++i) {
+      BatchKept& bk = kept[i];
+      const int pp = (int)(i % n_slots);
+      if (i >= n_slots) HIPCHK(hipEventSynchronize(g.ev_post[pp]));      // the pinned tables of this parity were the batch's before last
+      GzChain* h_chain = reinterpret_cast<GzChain*>(g.h_pmeta[pp] + offp_chain);
+      uint32_t v = valid;
+      for (uint32_t q = 0; q < bk.n_chain; ++q) {
+        h_chain[q] = bk.chain[q];
+        h_chain[q].valid_before = v;
+        v = (uint32_t)std::min<uint64_t>(kGzWindow, (uint64_t)v + bk.chain[q].n_sym);
+      }
+      std::memcpy(g.h_pmeta[pp] + offp_first, bk.first.data(), 4ull * bk.first.size());
+      std::memcpy(g.h_pmeta[pp] + offp_we, bk.we.data(), 4ull * bk.we.size());
+      std::memcpy(g.h_pmeta[pp] + offp_wt, bk.wt.data(), 4ull * bk.wt.size());
+      if ((rc = post_process(bk.k, pp, keep_store.base(), bk.n_chain, bk.n_chains, bk.n_work, bk.batch_out, bk.parts_here, valid > 0, i + 1 < kept.size()))) return rc;
+      HIPCHK(hipEventRecord(g.ev_post[pp], c->compute));
+      valid = v;
+    }
+    if ((rc = check_members())) return rc;
   } else if (map_only) {
     // (pass 1 of a stretch: no bytes, no CRC)
   } else if ((rc = check_members())) {
@@ -1118,7 +1209,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   }
   if (sx) {
     sx->end_byte = end_byte;
-    if (map_only) {
+    if (map_only && !keep) {
       sx->out_bytes = total_out;
       sx->member_ended = !stretch_to;
       sx->map.resize(kGzWindow);

@@ -324,9 +324,10 @@ def test_gzip_shard_cut_that_is_no_member_start(gpu, scfq, oracle, tmp_path):
 
 def test_one_gzip_member_shards_across_ranks(gpu, scfq, oracle, tmp_path):
     """the common case — ONE gzip member (gzip / pigz output) — over 2 and 3 ranks: the deflate stream is cut where blocks start; every
-    rank goes over its stretch twice (pass 1: search, decode, the stretch's window MAP; the maps cross the communicator; pass 2: windows,
-    bytes, CRC tiles, scan with the window the ranks before handed over), the member's CRC-32 / ISIZE are checked against the join of
-    the stretches', and the partials fold with the byte in front of each stretch put right.  CRLF records, structure check and quality
+    rank searches, decodes and proves its stretch, folds what it does to the 32 KiB window into a MAP and keeps the proven symbols; the
+    maps cross the communicator, composed in rank order they give every rank the window in front of its stretch, and the kept symbols
+    become bytes, CRC tiles and a scan (or, SCFQ_SHARD_GZ_KEEP=0, the stretch is decoded a second time); the member's CRC-32 / ISIZE are
+    checked against the join of the stretches', and the partials fold with the byte in front of each stretch put right.  CRLF records, structure check and quality
     histogram on: row, bad_at / bad_plus and the histogram are the oracle's; every rank moved compressed bytes and scanned."""
     import gzip
     data = fastq_bytes(90_000_000, seed=33).replace(b"\n+\n", b"\r\n+\r\n") + b"@tail\nACGT"
@@ -335,9 +336,10 @@ def test_one_gzip_member_shards_across_ranks(gpu, scfq, oracle, tmp_path):
     oc = oracle.count(np.frombuffer(data, dtype=np.uint8))
     sc = os.path.join(PKG, "sc")
     want_hist = "\t".join("%d:%d" % (v, oc.qual_hist[v]) for v in range(256) if oc.qual_hist[v])
-    for world in (2, 3):
-        outs, stats = _run_ranks(sc, world, f, ["--struct-check", "--qual-hist"], {"SCFQ_VERBOSE": "1"})
-        assert outs[-1][0] == oracle.tsv(oc) + "\n", (world, outs[-1][0], outs[-1][1][-2500:])
+    # (SCFQ_SHARD_GZ_KEEP=0: two passes per rank, the second decoding again; the default keeps the proven symbols between map and bytes)
+    for world, keep in ((2, "1"), (3, "1"), (2, "0"), (3, "0")):
+        outs, stats = _run_ranks(sc, world, f, ["--struct-check", "--qual-hist"], {"SCFQ_VERBOSE": "1", "SCFQ_SHARD_GZ_KEEP": keep})
+        assert outs[-1][0] == oracle.tsv(oc) + "\n", (world, keep, outs[-1][0], outs[-1][1][-2500:])
         assert "bad_at=%d\tbad_plus=%d" % (oc.bad_at, oc.bad_plus) in outs[-1][1] and want_hist in outs[-1][1]
         shares = [st["h2d_bytes"] for st in stats]
         assert all(s > 0 for s in shares) and max(shares) < 0.75 * sum(shares), shares
