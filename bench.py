@@ -175,10 +175,22 @@ def ingest_rows(scfq, member_bytes, bgzf_bytes):
                       "first_call_wall_s": round(walls[0], 4), "warm_wall_s": round(walls[1], 4), "warm_GBps": round(data_size / walls[1] / 1e9, 2),
                       "warm_what": "the faster of the second and third call in this process", "counters_match_generator": True}
 
+    def synth(nbytes):
+        # (generated on the device and copied to the host: the host generator is the same pure function — tests/test_gpu_parity.py holds the
+        # two to the same bytes — and needs 9 s per GB on one core)
+        import torch
+        plan = scfq.synth_plan(0, SEED, nbytes)
+        dbuf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda")
+        info = scfq.synth_device(0, SEED, plan.records, dbuf.data_ptr(), plan.bytes)
+        assert info.bytes == plan.bytes
+        host = dbuf[:plan.bytes].cpu().numpy()
+        del dbuf
+        torch.cuda.empty_cache()
+        return plan, host, info
+
     try:
         # ---- BGZF, bgzf_bytes ----
-        plan = scfq.synth_plan(0, SEED, bgzf_bytes)
-        data, info = scfq.synth_host(0, SEED, plan.records)
+        plan, data, info = synth(bgzf_bytes)
         want = (plan.records, info.gc_bases, info.n_bases, info.bases)
         bg = os.path.join(tmp, "bgzf.fq.gz")
         write_bgzf(data, bg)
@@ -191,8 +203,7 @@ def ingest_rows(scfq, member_bytes, bgzf_bytes):
         # ---- one gzip member, member_bytes (configs[3]) ----
         if member_bytes != bgzf_bytes:
             del data
-            plan = scfq.synth_plan(0, SEED, member_bytes)
-            data, info = scfq.synth_host(0, SEED, plan.records)
+            plan, data, info = synth(member_bytes)
             want = (plan.records, info.gc_bases, info.n_bases, info.bases)
         gz = os.path.join(tmp, "member.fq.gz")
         write_member(data, gz)

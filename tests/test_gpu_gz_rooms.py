@@ -183,6 +183,19 @@ def _crc32_combine(crc1, crc2, len2):
     return crc1 ^ crc2
 
 
+def _synth_on_device(scfq, torch, seed, nbytes):
+    """the synthetic stream generated on the DEVICE and copied to the host (the host generator is the same pure function, checked against
+    it in test_gpu_parity.py, and takes 9 s per GB on one core): (plan, info, bytes as a numpy array)"""
+    plan = scfq.synth_plan(0, seed, int(nbytes))
+    buf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda:0")
+    info = scfq.synth_device(0, seed, plan.records, buf.data_ptr(), plan.bytes)
+    assert info.bytes == plan.bytes
+    data = buf[:plan.bytes].cpu().numpy()
+    del buf
+    torch.cuda.empty_cache()
+    return plan, info, data
+
+
 def test_crc32_combine_helper():
     a, b = os.urandom(1000), os.urandom(77777)
     assert _crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
@@ -191,9 +204,8 @@ def test_crc32_combine_helper():
 def test_member_beyond_4_gib(gpu, scfq, tmp_path):
     """4.6 GB in ONE member (ISIZE wraps) through the device gzip path, and the same bytes as BGZF through the device BGZF path:
     counters == the generator's tallies (src/fq_count.nim:38-45 on bytes gzread would yield)"""
-    plan = scfq.synth_plan(0, 20260104, int(4.6e9))
+    plan, info, data = _synth_on_device(scfq, gpu, 20260104, 4.6e9)
     assert plan.bytes > (1 << 32) + (200 << 20)
-    data, info = scfq.synth_host(0, 20260104, plan.records)
     want = "%d\t" % plan.records, "\t%d\t%d\t%d\n" % (info.gc_bases, info.n_bases, info.bases)
     f = tmp_path / "big_member.fq.gz"
     _pigz_like(str(f), data)
@@ -229,8 +241,7 @@ def test_configs3_ten_gb_member(gpu, scfq, tmp_path):
     generator's tallies; the scan kernels stay hidden under the host's fill.  (src/fq_count.nim:30-45, gzip_stream.nim:16-17)"""
     import json
     import time
-    plan = scfq.synth_plan(0, 20260101, int(10e9))
-    data, info = scfq.synth_host(0, 20260101, plan.records)
+    plan, info, data = _synth_on_device(scfq, gpu, 20260101, 10e9)
     want = (plan.records, info.gc_bases, info.n_bases, info.bases)
     f = tmp_path / "configs3.fq.gz"
     _pigz_like(str(f), data, level=6)
