@@ -19,11 +19,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
                           "scan_kernel_ms": round(tm.scan_kernel_ms, 3), "h2d_bytes": tm.h2d_bytes}), flush=True)
     sys.exit(0)
 
+import torch      # (before the library: both then share ONE HIP runtime — torch ships its own libamdhip64, and a device pointer of one runtime means nothing to the other)
 import scfq
 nbytes = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2 << 30
 tmp = sys.argv[2] if len(sys.argv) > 2 else "/tmp"
 plan = scfq.synth_plan(0, 20260101, nbytes)
-data, info = scfq.synth_host(0, 20260101, plan.records)
+# (generated on the device and copied back: the host generator — the same pure function — needs 9 s per GB)
+_buf = torch.empty(plan.bytes + 4096, dtype=torch.uint8, device="cuda")
+info = scfq.synth_device(0, 20260101, plan.records, _buf.data_ptr(), plan.bytes)
+data = _buf[:plan.bytes].cpu().numpy()
+del _buf
+torch.cuda.empty_cache()
 plain = os.path.join(tmp, "scfq_gzd.fq")
 data.tofile(plain)
 t0 = time.time()

@@ -598,6 +598,14 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       last_start = st;
       ++n_seg;
     }
+    // Longest first (r4; SCFQ_GZ_DEVICE_SORT_SEGMENTS=0: file order).  A workgroup holds its LDS until its slowest wave is through, and the
+    // LDS is what limits the decode kernel's occupancy: with the segments of a batch in order of length the workgroups are of one kind
+    // each, the short ones end early and their room goes to the next batch's workgroups, which are queued on the other decode stream.
+    // Measured on the 10 GB member, three alternating pairs on one box (profiles/r04/gz_sort_segments_ab.jsonl): 111 - 112 ms against
+    // 120 - 123, decode kernels 78 ms against 88.  The walk finds segments by their start bit: their order in the table is free.
+    static const int sort_segs = env_int("SCFQ_GZ_DEVICE_SORT_SEGMENTS", 1);
+    if (sort_segs && n_seg > 1)
+      std::sort(h_segs, h_segs + n_seg, [](const GzSeg& a, const GzSeg& b) { return a.stop_bit - a.start_bit > b.stop_bit - b.start_bit; });
     sl.sym.rewind();
     for (uint32_t q = 0; q < n_seg; ++q) {
       const uint64_t cap = seg_cap(h_segs[q].start_bit, h_segs[q].stop_bit, 1.0);

@@ -8,6 +8,10 @@ Mirrors (reference tree):
 
 The counting itself always goes through the C ABI (include/sc_fqcount.h) into the HIP kernels; there is
 no Python or CPU fallback here: if the shared library is missing or no GPU is visible the calls raise.
+
+A process that also uses PyTorch: `import torch` BEFORE the first call of this module.  torch ships a libamdhip64 of its own; whichever
+copy is loaded first serves both, and with two copies in one process a device pointer of one runtime means nothing to the other
+(`scfq_synth_device` / `count_device` on a torch tensor then fail with SCFQ_EHIP).
 """
 import ctypes
 import os
