@@ -476,6 +476,15 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       if (th.joinable()) th.join();
     }
   } cp;
+  // (a second copy stream for the second half of every piece: measured, see DESIGN.md §5 "(r4) The warm path")
+  static const int copy_streams = env_int("SCFQ_GZ_DEVICE_COPY_STREAMS", 1);
+  hipStream_t s_copy2 = nullptr;
+  hipEvent_t ev_copy2 = nullptr;
+  struct Copy2Free { hipStream_t& s; hipEvent_t& e; ~Copy2Free() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } if (e) (void)hipEventDestroy(e); } } copy2_free{s_copy2, ev_copy2};
+  if (copy_streams >= 2 && nb > 1) {
+    HIPCHK(hipStreamCreateWithFlags(&s_copy2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_copy2, hipEventDisableTiming));
+  }
   auto copy_batch = [&](uint32_t k) -> int {       // (runs on the copier thread)
     const auto tf = clk::now();
     const int cb = (int)(k % 4);
@@ -489,7 +498,16 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       auto t1 = clk::now();
       copy_file_bytes(fbytes, off, c->h_pin[pb], len);
       auto t2 = clk::now();
-      HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
+      if (s_copy2 && len >= (8ull << 20)) {
+        // two halves on two streams: two copy engines share the link (SCFQ_GZ_DEVICE_COPY_STREAMS=2, files of several batches)
+        const uint64_t h1 = (len / 2 + 4095) & ~4095ull;
+        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)h1, hipMemcpyHostToDevice, c->copy));
+        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0) + h1, c->h_pin[pb] + h1, (size_t)(len - h1), hipMemcpyHostToDevice, s_copy2));
+        HIPCHK(hipEventRecord(ev_copy2, s_copy2));
+        HIPCHK(hipStreamWaitEvent(c->copy, ev_copy2, 0));      // (everything behind this on the copy stream — and every event recorded there — covers both halves)
+      } else {
+        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
+      }
       HIPCHK(hipEventRecord(c->ev_copied[pb], c->copy));
       auto t3 = clk::now();
       cp.evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
