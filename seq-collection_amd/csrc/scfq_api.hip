@@ -1618,7 +1618,17 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
         // ONE pass (the default): the stretch's proven symbols are kept — two bytes per inflated byte — while its map goes out and the window
         // comes back (GzStretch::exchange), then they become bytes.  SCFQ_SHARD_GZ_KEEP=0: two passes, the second decoding again (what a
         // device short of memory would want: nothing is kept between them).
-        static const bool keep_on = env_int("SCFQ_SHARD_GZ_KEEP", 1) != 0;
+        static const bool keep_env = env_int("SCFQ_SHARD_GZ_KEEP", 1) != 0;
+        bool keep_on = keep_env;
+        if (keep_on && !local) {
+          // (the store of kept symbols: two bytes per inflated byte — taken as 12 per compressed byte of the stretch, FASTQ compresses 3 - 5
+          // times — must leave the pipeline its own 12 GB or so: a rank whose device is short of that goes over its stretch twice instead;
+          // the ranks need not agree on this, the exchange in the middle is the same)
+          size_t free_b = 0, total_b = 0;
+          const uint64_t lo_b = sx.start_bit >> 3, hi_b = sx.stop_bit ? (sx.stop_bit >> 3) : size;
+          if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+          if ((hi_b > lo_b ? hi_b - lo_b : 0) * 12 + (16ull << 30) > (uint64_t)free_b) keep_on = false;
+        }
         uint64_t out1 = 0;
         if (keep_on) {
           if (!local && cuts_ok) local = begin_session(c, rank == 0);
