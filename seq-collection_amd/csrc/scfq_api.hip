@@ -1435,10 +1435,13 @@ bool gz_member_here(const uint8_t* img, uint64_t n, uint64_t p, uint64_t stop, i
   return true;
 }
 // the first demonstrable member start at or after `from`; n when there is none.  *first_byte as above (stop: the end of the rank's stretch)
-uint64_t gz_member_boundary(const uint8_t* img, uint64_t n, uint64_t from, uint64_t stop, int* first_byte) {
+// (limit: only starts in front of this offset are looked for — a rank that only wants to know what its own share of the file holds does
+// not walk a 25 GB member to its end)
+uint64_t gz_member_boundary(const uint8_t* img, uint64_t n, uint64_t from, uint64_t stop, int* first_byte, uint64_t limit = ~0ull) {
   *first_byte = -1;
-  for (uint64_t p = from; p + 18 <= n;) {
-    const void* hit = std::memchr(img + p, 0x1f, (size_t)(n - 17 - p));
+  const uint64_t last = std::min<uint64_t>(limit, n >= 17 ? n - 17 : 0);       // first offset that is no candidate any more
+  for (uint64_t p = from; p < last;) {
+    const void* hit = std::memchr(img + p, 0x1f, (size_t)(last - p));
     if (!hit) break;
     p = (uint64_t)(static_cast<const uint8_t*>(hit) - img);
     if (img[p + 1] == 0x8b && img[p + 2] == 8 && !(img[p + 3] & 0xE0) && gz_member_here(img, n, p, std::max(stop, p + 1), first_byte)) return p;
@@ -1536,16 +1539,21 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
       if (m != MAP_FAILED) {
         img = static_cast<const uint8_t*>(m);
         size = (uint64_t)sb.st_size;
-        int f_hi = -1;
-        const uint64_t nom_lo = size / (uint64_t)world * (uint64_t)rank, nom_hi = size / (uint64_t)world * (uint64_t)(rank + 1);
-        g_hi = rank + 1 < world ? gz_member_boundary(img, size, nom_hi, nom_hi, &f_hi) : size;
-        if (rank == 0) g_lo = gz_member_here(img, size, 0, std::max<uint64_t>(g_hi, 1), &g_first) ? 0 : size + 1;      // (size + 1: not a gzip file at all)
-        else g_lo = gz_member_boundary(img, size, nom_lo, g_hi, &g_first);
-        if (g_lo <= size) { if (g_hi < g_lo) g_hi = g_lo; mine_ok = 2; }
-        // (bit 2: no member starts at or behind this rank's cut — when every rank says so the file is ONE member, or as good as: the
-        // ranks cut its deflate stream where blocks start instead)
+        const uint64_t nom_lo = size / (uint64_t)world * (uint64_t)rank, nom_hi = rank + 1 < world ? size / (uint64_t)world * (uint64_t)(rank + 1) : size;
+        // (bit 1: an ordinary gzip file as far as this rank can tell without walking it — the cuts themselves are looked for once the ranks
+        // have agreed on a scheme; a rank that then finds none says so in the gathered rows)
+        int fb = -1;
+        if (rank != 0 || gz_member_here(img, size, 0, 1, &fb)) mine_ok = 2;
+        // (bit 2: at most ONE member starts inside this rank's share of the file — rank 0: none behind the file's first.  When every rank
+        // says so the members are big ones — one, or a few: `cat lane1.gz lane2.gz` — and the ranks cut the deflate streams where BLOCKS
+        // start, a member start being a cut of its own: no rank is left without work, as the member scheme leaves the ranks in whose share
+        // no member starts.  The search stays inside the rank's share.)
         static const bool shard_blocks = env_int("SCFQ_SHARD_GZ_BLOCKS", 1) != 0;
-        if (mine_ok == 2 && shard_blocks && size >= (uint64_t)world * (8ull << 20) && (rank == 0 ? g_hi == size : g_lo == size)) mine_ok = 6;
+        if (mine_ok == 2 && shard_blocks && size >= (uint64_t)world * (8ull << 20)) {
+          const uint64_t m1 = gz_member_boundary(img, size, rank == 0 ? 1 : nom_lo, size, &fb, nom_hi);
+          const uint64_t m2 = m1 < nom_hi ? gz_member_boundary(img, size, m1 + 1, size, &fb, nom_hi) : size;
+          if (rank == 0 ? m1 >= nom_hi : m2 >= nom_hi) mine_ok = 6;
+        }
       }
     }
     std::vector<uint64_t> oks((size_t)world, 0);
@@ -1561,6 +1569,15 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
         sharded_blk = sharded_blk && oks[(size_t)r] == 6;
       }
     }
+    if (sharded_gz && !sharded_blk) {
+      // (the member scheme's cuts: the first demonstrable member start at or after size * r / world and the one after the next rank's)
+      int f_hi = -1;
+      const uint64_t nom_lo = size / (uint64_t)world * (uint64_t)rank, nom_hi = size / (uint64_t)world * (uint64_t)(rank + 1);
+      g_hi = rank + 1 < world ? gz_member_boundary(img, size, nom_hi, nom_hi, &f_hi) : size;
+      if (rank == 0) g_lo = 0, (void)gz_member_here(img, size, 0, std::max<uint64_t>(g_hi, 1), &g_first);
+      else g_lo = gz_member_boundary(img, size, nom_lo, g_hi, &g_first);
+      if (g_hi < g_lo) g_hi = g_lo;
+    }
     if (sharded_gz) {
       // every rank inflates and scans the members of its stretch as if they were a file of their own (device path; the host's decoder
       // when that declines), scanned as if they began the input; the partials — with each stretch's first byte and whether its members
@@ -1568,46 +1585,77 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
       // (the last byte of the stretch before it) put right first: gz_shard_fix.
       if (o.n_devices >= 1 && hipSetDevice(o.device_ids[0]) != hipSuccess) local = SCFQ_EHIP;
       uint64_t end_off = 0;
-      uint64_t blk_crc_raw = 0, blk_len = 0, blk_end_byte = 0;      // block scheme: this stretch's raw CRC-32 and length; where the member ended
+      uint64_t blk_crc_raw = 0, blk_len = 0;      // block scheme: this stretch's raw CRC-32 and length
+      struct BlkGroup { uint64_t first, last, end_byte; };
+      std::vector<BlkGroup> blk_groups;          // ... and the members: the ranks that hold one, the offset just behind its trailer
       if (sharded_blk) {
-        // ---- ONE member: rank r's stretch is [s_r, s_{r+1}), s_r the first block start at or behind its share of the deflate data ----
+        // ---- big members: rank r's stretch is [cut_r, cut_{r+1}) — a cut is the member start inside the rank's share of the file when there
+        // is one, else the first block start at or behind the share's first byte; a stretch never crosses a member's end ----
+        struct Cut { bool found = false, member = false; uint64_t byte = 0, bit = 0; };
+        auto cut_of = [&](int r) -> Cut {
+          Cut ct;
+          if (r <= 0) { ct.found = true; ct.member = true; return ct; }
+          if (r >= world) { ct.found = true; ct.member = true; ct.byte = size; ct.bit = size * 8; return ct; }
+          const uint64_t lo = size / (uint64_t)world * (uint64_t)r, hi = r + 1 < world ? size / (uint64_t)world * (uint64_t)(r + 1) : size;
+          int fb = -1;
+          const uint64_t m = gz_member_boundary(img, size, lo, size, &fb, hi);
+          if (m < hi) { ct.found = true; ct.member = true; ct.byte = m; ct.bit = m * 8; return ct; }
+          const uint64_t bb = gz_block_boundary(img, size, lo, std::min<uint64_t>(16ull << 20, hi - lo));
+          if (bb && (bb >> 3) < hi) { ct.found = true; ct.bit = bb; ct.byte = bb >> 3; }
+          return ct;
+        };
+        const Cut c_lo = cut_of(rank), c_hi = cut_of(rank + 1);
         const long h0 = scfq_gzfast::member_header(img, (size_t)size);
-        const uint64_t data0 = h0 > 0 ? (uint64_t)h0 : 0, comp = size - data0;
-        auto cut_bit = [&](int r) -> uint64_t { return r == 0 ? 0 : (r >= world ? 0 : gz_block_boundary(img, size, data0 + comp / (uint64_t)world * (uint64_t)r, 16ull << 20)); };
+        // the stretch as the pipeline sees it: an image that begins at the member's start (a member cut) or at the file's (a block cut:
+        // bit positions are the file's), and ends where the next member starts (a member cut) or with the file
+        const uint64_t base = c_lo.member ? c_lo.byte : 0;
+        const uint64_t image_end = c_hi.member ? c_hi.byte : size;
         GzStretch sx;
-        sx.start_bit = cut_bit(rank);
-        sx.stop_bit = cut_bit(rank + 1);
-        const bool cuts_ok = h0 > 0 && (rank == 0 || sx.start_bit) && (rank + 1 == world || sx.stop_bit);
-        // What every rank learns of every stretch — [proven, start, stop, bytes, where the member ended, the map] — and what it makes of
-        // it: the window in front of its own stretch = the maps of the stretches before it, applied in order to the member's (empty) start.
-        const uint32_t kMapWords = (uint32_t)(scfq_gzfast::kWindow / 4), w1 = 5 + kMapWords;
+        sx.start_bit = c_lo.member ? 0 : c_lo.bit;
+        sx.stop_bit = c_hi.member ? 0 : c_hi.bit - 8 * base;
+        const bool cuts_ok = h0 > 0 && c_lo.found && c_hi.found && image_end > base + 64 && (c_hi.member || c_hi.bit > (c_lo.member ? c_lo.byte * 8 : c_lo.bit));
+        // What every rank learns of every stretch — [proven, cut kinds and positions, bytes, where its member ended, the map] — and what it
+        // makes of it: the window in front of its own stretch = the maps of the stretches before it IN THE SAME MEMBER, applied in order to
+        // the member's (empty) start.
+        const uint32_t kMapWords = (uint32_t)(scfq_gzfast::kWindow / 4), kHead = 8, w1 = kHead + kMapWords;
         std::vector<uint8_t> window(scfq_gzfast::kWindow, 0);
         bool exchanged = false, agree = false;
         int comm_rc = SCFQ_OK;
         auto exchange_fn = [&](GzStretch& x, bool proven) -> int {
           exchanged = true;
           std::vector<uint64_t> row1(w1, 0), rows1((size_t)world * w1, 0);
-          proven = proven && cuts_ok && !local && x.map.size() == scfq_gzfast::kWindow && x.member_ended == (rank + 1 == world);
+          // (a stretch that ends at a member cut must have ended WITH its member, exactly at the cut: nothing but members in between)
+          proven = proven && cuts_ok && !local && x.map.size() == scfq_gzfast::kWindow && x.member_ended == c_hi.member &&
+                   (!c_hi.member || c_hi.byte == size || base + x.end_byte == c_hi.byte);
           row1[0] = proven ? 1 : 0;
-          row1[1] = x.start_bit; row1[2] = x.stop_bit; row1[3] = x.out_bytes; row1[4] = x.end_byte;
-          if (proven) std::memcpy(row1.data() + 5, x.map.data(), 2 * scfq_gzfast::kWindow);
+          row1[1] = c_lo.member; row1[2] = c_lo.bit; row1[3] = c_hi.member; row1[4] = c_hi.bit;
+          row1[5] = x.out_bytes; row1[6] = base + x.end_byte;
+          if (proven) std::memcpy(row1.data() + kHead, x.map.data(), 2 * scfq_gzfast::kWindow);
           comm_rc = scfq_comm_allgather_u64(comm, row1.data(), w1, rows1.data(), 0);
           if (comm_rc) return 1;
           agree = true;
           for (int r = 0; r < world; ++r) {
             const uint64_t* rr = rows1.data() + (size_t)r * w1;
-            agree = agree && rr[0] == 1 && (r + 1 == world ? rr[2] == 0 : rr[2] == rows1[(size_t)(r + 1) * w1 + 1]);      // a stretch ends where the next begins
+            const uint64_t* nx = r + 1 < world ? rows1.data() + (size_t)(r + 1) * w1 : nullptr;
+            agree = agree && rr[0] == 1 && (nx ? (rr[3] == nx[1] && rr[4] == nx[2]) : (rr[3] == 1 && rr[4] == size * 8));      // a stretch ends where the next begins
           }
           if (!agree) return 1;
+          // the members' ends, for the CRC check at the fold: [first rank, last rank, offset just behind the trailer]
+          blk_groups.clear();
+          for (int r = 0, a0 = 0; r < world; ++r) {
+            const uint64_t* rr = rows1.data() + (size_t)r * w1;
+            if (rr[3] == 1) { blk_groups.push_back({(uint64_t)a0, (uint64_t)r, rr[6]}); a0 = r + 1; }
+          }
+          int first_of_member = rank;
+          while (first_of_member > 0 && rows1[(size_t)first_of_member * w1 + 1] == 0) --first_of_member;
           std::vector<uint8_t> next(scfq_gzfast::kWindow, 0);
           uint64_t before_bytes = 0;
-          for (int r = 0; r < rank; ++r) {
-            const uint16_t* m = reinterpret_cast<const uint16_t*>(rows1.data() + (size_t)r * w1 + 5);
+          for (int r = first_of_member; r < rank; ++r) {
+            const uint16_t* m = reinterpret_cast<const uint16_t*>(rows1.data() + (size_t)r * w1 + kHead);
             for (uint32_t i = 0; i < scfq_gzfast::kWindow; ++i) next[i] = (m[i] & 0x8000u) ? window[m[i] & 0x7FFFu] : (uint8_t)m[i];
             window.swap(next);
-            before_bytes += rows1[(size_t)r * w1 + 3];
+            before_bytes += rows1[(size_t)r * w1 + 5];
           }
-          blk_end_byte = rows1[(size_t)(world - 1) * w1 + 4];
           x.window = window.data();
           x.valid = (uint32_t)std::min<uint64_t>(scfq_gzfast::kWindow, before_bytes);
           return 0;
@@ -1625,7 +1673,7 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
           // times — must leave the pipeline its own 12 GB or so: a rank whose device is short of that goes over its stretch twice instead;
           // the ranks need not agree on this, the exchange in the middle is the same)
           size_t free_b = 0, total_b = 0;
-          const uint64_t lo_b = sx.start_bit >> 3, hi_b = sx.stop_bit ? (sx.stop_bit >> 3) : size;
+          const uint64_t lo_b = c_lo.byte, hi_b = c_hi.byte;
           if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
           if ((hi_b > lo_b ? hi_b - lo_b : 0) * 12 + (16ull << 30) > (uint64_t)free_b) keep_on = false;
         }
@@ -1634,7 +1682,7 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
           if (!local && cuts_ok) local = begin_session(c, rank == 0);
           if (!local && cuts_ok) {
             sx.exchange = exchange_fn;
-            const int r1 = ingest_gz_device(c, img, size, o.flags, timing, nullptr, fd, 0, &sx);
+            const int r1 = ingest_gz_device(c, img + base, image_end - base, o.flags, timing, nullptr, fd, base, &sx);
             if (r1 == kFallbackToHost) { if (agree) local = SCFQ_EGZ; } else if (r1) local = r1;
           }
           if (!exchanged) (void)exchange_fn(sx, false);
@@ -1644,7 +1692,7 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
           sx1.map_only = true;
           bool proven = false;
           if (!local && cuts_ok) {
-            const int r1 = ingest_gz_device(c, img, size, o.flags, false, nullptr, fd, 0, &sx1);
+            const int r1 = ingest_gz_device(c, img + base, image_end - base, o.flags, false, nullptr, fd, base, &sx1);
             if (r1 == SCFQ_OK) proven = true; else if (r1 != kFallbackToHost) local = r1;
           }
           (void)exchange_fn(sx1, proven);
@@ -1654,7 +1702,7 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
             sx.valid = sx1.valid;
             if (!local) local = begin_session(c, rank == 0);
             if (!local) {
-              const int r2 = ingest_gz_device(c, img, size, o.flags, timing, nullptr, fd, 0, &sx);
+              const int r2 = ingest_gz_device(c, img + base, image_end - base, o.flags, timing, nullptr, fd, base, &sx);
               local = r2 == kFallbackToHost ? SCFQ_EGZ : r2;
             }
           }
@@ -1720,24 +1768,25 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
       bool all_ok = true;
       for (int r = 0; r < world; ++r) all_ok = all_ok && rows[(size_t)r * words + offsetof(scfq_partial, reserved) / 8] == 0;
       if (all_ok && sharded_blk) {
-        // the member's CRC-32 and ISIZE against the join of the stretches' (x^(8 |part|), as between the batches of one stretch)
-        uint32_t raw = 0;
-        uint64_t len = 0;
-        for (int r = 0; r < world; ++r) {
-          const uint64_t* rr = rows.data() + (size_t)r * words + offsetof(scfq_partial, reserved) / 8;
-          raw = gz_mulmod(gz_xpow8n(rr[3]), raw) ^ (uint32_t)rr[2];
-          len += rr[3];
+        // every member's CRC-32 and ISIZE against the join of its stretches' (x^(8 |part|), as between the batches of one stretch)
+        const int tfd = open(path, O_RDONLY);
+        for (const BlkGroup& gpm : blk_groups) {
+          uint32_t raw = 0;
+          uint64_t len = 0;
+          for (uint64_t r = gpm.first; r <= gpm.last; ++r) {
+            const uint64_t* rr = rows.data() + (size_t)r * words + offsetof(scfq_partial, reserved) / 8;
+            raw = gz_mulmod(gz_xpow8n(rr[3]), raw) ^ (uint32_t)rr[2];
+            len += rr[3];
+          }
+          const uint32_t crc = raw ^ gz_mulmod(gz_xpow8n(len), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+          uint8_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          const bool have_trailer = tfd >= 0 && gpm.end_byte >= 8 && pread(tfd, t, 8, (off_t)(gpm.end_byte - 8)) == 8;
+          const uint32_t t_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+          const uint32_t t_len = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+          if (!have_trailer || t_crc != crc || t_len != (uint32_t)(len & 0xFFFFFFFFull)) all_ok = false;      // damaged: gzread's verdict, from rank 0's readers
         }
-        const uint32_t crc = raw ^ gz_mulmod(gz_xpow8n(len), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
-        uint8_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        bool have_trailer = false;
-        if (blk_end_byte >= 8) {
-          const int tfd = open(path, O_RDONLY);
-          if (tfd >= 0) { have_trailer = pread(tfd, t, 8, (off_t)(blk_end_byte - 8)) == 8; close(tfd); }
-        }
-        const uint32_t t_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-        const uint32_t t_len = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-        if (!have_trailer || t_crc != crc || t_len != (uint32_t)(len & 0xFFFFFFFFull)) all_ok = false;      // damaged: gzread's verdict, from rank 0's readers
+        if (tfd >= 0) close(tfd);
+        if (blk_groups.empty()) all_ok = false;
       }
       if (all_ok) {
         scfq_partial_identity(&all, want_hist ? hist_all.data() : nullptr);

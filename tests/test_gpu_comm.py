@@ -360,3 +360,26 @@ def test_one_gzip_member_shards_across_ranks(gpu, scfq, oracle, tmp_path):
     single = subprocess.run([sc, "fq-count", str(bad)], capture_output=True, text=True, timeout=300)
     assert single.returncode != 0 and procs[1].returncode == single.returncode and outs[1][0] == single.stdout == ""
     assert procs[0].returncode != 0 and outs[0][0] == ""
+
+
+def test_a_few_big_gzip_members_shard_across_ranks(gpu, scfq, oracle, tmp_path):
+    """`cat lane1.fq.gz lane2.fq.gz`: two members of 20 MB (compressed) each over 2, 3 and 4 ranks.  The member scheme would leave the ranks
+    in whose share no member starts without work; with at most one member start per share the ranks cut where BLOCKS start, a member
+    start being a cut of its own: a stretch never crosses a member's end, the window maps compose inside a member only, and each member's
+    CRC-32 is the join of the stretches that hold it.  Row, structure check and histogram == oracle; every rank moved bytes and scanned."""
+    import gzip
+    a = fastq_bytes(60_000_000, seed=41).replace(b"\n+\n", b"\r\n+\r\n")
+    b = fastq_bytes(61_000_000, seed=42)
+    data = a + b
+    f = tmp_path / "two_lanes.fq.gz"
+    f.write_bytes(gzip.compress(a, 6) + gzip.compress(b, 6))
+    oc = oracle.count(np.frombuffer(data, dtype=np.uint8))
+    sc = os.path.join(PKG, "sc")
+    want_hist = "\t".join("%d:%d" % (v, oc.qual_hist[v]) for v in range(256) if oc.qual_hist[v])
+    for world in (2, 3, 4):
+        outs, stats = _run_ranks(sc, world, f, ["--struct-check", "--qual-hist"], {"SCFQ_VERBOSE": "1"})
+        assert outs[-1][0] == oracle.tsv(oc) + "\n", (world, outs[-1][0], outs[-1][1][-2500:])
+        assert "bad_at=%d\tbad_plus=%d" % (oc.bad_at, oc.bad_plus) in outs[-1][1] and want_hist in outs[-1][1]
+        shares = [st["h2d_bytes"] for st in stats]
+        assert all(s > 0 for s in shares) and max(shares) < 0.75 * sum(shares), (world, shares)
+        assert "did not join up" not in outs[-1][1]
