@@ -215,7 +215,8 @@ int scfq_prepare(const scfq_opts* opts);
  * cut is the first position at or after size*r/world with the magic bytes, a header that parses and deflate data that inflates
  * cleanly; it inflates and scans the members of its stretch as if they began the input, and the byte in front of its first
  * inflated byte — the last byte of the rank before it — is put right when the gathered partials are folded.  A file of ONE member
- * (gzip, pigz) is cut where deflate BLOCKS start: every rank decodes its stretch to symbols, folds what the stretch does to the
+ * (gzip, pigz) or of a few big ones (every rank finds at most one member start inside its share of the file) is cut where deflate
+ * BLOCKS start, a member start being a cut of its own and no stretch crossing a member's end: every rank decodes its stretch to symbols, folds what the stretch does to the
  * 32 KiB window into a map and keeps the symbols; the ranks exchange their maps and compose them in rank order, which gives each
  * the window in front of its stretch; then the symbols become bytes, are checksummed and scanned (SCFQ_SHARD_GZ_KEEP=0: nothing
  * is kept, the stretch is decoded a second time); the member's CRC-32 and ISIZE are checked against the join of the stretches'.  What proves a cut, in both schemes, is the rank before it: its members (its chain of blocks) must end exactly where

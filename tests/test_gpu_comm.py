@@ -368,8 +368,10 @@ def test_a_few_big_gzip_members_shard_across_ranks(gpu, scfq, oracle, tmp_path):
     start being a cut of its own: a stretch never crosses a member's end, the window maps compose inside a member only, and each member's
     CRC-32 is the join of the stretches that hold it.  Row, structure check and histogram == oracle; every rank moved bytes and scanned."""
     import gzip
-    a = fastq_bytes(60_000_000, seed=41).replace(b"\n+\n", b"\r\n+\r\n")
-    b = fastq_bytes(61_000_000, seed=42)
+    # (the first member the longer one: the second then starts inside the second rank's share whatever the number of ranks here — a share
+    # that holds two member starts, or a second one in rank 0's, sends the file to the member scheme)
+    a = fastq_bytes(66_000_000, seed=41).replace(b"\n+\n", b"\r\n+\r\n")
+    b = fastq_bytes(56_000_000, seed=42)
     data = a + b
     f = tmp_path / "two_lanes.fq.gz"
     f.write_bytes(gzip.compress(a, 6) + gzip.compress(b, 6))
