@@ -11,11 +11,12 @@
 //   D1  dd_hash_headers       64-bit hash of every header line (line 4i, EOL stripped as Nim readLine does)
 //   D2  radix sort            (hash, record) pairs, rocprim::radix_sort_pairs; stable, so equal hashes stay in file order
 //   D3  dd_mark_duplicates    a record is a duplicate iff an EARLIER record of its equal-hash run has the same bytes:
-//                             exact string compare, so hash collisions cost time, never correctness
+//                             exact string compare, so hash collisions cost time, never correctness (dd_count_marks: the statistics,
+//                             summed per block — an atomic per wave on one counter was half of D3's time)
 //   D4  dd_record_lengths     bytes each kept record echoes: for each of its lines, text + '\n' ("\r\n" comes out as "\n",
-//                             a final line without '\n' gains one: `echo record`, fq_dedup.nim:59,67,71)
-//   D5  exclusive scan        output offset of every kept record (rocprim::exclusive_scan)
-//   D6  dd_gather             one wave per 32 records: one contiguous 16 B/lane copy when the group is kept verbatim
+//                             a final line without '\n' gains one: `echo record`, fq_dedup.nim:59,67,71), summed per group of 32 records
+//   D5  exclusive scan        output offset of every GROUP (rocprim::exclusive_scan)
+//   D6  dd_gather             one wave per group: one contiguous copy, eight 16 B loads per lane in flight, when the group is kept verbatim
 // Everything is integer / byte work bound by HBM traffic; there is no CPU fallback.
 #include "../../include/sc_fqcount.h"
 
@@ -78,6 +79,36 @@ int scratch_pool(hipMemPool_t* out) {
   *out = it->second;
   return SCFQ_OK;
 }
+
+// The call's private stream comes from a per-device list of idle ones and goes back to it (r4: creating and destroying a stream per
+// call cost more host time than all the launches of the pipeline; scfq_shutdown destroys them).  A stream is only returned by a call
+// that has waited for everything it put on it.
+std::map<int, std::vector<hipStream_t>> g_idle_streams;      // under g_pool_mu
+
+struct StreamLease {
+  hipStream_t s = nullptr;
+  int dev = -1;
+  bool clean = false;            // set by the owner once nothing is pending on s: a stream with work in flight is destroyed instead
+  int acquire() {
+    DCHK(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      auto& v = g_idle_streams[dev];
+      if (!v.empty()) { s = v.back(); v.pop_back(); return SCFQ_OK; }
+    }
+    DCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return SCFQ_OK;
+  }
+  ~StreamLease() {
+    if (!s) return;
+    if (clean || hipStreamSynchronize(s) == hipSuccess) {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      auto& v = g_idle_streams[dev];
+      if (v.size() < 8) { v.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+  }
+};
 
 struct DevBuf {   // returns its memory to the pool on scope exit (stream-ordered)
   void* p = nullptr;
@@ -264,9 +295,8 @@ __global__ __launch_bounds__(256) void dd_find_equal(const K* keys_sorted, uint6
 // the per-thread walk.
 template <typename K>
 __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, uint64_t n, const uint64_t* line_off, const uint64_t* hdr,
-                                                         const K* keys_sorted, const uint32_t* idx_sorted, const uint32_t* cand,
-                                                         const uint32_t* n_cand, uint8_t* dup,
-                                                         unsigned long long* counters /* [0] dups, [1] hash collisions */, bool has_cr) {
+                                                         const K* keys_sorted, const uint32_t* idx_sorted, uint32_t* cand /* in: sorted position; out: collisions met */,
+                                                         const uint32_t* n_cand, uint8_t* dup, bool has_cr) {
   __shared__ uint64_t sh_s[4][128];
   __shared__ uint32_t sh_len[4][128];
   __shared__ uint64_t sh_w[4][128][9];
@@ -313,71 +343,142 @@ __global__ __launch_bounds__(256) void dd_mark_duplicates(const uint8_t* base, u
       ++collided;
     }
   }
-  if (is_dup) {                       // dup[] was zeroed: only the duplicates pay a scattered byte store
-    dup[me] = 1;
-    atomicAdd(&counters[0], 1ull);
-  }
-  if (collided) atomicAdd(&counters[1], (unsigned long long)collided);
+  // dup[] was zeroed: only the duplicates pay a scattered byte store.  They are COUNTED by dd_count_marks afterwards: an atomic per
+  // wave on the one counter here (72 K of them behind each other at the L2) was most of this kernel's time (r4)
+  if (is_dup) dup[me] = 1;
+  cand[t] = collided;                  // (this thread's own entry, read above: summed by dd_count_marks like the marks)
 }
 
-// D4: bytes record i echoes (0 when dropped): its lines 4i .. min(4i+3, lines-1), each text + '\n'
-__global__ __launch_bounds__(256) void dd_record_lengths(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
-                                                        uint64_t n_hdr, const uint8_t* dup, uint64_t* out_len, bool has_cr) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_hdr) return;
-  uint64_t total = 0;
-  if (!dup[i] && !has_cr) {
-    // no "\r\n" anywhere: a record echoes exactly its own bytes (a final line without '\n' gains the one its sentinel implies)
-    const uint64_t j1 = (4 * i + 4 < lines) ? 4 * i + 4 : lines;
-    total = line_off[j1] - line_off[4 * i];
-  } else if (!dup[i]) {
-    for (uint64_t j = 4 * i; j < 4 * i + 4 && j < lines; ++j) {
-      uint64_t s, e;
-      line_span(base, n, line_off, j, s, e);
-      total += e - s + 1;
+// the number of marked records and of collisions met: a block per slice of dup[] (16 bytes per load) and of the candidates' collision
+// counts, ONE atomic per block and counter
+__global__ __launch_bounds__(256) void dd_count_marks(const uint8_t* dup, uint64_t n_hdr, const uint32_t* coll, const uint32_t* n_cand,
+                                                     unsigned long long* counters /* [0] dups, [1] hash collisions */) {
+  __shared__ uint32_t sum_sh[2][4];
+  const uint64_t per_block = ((n_hdr + gridDim.x - 1) / gridDim.x + 15) & ~15ull;       // (dup + a multiple of 16 is 16-byte aligned)
+  const uint64_t lo = std::min<uint64_t>((uint64_t)blockIdx.x * per_block, n_hdr), hi = std::min<uint64_t>(lo + per_block, n_hdr);
+  uint32_t c = 0, k = 0;
+  for (uint64_t p = lo + 16ull * threadIdx.x; p < hi; p += 16ull * 256) {
+    if (p + 16 <= hi) {
+      const uint4 v = *reinterpret_cast<const uint4*>(dup + p);                          // flags are 0 or 1: a byte sum is a popcount
+      c += (uint32_t)__builtin_popcount(v.x) + (uint32_t)__builtin_popcount(v.y) + (uint32_t)__builtin_popcount(v.z) + (uint32_t)__builtin_popcount(v.w);
+    } else {
+      for (uint64_t q = p; q < hi; ++q) c += dup[q];
     }
   }
-  out_len[i] = total;
+  const uint64_t nc = *n_cand;
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < nc; t += (uint64_t)gridDim.x * 256) k += coll[t];
+  for (int off = 32; off > 0; off >>= 1) { c += (uint32_t)__shfl_down((int)c, off, 64); k += (uint32_t)__shfl_down((int)k, off, 64); }
+  if ((threadIdx.x & 63) == 0) { sum_sh[0][threadIdx.x >> 6] = c; sum_sh[1][threadIdx.x >> 6] = k; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const uint32_t t = sum_sh[threadIdx.x][0] + sum_sh[threadIdx.x][1] + sum_sh[threadIdx.x][2] + sum_sh[threadIdx.x][3];
+    if (t) atomicAdd(&counters[threadIdx.x], (unsigned long long)t);
+  }
+}
+
+// D6 works on groups of kGatherGroup consecutive records, one wave each
+constexpr uint64_t kGatherGroup = 32;
+
+// D4: bytes record i echoes (0 when dropped): its lines 4i .. min(4i+3, lines-1), each text + '\n' — and their sum over every group of
+// kGatherGroup records: the output offsets are a prefix sum over the GROUPS (870 K of them for 28 M records: the scan over the records,
+// its 0.19 ms and its two arrays went with that, r4), a record's own offset is found by the wave that gathers its group
+__global__ __launch_bounds__(256) void dd_record_lengths(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
+                                                        uint64_t n_hdr, const uint8_t* dup, uint64_t* out_len, uint64_t* group_len, bool has_cr) {
+  static_assert(kGatherGroup == 32, "the sum below runs over the two halves of a wave");
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t total = 0;
+  if (i < n_hdr && !dup[i]) {
+    if (!has_cr) {
+      // no "\r\n" anywhere: a record echoes exactly its own bytes (a final line without '\n' gains the one its sentinel implies)
+      const uint64_t j1 = (4 * i + 4 < lines) ? 4 * i + 4 : lines;
+      total = line_off[j1] - line_off[4 * i];
+    } else {
+      for (uint64_t j = 4 * i; j < 4 * i + 4 && j < lines; ++j) {
+        uint64_t s, e;
+        line_span(base, n, line_off, j, s, e);
+        total += e - s + 1;
+      }
+    }
+  }
+  if (i < n_hdr) out_len[i] = total;
+  uint64_t sum = total;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)sum, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(sum >> 32), off, 64);
+    sum += (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  if ((threadIdx.x & 31) == 0 && i < n_hdr) group_len[i / kGatherGroup] = sum;
 }
 
 // D6: one wave per group of kGatherGroup consecutive records.  When the whole group is kept and echoed verbatim (same
-// number of bytes in and out: no '\r' stripped, no '\n' added, nothing dropped) it is ONE contiguous copy of ~11 KB,
-// 16 bytes per lane per step; a group that is dropped entirely costs two loads.  Mixed groups go record by record, a
-// record that is not verbatim line by line.
-constexpr uint64_t kGatherGroup = 32;
-
-__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint64_t len, uint32_t lane) {
-  uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+// number of bytes in and out: no '\r' stripped, no '\n' added, nothing dropped) it is ONE contiguous copy of ~11 KB;
+// a group that is dropped entirely costs two loads.  Mixed groups go record by record, a record that is not verbatim line by line.
+//
+// The copy keeps EIGHT 16-byte loads per lane in flight before the first store (r4: with one load, one wait and one store per step a
+// wave had 1 KB on its way, the device 8 MB: the kernel ran at 4.96 TB/s of reads + writes).
+// NT: the stores go out non-temporal (measured r4: 8 % slower; SCFQ_DEDUP_NT=1)
+template <bool NT>
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint64_t len, uint32_t lane, uint32_t dst_align) {
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  // dst_align (16, 64 or 128): the 16-byte stores of a step cover whole lines of the destination when the body starts on a line
+  uint64_t head = (dst_align - ((uintptr_t)dst & (dst_align - 1))) & (dst_align - 1);
   if (head > len) head = len;
-  if (lane < head) dst[lane] = src[lane];
+  for (uint64_t t = lane; t < head; t += 64) dst[t] = src[t];
   const uint64_t body = (len - head) / 16;
-  for (uint64_t k = lane; k < body; k += 64) {
-    uint4 v;
-    __builtin_memcpy(&v, src + head + k * 16, 16);       // the source is arbitrarily aligned
-    *reinterpret_cast<uint4*>(dst + head + k * 16) = v;
+  const uint8_t* sp = src + head;
+  uint8_t* dp = dst + head;
+  auto put = [&](const v4u& v, uint64_t k) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dp + k * 16));
+    else *reinterpret_cast<v4u*>(dp + k * 16) = v;
+  };
+  uint64_t k = lane;
+  for (; k + 7 * 64 < body; k += 8 * 64) {
+    v4u v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) __builtin_memcpy(&v[u], sp + (k + 64u * u) * 16, 16);       // the source is arbitrarily aligned
+#pragma unroll
+    for (int u = 0; u < 8; ++u) put(v[u], k + 64u * u);
   }
-  for (uint64_t k = head + body * 16 + lane; k < len; k += 64) dst[k] = src[k];
+  if (k + 3 * 64 < body) {
+    v4u v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) __builtin_memcpy(&v[u], sp + (k + 64u * u) * 16, 16);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) put(v[u], k + 64u * u);
+    k += 4 * 64;
+  }
+  {   // at most four steps are left: all their loads first as well
+    v4u v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (k + 64u * u < body) __builtin_memcpy(&v[u], sp + (k + 64u * u) * 16, 16);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (k + 64u * u < body) put(v[u], k + 64u * u);
+  }
+  for (uint64_t t = head + body * 16 + lane; t < len; t += 64) dst[t] = src[t];
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void dd_gather(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
-                                                uint64_t n_hdr, const uint64_t* out_off, const uint64_t* out_len, uint8_t* out) {
+                                                uint64_t n_hdr, const uint64_t* group_off, const uint64_t* out_len, uint8_t* out, uint32_t dst_align) {
   const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t i0 = g * kGatherGroup;
   if (i0 >= n_hdr) return;
   const uint64_t i1 = (i0 + kGatherGroup < n_hdr) ? i0 + kGatherGroup : n_hdr;
-  const uint64_t o0 = out_off[i0], o1 = out_off[i1];          // out_off has n_hdr + 1 entries
+  const uint64_t o0 = group_off[g], o1 = group_off[g + 1];    // group_off has one entry more than there are groups
   if (o1 == o0) return;                                       // every record of the group was dropped
   const uint64_t jl = (4 * i1 < lines) ? 4 * i1 : lines;
   const uint64_t s0 = line_off[4 * i0], s1 = line_off[jl];
-  if (s1 - s0 == o1 - o0 && s1 <= n) { wave_copy(out + o0, base + s0, o1 - o0, lane); return; }
+  if (s1 - s0 == o1 - o0 && s1 <= n) { wave_copy<NT>(out + o0, base + s0, o1 - o0, lane, dst_align); return; }
+  uint64_t at = o0;                                            // where the next kept record of the group goes
   for (uint64_t i = i0; i < i1; ++i) {
     const uint64_t len = out_len[i];
     if (!len) continue;
-    uint8_t* dst = out + out_off[i];
+    uint8_t* dst = out + at;
+    at += len;
     const uint64_t j0 = 4 * i, j1 = (j0 + 4 < lines) ? j0 + 4 : lines;
     const uint64_t r0 = line_off[j0], r1 = line_off[j1];
-    if (r1 - r0 == len && r1 <= n) { wave_copy(dst, base + r0, len, lane); continue; }
+    if (r1 - r0 == len && r1 <= n) { wave_copy<NT>(dst, base + r0, len, lane, 16u); continue; }
     uint64_t w = 0;
     for (uint64_t j = j0; j < j1; ++j) {
       uint64_t s, e;
@@ -397,20 +498,22 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   *out_bytes = 0;
   uint64_t lines = 0;
   // SCFQ_DEDUP_TRACE=1: host-clock stage times on stderr (each mark synchronises the stream: diagnostic only)
-  static const bool trace = std::getenv("SCFQ_DEDUP_TRACE") != nullptr;
+  // (=2: the same marks WITHOUT the synchronisation: what the host spends enqueueing each stage)
+  static const int trace = [] { const char* e = std::getenv("SCFQ_DEDUP_TRACE"); return e ? std::max(1, std::atoi(e)) : 0; }();
   auto t_last = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
     if (!trace) return;
-    (void)hipStreamSynchronize(stream);
+    if (trace == 1) (void)hipStreamSynchronize(stream);
     const auto now = std::chrono::steady_clock::now();
     std::fprintf(stderr, "scfq dedup: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
+  auto mark2 = [&](const char* what) { if (trace == 2) mark(what); };      // (enqueue-only marks)
   // the line index in ONE pass (count and offsets together): its size is guessed first — a FASTQ line is rarely shorter
   // than 24 bytes on average — and only a wrong guess costs a second pass with the exact size
   int rc = SCFQ_OK;
   uint32_t index_flags = 1;
-  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, out_off, counters, tmp, hdr, cand;
+  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, group_len, group_off, counters, tmp, hdr, cand;
   {
     uint64_t cap = n / 24 + 1024;
     if ((rc = line_off.alloc(cap * 8, stream))) return rc;
@@ -433,22 +536,23 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   if (n_hdr >= (1ull << 31)) { std::snprintf(g_derr, sizeof g_derr, "more than 2^31 records in one input"); return SCFQ_EARG; }
   if (n_hdr == 0) return SCFQ_OK;
   mark("line index (K5, one pass)");
+  const uint64_t n_groups = (n_hdr + kGatherGroup - 1) / kGatherGroup;
   if ((rc = keys.alloc(n_hdr * 8, stream)) || (rc = keys2.alloc(n_hdr * 8, stream)) || (rc = idx.alloc(n_hdr * 4, stream)) ||
-      (rc = idx2.alloc(n_hdr * 4, stream)) || (rc = dup.alloc(n_hdr, stream)) || (rc = out_len.alloc((n_hdr + 1) * 8, stream)) ||
-      (rc = out_off.alloc((n_hdr + 1) * 8, stream)) || (rc = counters.alloc(32, stream)) || (rc = hdr.alloc(n_hdr * 8, stream)) ||
+      (rc = idx2.alloc(n_hdr * 4, stream)) || (rc = dup.alloc(n_hdr, stream)) || (rc = out_len.alloc(n_hdr * 8, stream)) ||
+      (rc = group_len.alloc((n_groups + 1) * 8, stream)) || (rc = group_off.alloc((n_groups + 1) * 8, stream)) || (rc = counters.alloc(32, stream)) || (rc = hdr.alloc(n_hdr * 8, stream)) ||
       (rc = cand.alloc(n_hdr * 4, stream)))
     return rc;
   mark("alloc scratch");
   DCHK(hipMemsetAsync(counters.p, 0, 32, stream));
   const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
-  // 40 bits of hash: the radix sort makes 5 passes over the (key, record) pairs instead of 8, and the exact compare behind the
-  // sort makes collisions (n^2 / 2^41 pairs: ~350 among 28 M records) a matter of time, never of correctness.  (32 bits in
-  // 32-bit keys — SCFQ_DEDUP_HASH_BITS=32 — sort in 0.93 instead of 1.29 ms for 28 M records, but their 88 K colliding pairs
-  // cost the compare kernel 0.48 ms more: measured, not the default.)
+  // 32 bits of hash in 32-bit keys: the radix sort makes 4 passes over 8-byte (key, record) pairs — 0.93 ms for 28 M records against
+  // 1.29 ms for 40 bits in 64-bit keys — and the exact compare behind the sort makes collisions (n^2 / 2^33 pairs: 88 K among 28 M
+  // records) a matter of time, never of correctness.  (r2 - r3 kept 40 bits: the colliding pairs cost the compare kernel 0.48 ms —
+  // which was the atomic each of them did on one statistics counter, not the compares; r4 sums the statistics per block.)
   static const int hash_bits_env = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); return e ? std::min(64, std::max(1, std::atoi(e))) : 0; }();
-  const uint32_t hash_bits = hash_bits_env ? (uint32_t)hash_bits_env : 40u;
+  const uint32_t hash_bits = hash_bits_env ? (uint32_t)hash_bits_env : 32u;
   size_t scan_bytes = 0;
-  DCHK(rocprim::exclusive_scan(nullptr, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_hdr + 1),
+  DCHK(rocprim::exclusive_scan(nullptr, scan_bytes, group_len.as<uint64_t>(), group_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_groups + 1),
                                rocprim::plus<uint64_t>(), stream));
   uint32_t* n_cand = reinterpret_cast<uint32_t*>(counters.as<unsigned long long>() + 2);
   auto hash_sort_mark = [&](auto key_tag) -> int {
@@ -467,31 +571,37 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
     DCHK(hipGetLastError());
     // (the launch covers the worst case; blocks past the candidate count leave at once)
     hipLaunchKernelGGL(dd_mark_duplicates<K>, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), hdr.as<uint64_t>(),
-                       keys2.as<K>(), idx2.as<uint32_t>(), cand.as<uint32_t>(), n_cand, dup.as<uint8_t>(),
-                       counters.as<unsigned long long>(), has_cr);
+                       keys2.as<K>(), idx2.as<uint32_t>(), cand.as<uint32_t>(), n_cand, dup.as<uint8_t>(), has_cr);
+    DCHK(hipGetLastError());
+    hipLaunchKernelGGL(dd_count_marks, dim3(512), dim3(256), 0, stream, dup.as<uint8_t>(), n_hdr, cand.as<uint32_t>(), n_cand, counters.as<unsigned long long>());
     DCHK(hipGetLastError());
     return SCFQ_OK;
   };
   if ((rc = hash_bits <= 32 ? hash_sort_mark(uint32_t{}) : hash_sort_mark(uint64_t{}))) return rc;
   mark("mark duplicates");
   hipLaunchKernelGGL(dd_record_lengths, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
-                     dup.as<uint8_t>(), out_len.as<uint64_t>(), has_cr);
+                     dup.as<uint8_t>(), out_len.as<uint64_t>(), group_len.as<uint64_t>(), has_cr);
   DCHK(hipGetLastError());
-  DCHK(hipMemsetAsync(out_len.as<uint64_t>() + n_hdr, 0, 8, stream));       // the scan's last output is the total
-  DCHK(rocprim::exclusive_scan(tmp.p, scan_bytes, out_len.as<uint64_t>(), out_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_hdr + 1),
+  DCHK(hipMemsetAsync(group_len.as<uint64_t>() + n_groups, 0, 8, stream));       // the scan's last output is the total
+  DCHK(rocprim::exclusive_scan(tmp.p, scan_bytes, group_len.as<uint64_t>(), group_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_groups + 1),
                                rocprim::plus<uint64_t>(), stream));
+  mark2("lengths + scan enqueued");
   uint64_t h[3] = {0, 0, 0};
-  const uint64_t n_groups = (n_hdr + kGatherGroup - 1) / kGatherGroup;
+  static const bool gather_nt = [] { const char* e = std::getenv("SCFQ_DEDUP_NT"); return e ? std::atoi(e) != 0 : false; }();
+  static const uint32_t dst_align = [] { const char* e = std::getenv("SCFQ_DEDUP_DST_ALIGN"); const int v = e ? std::atoi(e) : 128; return (uint32_t)(v == 16 || v == 64 ? v : 128); }();
+  const auto gather_kernel = gather_nt ? dd_gather<true> : dd_gather<false>;
   // a caller's buffer that holds the whole input holds any result: the gather goes out behind the scan at once, and the one
   // wait of the call is the one at the end (otherwise the size has to come back first — the result is allocated to fit)
   const bool gather_first = !sized_only && user_out && user_cap >= n;
   if (gather_first) {
-    hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
-                       out_off.as<uint64_t>(), out_len.as<uint64_t>(), user_out);
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                       group_off.as<uint64_t>(), out_len.as<uint64_t>(), user_out, dst_align);
     DCHK(hipGetLastError());
   }
-  DCHK(hipMemcpyAsync(&h[0], out_off.as<uint64_t>() + n_hdr, 8, hipMemcpyDeviceToHost, stream));
+  mark2("gather enqueued");
+  DCHK(hipMemcpyAsync(&h[0], group_off.as<uint64_t>() + n_groups, 8, hipMemcpyDeviceToHost, stream));
   DCHK(hipMemcpyAsync(&h[1], counters.p, 16, hipMemcpyDeviceToHost, stream));
+  mark2("readbacks enqueued");
   DCHK(hipStreamSynchronize(stream));
   mark(gather_first ? "lengths + scan + gather + readback" : "lengths + scan + readback");
   st->duplicates = h[1];
@@ -509,8 +619,8 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   } else if (user_cap < h[0]) {
     return SCFQ_EARG;
   }
-  hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
-                     out_off.as<uint64_t>(), out_len.as<uint64_t>(), o);
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                     group_off.as<uint64_t>(), out_len.as<uint64_t>(), o, dst_align);
   DCHK(hipGetLastError());
   DCHK(hipStreamSynchronize(stream));
   mark("gather");
@@ -538,6 +648,8 @@ int write_all(int fd, const uint8_t* p, uint64_t n) {
 // called by scfq_shutdown(): the pools go back to the driver
 extern "C" void scfq_dedup_release_pools(void) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto& kv : g_idle_streams) { if (hipSetDevice(kv.first) == hipSuccess) for (hipStream_t st : kv.second) (void)hipStreamDestroy(st); }
+  g_idle_streams.clear();
   for (auto& kv : g_pools) { if (hipSetDevice(kv.first) == hipSuccess) (void)hipMemPoolDestroy(kv.second); }
   g_pools.clear();
 }
@@ -553,9 +665,9 @@ int scfq_dedup_buffer(const void* ptr, uint64_t n, int is_device, void* out, uin
   std::memset(st, 0, sizeof(*st));
   st->struct_size = keep_size;
   *out_bytes = 0;
-  hipStream_t stream = nullptr;
-  DCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+  StreamLease lease;
+  { const int lrc = lease.acquire(); if (lrc) return lrc; }
+  const hipStream_t stream = lease.s;
   DevBuf staged;
   const uint8_t* d_in = static_cast<const uint8_t*>(ptr);
   if (is_device || (out && out_is_device)) { int rc = wait_for_caller(stream); if (rc) return rc; }
@@ -591,9 +703,9 @@ int scfq_dedup_file(const char* path, const scfq_opts* opts, int out_fd, scfq_de
   int rc = scfq_stage_file(path, opts, &d_in, &n);      // whole (inflated) input into HBM
   if (rc) return rc;
   struct InGuard { void* p; ~InGuard() { if (p) (void)hipFree(p); } } ig{d_in};
-  hipStream_t stream = nullptr;
-  DCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+  StreamLease lease;
+  { const int lrc = lease.acquire(); if (lrc) return lrc; }
+  const hipStream_t stream = lease.s;
   uint8_t* d_out = nullptr;
   uint64_t nb = 0;
   rc = dedup_device(static_cast<const uint8_t*>(d_in), n, nullptr, 0, /*sized_only=*/out_fd < 0, &d_out, &nb, st, stream);

@@ -108,7 +108,7 @@ def test_device_resident_and_generator(gpu, scfq, oracle):
 
 def test_hash_collisions_are_resolved_exactly(gpu, scfq, oracle):
     """SCFQ_DEDUP_HASH_BITS truncates the header hash (test hook): every equal-hash run then mixes many different IDs and
-    only the exact compare separates them.  4 bits take the 32-bit key path, 40 (the default) and 64 the 64-bit one: same
+    only the exact compare separates them.  4 bits and 32 (the default) take the 32-bit key path, 40 and 64 the 64-bit one: same
     bytes, same counts."""
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -128,7 +128,7 @@ def test_hash_collisions_are_resolved_exactly(gpu, scfq, oracle):
         "assert (st.hash_collisions > 1000) == (os.environ['SCFQ_DEDUP_HASH_BITS'] == '4'), st.hash_collisions\n"
         "print('collisions ok', st.hash_collisions)\n"
     ) % (os.path.join(os.path.dirname(HERE), "seq-collection_amd", "pyhost"), HERE)
-    for bits in ("4", "40", "64"):
+    for bits in ("4", "32", "40", "64"):
         env = dict(os.environ, SCFQ_DEDUP_HASH_BITS=bits)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         assert r.returncode == 0 and "collisions ok" in r.stdout, (bits, r.stdout + r.stderr)
