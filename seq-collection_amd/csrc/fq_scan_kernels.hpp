@@ -1572,7 +1572,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_masks(IndexMaskA
   }
   const uint32_t total = wave_sum(cnt);
   if (lane == 0) a.counts[range] = total;
-  if (want_cr && __builtin_amdgcn_ballot_w64(cr_seen != 0) != 0 && lane == 0) atomicOr(a.flags_out, 1u);
+  // (a look before the atomic: on a "\r\n" input EVERY wave would otherwise queue one on the same word)
+  if (want_cr && __builtin_amdgcn_ballot_w64(cr_seen != 0) != 0 && lane == 0 &&
+      !(__hip_atomic_load(a.flags_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u))
+    atomicOr(a.flags_out, 1u);
 }
 
 struct IndexExpandArgs {

@@ -148,34 +148,40 @@ __global__ __launch_bounds__(256) void k_write(int kind, uint64_t seed, uint64_t
   __shared__ char hdr[4][kMaxHeader];
   __shared__ RecordShape shp[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ uint32_t tal[4][3];
   const uint64_t i = (uint64_t)blockIdx.x * 4 + w;
-  if (i >= records) return;
-  const uint64_t rec = first + i;
-  if (lane == 0) shp[w] = header(kind, seed, rec, hdr[w]);
-  __builtin_amdgcn_wave_barrier();
-  __threadfence_block();
-  const RecordShape s = shp[w];
-  uint8_t* out = dst + offset[i];
-  for (uint32_t k = lane; k < s.header_len; k += 64) out[k] = (uint8_t)hdr[w][k];
-  uint8_t* seq = out + s.header_len;
-  uint8_t* qual = seq + s.read_len + 3;
-  uint32_t gc = 0, nn = 0;
-  for (uint32_t k = lane; k < s.read_len; k += 64) {
-    const char b = base_at(kind, seed, rec, k);
-    seq[k] = (uint8_t)b;
-    gc += (b == 'G' || b == 'C');
-    nn += (b == 'N');
-    qual[k] = (uint8_t)qual_at(kind, seed, rec, k);
+  if (lane < 3) tal[w][lane] = 0;
+  if (i < records) {      // (wave-uniform; every wave of the block reaches the barrier below)
+    const uint64_t rec = first + i;
+    if (lane == 0) shp[w] = header(kind, seed, rec, hdr[w]);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const RecordShape s = shp[w];
+    uint8_t* out = dst + offset[i];
+    for (uint32_t k = lane; k < s.header_len; k += 64) out[k] = (uint8_t)hdr[w][k];
+    uint8_t* seq = out + s.header_len;
+    uint8_t* qual = seq + s.read_len + 3;
+    uint32_t gc = 0, nn = 0;
+    for (uint32_t k = lane; k < s.read_len; k += 64) {
+      const char b = base_at(kind, seed, rec, k);
+      seq[k] = (uint8_t)b;
+      gc += (b == 'G' || b == 'C');
+      nn += (b == 'N');
+      qual[k] = (uint8_t)qual_at(kind, seed, rec, k);
+    }
+    if (lane == 0) {
+      seq[s.read_len] = '\n'; seq[s.read_len + 1] = '+'; seq[s.read_len + 2] = '\n';
+      qual[s.read_len] = '\n';
+    }
+    for (int off = 32; off; off >>= 1) { gc += __shfl_down(gc, off); nn += __shfl_down(nn, off); }
+    // the tallies of the block's four records through LDS, then ONE atomic per counter and block (an atomic per record and counter
+    // queued 1.7 G of them on three words for the 200 GB stream)
+    if (lane == 0) { tal[w][0] = gc; tal[w][1] = nn; tal[w][2] = s.read_len; }
   }
-  if (lane == 0) {
-    seq[s.read_len] = '\n'; seq[s.read_len + 1] = '+'; seq[s.read_len + 2] = '\n';
-    qual[s.read_len] = '\n';
-  }
-  for (int off = 32; off; off >>= 1) { gc += __shfl_down(gc, off); nn += __shfl_down(nn, off); }
-  if (lane == 0) {
-    atomicAdd(&tally[0], (unsigned long long)gc);
-    atomicAdd(&tally[1], (unsigned long long)nn);
-    atomicAdd(&tally[2], (unsigned long long)s.read_len);
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const unsigned long long t = (unsigned long long)tal[0][threadIdx.x] + tal[1][threadIdx.x] + tal[2][threadIdx.x] + tal[3][threadIdx.x];
+    if (t) atomicAdd(&tally[threadIdx.x], t);
   }
 }
 
