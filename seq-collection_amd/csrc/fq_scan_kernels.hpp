@@ -733,7 +733,7 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   const uint4 q0v = p[0], q1v = p[1], q2v = p[2], q3v = p[3];
   uint32_t d[16] = {q0v.x, q0v.y, q0v.z, q0v.w, q1v.x, q1v.y, q1v.z, q1v.w,
                     q2v.x, q2v.y, q2v.z, q2v.w, q3v.x, q3v.y, q3v.z, q3v.w};
-  uint64_t WNL, WGC, WNN, WAT = 0, WPL = 0;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N' / '@' / '+'
+  uint64_t WNL, WGC, WNN;   // inverted masks: bit set = byte is NOT '\n' / G|C / 'N'
   uint32_t xa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xb[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bit planes of the two 32-byte groups (live past the classifier for HIST == 2 only)
   if (SCFQ_ABLATE == 1 || SCFQ_ABLATE == 3) {   // timing-only: masks are a cheap function of the data
     WNL = ~((uint64_t)(d[0] & d[5] & 0x01010101u) | ((uint64_t)(d[9] & d[13] & 0x00010100u) << 32));
@@ -741,12 +741,12 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
     WNN = ((uint64_t)d[3] << 32) | d[4] | d[6] | d[7] | d[8] | d[10] | d[11] | d[12] | d[14] | d[15];
   } else {
     uint32_t a0, a1, a2, a3 = 0, a4 = 0, b0, b1, b2, b3 = 0, b4 = 0;
-    masks32_planes_x<STRUCT>(d, pc, xa, a0, a1, a2, a3, a4);
-    masks32_planes_x<STRUCT>(d + 8, pc, xb, b0, b1, b2, b3, b4);
+    // (K4 takes no '@' / '+' masks from the classifier any more: it looks at the ONE byte behind each newline, below)
+    masks32_planes_x<false>(d, pc, xa, a0, a1, a2, a3, a4);
+    masks32_planes_x<false>(d + 8, pc, xb, b0, b1, b2, b3, b4);
     WNL = (uint64_t)a0 | ((uint64_t)b0 << 32);
     WGC = (uint64_t)a1 | ((uint64_t)b1 << 32);
     WNN = (uint64_t)a2 | ((uint64_t)b2 << 32);
-    if (STRUCT) { WAT = (uint64_t)a3 | ((uint64_t)b3 << 32); WPL = (uint64_t)a4 | ((uint64_t)b4 << 32); }
   }
   const uint64_t NL = ~WNL;
 
@@ -764,13 +764,6 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
     }
   }
 
-  // K4: line-start bytes = the byte after a '\n' (bit 0: previous lane's / previous tile's last byte)
-  uint64_t LS = 0;
-  if (STRUCT) {
-    const uint32_t carry0 = (st.prev_last == '\n' || st.prev_last == -1) ? 1u : 0u;
-    LS = (NL << 1) | wave_shr1((uint32_t)(NL >> 63), carry0);
-  }
-
   // first segment: everything below the first newline (the whole lane when there is none)
   const uint64_t xm1 = NL - 1;
   const uint64_t below = WNL & xm1;
@@ -781,12 +774,19 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
   uint32_t t_gc = st.p_gc + (s_gc << sh0);
   uint32_t t_nn = st.p_nn + (s_nn << sh0);
   uint32_t t_crlf = st.p_crlf;
-  uint32_t s_fat = 0, s_fpl = 0, t_fat = 0, t_fpl = 0;
+  // K4: a line is tested by its FIRST byte, and a line starts behind a newline: the byte behind each newline of the lane is read
+  // from LDS next to the byte in front of it (the "\r\n" test) and compared — r3 built '@' and '+' masks of all 64 bytes with the
+  // classifier (16 v_bitop3), a line-start mask and two 64-bit popcounts per segment for it: ~58 vector instructions per tile
+  // against ~25 here.  Every line start is counted ONCE, by the tile that holds its first byte: the line behind a newline in the
+  // tile's last byte belongs to the next tile (edge tiles, process_tile, count by the same rule), whose first byte it is.
+  uint32_t t_fat = 0, t_fpl = 0;
   if (STRUCT) {
-    // a line start may be the newline itself (empty line): its segment includes the newline bit
-    const uint64_t ls0 = LS & (NL ^ xm1);
-    s_fat = popc64(ls0 & ~WAT); s_fpl = popc64(ls0 & ~WPL);
-    t_fat = st.p_fat + (s_fat << sh0); t_fpl = st.p_fpl + (s_fpl << sh0);
+    t_fat = st.p_fat; t_fpl = st.p_fpl;
+    if (st.prev_last == '\n' || st.prev_last == -1) {       // wave-uniform: this tile's first byte starts a line (class: lane 0's)
+      const uint32_t b0 = slot[0];
+      t_fat += ((lane == 0 && b0 == '@') ? 1u : 0u) << sh0;
+      t_fpl += ((lane == 0 && b0 == '+') ? 1u : 0u) << sh0;
+    }
   }
 
   if (total != 0 && SCFQ_ABLATE < 2) {   // wave-uniform: some lane of this tile holds a newline
@@ -798,10 +798,20 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
     const bool has2 = (x1 != 0);
     // '\r' directly before a newline is not part of the line: both look-behind bytes are requested from LDS
     // before anything consumes them (newline-free lanes read bank-spread dummies)
+    const int q1 = (int)popc64(below1);                         // index of the lane's second newline (64: none)
     const int idx0 = lane_base + (int)s_len - 1;
-    const int idx1 = lane_base + (int)popc64(below1) - 1;      // >= 0: a lane's second newline is never at bit 0
+    const int idx1 = lane_base + q1 - 1;                        // >= 0: a lane's second newline is never at bit 0
     int pb0 = slot[has1 ? (idx0 < 0 ? 0 : idx0) : lane * 4];
     const int pb1 = slot[has2 ? idx1 : lane * 4 + 256];
+    int na0 = 0, na1 = 0;
+    bool v0 = false, v1 = false;
+    if (STRUCT) {
+      // the bytes BEHIND the two newlines (the next lane's first byte when the newline is this lane's last; nothing when it is the tile's)
+      v0 = has1 && idx0 + 2 < kTile;
+      v1 = has2 && idx1 + 2 < kTile;
+      na0 = slot[v0 ? idx0 + 2 : lane * 4 + 512];
+      na1 = slot[v1 ? idx1 + 2 : lane * 4 + 768];
+    }
     if (idx0 < 0) pb0 = st.prev_last;
     t_crlf += ((has1 && pb0 == '\r') ? 1u : 0u) << sh0;
     uint32_t sh = (sh0 + 8u) & 31u;
@@ -813,11 +823,10 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       t_len += m_len << sh; t_gc += m_gc << sh; t_nn += m_nn << sh;
       s_len += m_len; s_gc += m_gc; s_nn += m_nn;
       if (STRUCT) {
-        uint64_t lsm = LS & (x1 ^ x1m1) & ~upto0;  // the segment plus its terminating newline
-        lsm = has2 ? lsm : 0;
-        const uint32_t m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
-        t_fat += m_fat << sh; t_fpl += m_fpl << sh;
-        s_fat += m_fat; s_fpl += m_fpl;
+        // the line behind the first newline has the class of this segment, the one behind the second the class after it
+        const uint32_t sh2 = (sh + 8u) & 31u;
+        t_fat += ((v0 && na0 == '@') ? 1u : 0u) << sh; t_fpl += ((v0 && na0 == '+') ? 1u : 0u) << sh;
+        t_fat += ((v1 && na1 == '@') ? 1u : 0u) << sh2; t_fpl += ((v1 && na1 == '+') ? 1u : 0u) << sh2;
       }
       t_crlf += ((has2 && pb1 == '\r') ? 1u : 0u) << sh;
     }
@@ -836,15 +845,14 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
       const uint32_t m_len = popc64(seg), m_gc = popc64(seg & ~WGC), m_nn = popc64(seg & ~WNN);
       t_len += m_len << sh; t_gc += m_gc << sh; t_nn += m_nn << sh;
       s_len += m_len; s_gc += m_gc; s_nn += m_nn;
-      if (STRUCT) {
-        uint64_t lsm = LS & (x2 ^ x2m1) & ~upto1;
-        lsm = has3 ? lsm : 0;
-        const uint32_t m_fat = popc64(lsm & ~WAT), m_fpl = popc64(lsm & ~WPL);
-        t_fat += m_fat << sh; t_fpl += m_fpl << sh;
-        s_fat += m_fat; s_fpl += m_fpl;
-      }
       const int idx = lane_base + (int)popc64(below2) - 1;
       const int pb = slot[has3 ? idx : lane * 4];
+      if (STRUCT) {
+        const bool v = has3 && idx + 2 < kTile;
+        const int na = slot[v ? idx + 2 : lane * 4 + 512];
+        const uint32_t shn = (sh + 8u) & 31u;
+        t_fat += ((v && na == '@') ? 1u : 0u) << shn; t_fpl += ((v && na == '+') ? 1u : 0u) << shn;
+      }
       t_crlf += ((has3 && pb == '\r') ? 1u : 0u) << sh;
       xc = x2; xcm1 = x2m1;
     }
@@ -854,10 +862,6 @@ __device__ __forceinline__ void process_tile_fast(const uint8_t* slot, int lane,
     t_len += (64u - cnt - s_len) << shl;
     t_gc += (64u - popc64(WGC) - s_gc) << shl;
     t_nn += (64u - popc64(WNN) - s_nn) << shl;
-    if (STRUCT) {
-      t_fat += (popc64(LS & ~WAT) - s_fat) << shl;
-      t_fpl += (popc64(LS & ~WPL) - s_fpl) << shl;
-    }
   }
 
   st.p_len = t_len; st.p_gc = t_gc; st.p_nn = t_nn; st.p_crlf = t_crlf;
