@@ -11,4 +11,4 @@ make -C $R/oracle asan >/dev/null
 ASAN=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cd $R
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 SCFQ_LIB_OVERRIDE=/tmp/libsc_fqcount_hip_asan.so \
-  python -m pytest tests/test_ingest_sources.py tests/test_inflate_host.py tests/test_meta_host.py tests/test_dedup_oracle.py tests/test_property_host.py tests/test_abi.py -q -m "not gpu"
+  python -m pytest tests/test_ingest_sources.py tests/test_inflate_host.py tests/test_meta_host.py tests/test_dedup_oracle.py tests/test_property_host.py tests/test_abi.py tests/test_gz_shard_rules_host.py tests/test_comm_host.py -q -m "not gpu"
