@@ -618,13 +618,15 @@ __device__ __forceinline__ void hist_tile_q(uint32_t* hq, const uint8_t* slot, i
 // set switches to hist_tile_q (the dword loop) for its remaining tiles.
 #include "hot_dispatch.inc"     // SCFQ_HOT_STANZAS: 256 stanzas of SCFQ_HOT_STANZA_BYTES, generated by scripts/gen_hot_dispatch.py
 
-// bytes equal to v (wave-uniform, 0..255) inside the masks (Ma: positions 0..31 of the lane, Mb: 32..63).
+// Bytes equal to v (wave-uniform, 0..127) inside the segment masks.  pa0 / pa1 (positions 0..31 of the lane) and pb0 / pb1 (32..63) are
+// the segment mask ANDed with "plane 7 clear, plane 6 clear / set" — made once per tile, shared by every value (r4; r2 - r3 matched
+// planes 6 and 7 and the mask per value: 8 v_bitop3 per value where this form has 6).
 // One computed jump into the stanza of v (six v_bitop3 with v's truth tables as immediates), one jump back: a compare
 // chain over the bits of v (what a C++ switch becomes here) cost ~30 scalar instructions and ~8 branches per 3-plane
 // group and saturated the CU's scalar unit.  s[90:91] hold the target address.
-__device__ __forceinline__ void hot_match(const uint32_t* xa, const uint32_t* xb, uint32_t Ma, uint32_t Mb, uint32_t v,
-                                          uint32_t& ma, uint32_t& mb) {
-  uint32_t t0, t1, t2, t3, st;
+__device__ __forceinline__ void hot_match(const uint32_t* xa, const uint32_t* xb, uint32_t pa0, uint32_t pa1, uint32_t pb0, uint32_t pb1,
+                                          uint32_t v, uint32_t& ma, uint32_t& mb) {
+  uint32_t t0, t1, st;
   asm volatile(
       "s_mul_i32 %[st], %[v], %[stanza]\n\t"
       "s_getpc_b64 s[90:91]\n"
@@ -641,13 +643,11 @@ __device__ __forceinline__ void hot_match(const uint32_t* xa, const uint32_t* xb
       // branch, padding) this stops the build instead of jumping into the middle of an instruction
       ".if (.Lhm_end%= - .Lhm_tab%=) != 256 * %c[stanza]\n\t"
       ".error \"hot_match: the 256 stanzas of hot_dispatch.inc are not SCFQ_HOT_STANZA_BYTES each\"\n\t"
-      ".endif\n\t"
-      "v_bitop3_b32 %[ma], %[ma], %[t0], %[t2] bitop3:0x80\n\t"
-      "v_bitop3_b32 %[mb], %[mb], %[t1], %[t3] bitop3:0x80"
-      : [ma] "=&v"(ma), [mb] "=&v"(mb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [st] "=&s"(st)
+      ".endif"
+      : [ma] "=&v"(ma), [mb] "=&v"(mb), [t0] "=&v"(t0), [t1] "=&v"(t1), [st] "=&s"(st)
       : [v] "s"(v), [stanza] "n"(SCFQ_HOT_STANZA_BYTES), [a0] "v"(xa[0]), [a1] "v"(xa[1]), [a2] "v"(xa[2]), [a3] "v"(xa[3]),
-        [a4] "v"(xa[4]), [a5] "v"(xa[5]), [a6] "v"(xa[6]), [a7] "v"(xa[7]), [b0] "v"(xb[0]), [b1] "v"(xb[1]), [b2] "v"(xb[2]),
-        [b3] "v"(xb[3]), [b4] "v"(xb[4]), [b5] "v"(xb[5]), [b6] "v"(xb[6]), [b7] "v"(xb[7]), [Ma] "v"(Ma), [Mb] "v"(Mb)
+        [a4] "v"(xa[4]), [a5] "v"(xa[5]), [b0] "v"(xb[0]), [b1] "v"(xb[1]), [b2] "v"(xb[2]),
+        [b3] "v"(xb[3]), [b4] "v"(xb[4]), [b5] "v"(xb[5]), [pa0] "v"(pa0), [pa1] "v"(pa1), [pb0] "v"(pb0), [pb1] "v"(pb1)
       : "s90", "s91", "scc");
 }
 
@@ -664,48 +664,73 @@ __device__ __forceinline__ void hist_tile_planes(const uint32_t* xa, const uint3
   // (r4, measured: the same selection with masks instead of ?: — 12 instructions where the compiler's nested exec-mask regions are ~25 —
   // ran no faster, 0.664–0.671 against 0.674; and the dword loop without its pivot ran 2.7 % SLOWER on long reads: profiles/r04/hist_ab.txt)
   const uint64_t M = (i0 == 0) ? seg0 : (i0 == 1) ? seg1 : (i0 == 2) ? seg2 : 0ull;
-  uint32_t ra = (uint32_t)M, rb = (uint32_t)(M >> 32);   // quality bytes not yet accounted for
-  uint64_t have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
-  if (have == 0) return;                                 // long reads: most tiles hold no quality byte at all
-  uint32_t k = 0;
-  for (;;) {
-    const uint32_t n_hot = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
-    // wave-uniform loop, one dispatch per hot value; the values sit in a 64-bit scalar shift register, the counts go to
-    // 8-bit fields of two registers (values 0..3 / 4..7) with one shift-add each
-    uint64_t hv = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0])) >> (8u * k);
-    uint32_t p0 = st.p_hot[0], p1 = st.p_hot[1];
+  const uint32_t Ma = (uint32_t)M, Mb = (uint32_t)(M >> 32);
+  if (__builtin_amdgcn_ballot_w64((Ma | Mb) != 0) == 0) return;      // long reads: most tiles hold no quality byte at all
+  // the segment mask with planes 7 and 6 folded in, for the values 0..63 and 64..127 (truth-table index: mask << 2 | plane 7 << 1 | plane 6)
+  const uint32_t pa0 = __builtin_amdgcn_bitop3_b32(Ma, xa[7], xa[6], 0x10), pa1 = __builtin_amdgcn_bitop3_b32(Ma, xa[7], xa[6], 0x20);
+  const uint32_t pb0 = __builtin_amdgcn_bitop3_b32(Mb, xb[7], xb[6], 0x10), pb1 = __builtin_amdgcn_bitop3_b32(Mb, xb[7], xb[6], 0x20);
+  const uint32_t total = (uint32_t)__builtin_popcount(Ma) + (uint32_t)__builtin_popcount(Mb);
+  // ---- the common pass: every hot value counted inside M, no remainder kept — whether the hot set covers the segment is told by the
+  // COUNTS (hot values are distinct, a byte matches at most one: the sum of the counts is the number of covered bytes).  One dispatch
+  // per value (wave-uniform loop; the values sit in a 64-bit scalar shift register), the counts go to 8-bit fields of two registers
+  // (values 0..3 / 4..7) with one shift-add each.
+  uint32_t n_hot = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.n_hot);
+  {
+    uint64_t hv = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0]);
+    uint32_t p0 = st.p_hot[0], p1 = st.p_hot[1], covered = 0, k = 0;
     for (; k < n_hot && k < 4u; ++k, hv >>= 8) {
       uint32_t ma, mb;
-      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);    // hot values are distinct: matching inside the rest is exact
+      hot_match(xa, xb, pa0, pa1, pb0, pb1, (uint32_t)hv & 0xFFu, ma, mb);
       const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
       p0 = (c << (8u * k)) + p0;
-      ra &= ~ma;
-      rb &= ~mb;
+      covered += c;
     }
     for (; k < n_hot; ++k, hv >>= 8) {
       uint32_t ma, mb;
-      hot_match(xa, xb, ra, rb, (uint32_t)hv & 0xFFu, ma, mb);
+      hot_match(xa, xb, pa0, pa1, pb0, pb1, (uint32_t)hv & 0xFFu, ma, mb);
       const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
       p1 = (c << (8u * (k - 4u))) + p1;
-      ra &= ~ma;
-      rb &= ~mb;
+      covered += c;
     }
     st.p_hot[0] = p0;
     st.p_hot[1] = p1;
-    have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
-    if (have == 0 || n_hot >= (uint32_t)kHot) break;
-    // a byte outside the hot set while the set has room: its value joins (the loop above then counts it)
+    if (__builtin_amdgcn_ballot_w64(covered != total) == 0) return;      // (nearly every tile of a file with binned qualities)
+  }
+  // ---- a tile with bytes outside the hot set (the first tiles of a range; a file with many quality values): the remainder, by
+  // matching the hot values once more — their counts are in already
+  uint32_t ra = Ma, rb = Mb;
+  {
+    uint64_t hv = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[1]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hotp[0]);
+    for (uint32_t k = 0; k < n_hot; ++k, hv >>= 8) {
+      uint32_t ma, mb;
+      hot_match(xa, xb, pa0, pa1, pb0, pb1, (uint32_t)hv & 0xFFu, ma, mb);
+      ra &= ~ma;
+      rb &= ~mb;
+    }
+  }
+  uint64_t have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
+  while (have != 0 && n_hot < (uint32_t)kHot) {
+    // a byte outside the hot set while the set has room: its value joins and is counted at once.  (A value >= 128 cannot be matched by
+    // this form — FASTQ text is ASCII — and goes the way of an overflowing set, below.)
     const int L = __builtin_ctzll(have);
     const uint32_t la = (uint32_t)__builtin_amdgcn_readlane((int)ra, L), lb = (uint32_t)__builtin_amdgcn_readlane((int)rb, L);
     const uint32_t kbit = la ? (uint32_t)__builtin_ctz(la) : 32u + (uint32_t)__builtin_ctz(lb);
     const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)slot[L * 64 + kbit]);
+    if (v >= 128u) break;
     if (n_hot < 4u) st.hotp[0] |= v << (n_hot * 8u); else st.hotp[1] |= v << ((n_hot - 4u) * 8u);
-    st.n_hot = n_hot + 1u;
+    uint32_t ma, mb;
+    hot_match(xa, xb, pa0, pa1, pb0, pb1, v, ma, mb);
+    const uint32_t c = (uint32_t)__builtin_popcount(ma) + (uint32_t)__builtin_popcount(mb);
+    if (n_hot < 4u) st.p_hot[0] += c << (8u * n_hot); else st.p_hot[1] += c << (8u * (n_hot - 4u));
+    ra &= ~ma;
+    rb &= ~mb;
+    n_hot += 1u;
+    st.n_hot = n_hot;
+    have = __builtin_amdgcn_ballot_w64((ra | rb) != 0);
   }
   if (have == 0) return;
-  // the hot set is full: the rest is counted in the workgroup's LDS histogram byte by byte; a range that keeps coming
-  // here has a large alphabet (unbinned qualities) and is better served by the dword loop of hist_tile_q
+  // the hot set is full (or the byte is not ASCII): the rest is counted in the workgroup's LDS histogram byte by byte; a range that
+  // keeps coming here has a large alphabet (unbinned qualities) and is better served by the dword loop of hist_tile_q
   uint64_t r = (uint64_t)ra | ((uint64_t)rb << 32);
   const uint8_t* lane_bytes = slot + lane * 64;
   bool q_high = false;
