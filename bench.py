@@ -11,7 +11,8 @@ librccl; the combine is ordered / non-commutative, so a sum-allreduce of counter
 -> "scaling": "weak".  torch.distributed only provides the contract's barrier and the max over ranks (control plane: gloo by
 default, so that the library's RCCL communicator is the only one a rank creates).  At N=1 the line also carries a non-headline
 `ingest` object: a gzip member and a BGZF file of the same stream, written here, counted by a fresh `sc fq-count` process (cold)
-and by the second call in this process (warm) — BASELINE configs[3] end to end, compressed bytes over PCIe, inflate on the device.
+and by the second call in this process (warm) — BASELINE configs[3] end to end, compressed bytes over PCIe, inflate on the device —
+and a non-headline `dedup` object: the fq-dedup pipeline over a resident 10 GB input with one record in six repeated.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -225,6 +226,40 @@ def ingest_rows(scfq, member_bytes, bgzf_bytes):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return rows
+
+
+def dedup_row(scfq, torch, nbytes=int(10e9), frac=0.2, reps=5):
+    """NON-headline: `sc fq-dedup`'s device pipeline (/root/reference/src/fq_dedup.nim:14-84) over an HBM-resident input
+    of the headline workload's shape in which one record in six re-appears later — the input of scripts/bench_dedup.py, whose CPU
+    comparison and oracle check live there and in tests/test_gpu_dedup.py.  Checked here by what needs no oracle: every record is
+    echoed or counted, the appended copies are all found, and de-duplicating the result changes nothing."""
+    seed = 20260101
+    uniq = int(nbytes / (1 + frac))
+    plan = scfq.synth_plan(0, seed, uniq)
+    again = scfq.synth_plan(0, seed, int(uniq * frac))            # the first records once more: every one a duplicate
+    n = plan.bytes + again.bytes
+    buf = torch.empty(n + 4096, dtype=torch.uint8, device="cuda")
+    scfq.synth_device(0, seed, plan.records, buf.data_ptr(), plan.bytes)
+    buf[plan.bytes:n] = buf[:again.bytes]
+    out = torch.empty(n + 4096, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    walls = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb, st = scfq.dedup_device(buf.data_ptr(), n, out.data_ptr(), n)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    best = min(walls[1:])
+    records = plan.records + again.records
+    assert st.total_reads == records and st.duplicates >= again.records and st.records_out == records - st.duplicates and nb < n
+    nb2, st2 = scfq.dedup_device(out.data_ptr(), nb, buf.data_ptr(), n)      # (the input is not needed any more)
+    assert nb2 == nb and st2.duplicates == 0 and st2.total_reads == st.records_out
+    return {"what": "fq-dedup, input and result resident in HBM: line index, header hashes, radix sort, exact compares, gather (DESIGN.md §4); "
+                    "wall of one scfq_dedup_buffer call, the fastest of %d after a first one" % reps,
+            "input_bytes": n, "records": records, "duplicates": st.duplicates, "bytes_out": nb, "hash_collisions": st.hash_collisions,
+            "wall_ms": round(best * 1e3, 3), "first_call_wall_ms": round(walls[0] * 1e3, 3), "input_GBps": round(n / best / 1e9, 1),
+            "records_per_s": round(records / best), "idempotent": True}
 
 
 def crc32_combine(crc1, crc2, len2):
@@ -634,6 +669,11 @@ def main():
         torch.cuda.empty_cache()
         # (non-headline: a failure here — no room for the files, a host short of memory — is reported in the object, never allowed to take
         # the headline line with it)
+        try:
+            out["dedup"] = dedup_row(scfq, torch)
+        except BaseException as e:      # noqa: BLE001
+            out["dedup"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
         try:
             out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes), int(min(args.ingest_bgzf_bytes, args.ingest_bytes)))
         except BaseException as e:      # noqa: BLE001
