@@ -1651,6 +1651,175 @@ __global__ __launch_bounds__(256) void fq_index_expand(IndexExpandArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5, compact form (r4, the default): the pass over the input writes the newline POSITIONS of every tile — 16-bit offsets inside the
+// tile, packed, behind their count — instead of a bit per byte: ~2 x 46 bytes per 4 KiB tile of 150 bp FASTQ where the masks are 512,
+// and the second kernel turns them into offsets with one coalesced 8-byte store per line where the mask form's lanes each walk their
+// own bits.  A tile with more than kPosCap - 1 newlines (lines shorter than 33 bytes on average) raises a flag: the caller then runs
+// the mask form (above), which has no such limit.
+// Algorithmic bytes: input x (1 + 2 x ~0.023) + 8 B per line = 1.14 x input for 150 bp reads (mask form: 1.34 x).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kPosCap = 128;     // uint16 entries per tile: [0] the count, [1 ..] the positions
+constexpr uint32_t kIndexPosLds = kWavesPerBlock * (2 * kTile + 2 * kPosCap);      // fq_index_pos: the waves' tile rings + their staging slots
+
+struct IndexPosArgs {
+  const uint8_t* base;        // first byte of the input (any alignment)
+  uint64_t n;                 // bytes
+  uint32_t tiles_per_range;
+  uint64_t n_ranges;
+  uint16_t* pos;              // [n_tiles][kPosCap]
+  uint64_t* counts;           // [n_ranges]
+  uint32_t* flags;            // bit 0: the input may hold a '\r' directly before a '\n' (as fq_index_masks; only when want_cr); bit 1: a tile overflowed
+  uint32_t want_cr;
+};
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_pos(IndexPosArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* ring = smem + wave * (2 * kTile);
+  uint16_t* stage = reinterpret_cast<uint16_t*>(smem + kWavesPerBlock * (2 * kTile) + wave * (2 * kPosCap));      // (launch: kIndexPosLds bytes)
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
+  const uint64_t range = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (range >= a.n_ranges) return;
+  const uint64_t B = (uint64_t)(uintptr_t)a.base, E = B + a.n;
+  const uint64_t A0 = B & ~(uint64_t)(kTile - 1);
+  const uint32_t n_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((E - A0 + kTile - 1) / kTile));
+  const uint32_t t_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(range * a.tiles_per_range));
+  uint32_t t_end = t_begin + a.tiles_per_range;
+  if (t_end > n_tiles) t_end = n_tiles;
+  t_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_end);
+  const uint32_t full_lo = (uint32_t)__builtin_amdgcn_readfirstlane((A0 < B) ? 1 : 0);
+  const uint32_t full_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A0 + (uint64_t)n_tiles * kTile > E) ? n_tiles - 1 : n_tiles));
+  const bool want_cr = (bool)__builtin_amdgcn_readfirstlane((int)a.want_cr);
+  PlaneConsts pc;
+  pc.init();
+
+  auto issue = [&](uint32_t t, uint32_t slot) {
+    const uint64_t ts = A0 + (uint64_t)t * kTile;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + slot * kTile));
+    if (t >= full_lo && t < full_hi) {
+      glds_tile<true>(reinterpret_cast<const uint8_t*>(ts + (uint64_t)lane * 16), dst);
+    } else {
+      const uint64_t safe = (B & ~15ull);
+      uint64_t s[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint64_t ps = ts + (uint64_t)k * 1024 + (uint64_t)lane * 16;
+        const bool ok = (ps + 16 > B) && (ps < E);
+        s[k] = (ok ? ps : safe) - (uint64_t)k * 1024;
+      }
+      glds_tile_edge(reinterpret_cast<const uint8_t*>(s[0]), reinterpret_cast<const uint8_t*>(s[1]),
+                     reinterpret_cast<const uint8_t*>(s[2]), reinterpret_cast<const uint8_t*>(s[3]), dst);
+    }
+  };
+
+  uint64_t cr_seen = 0;
+  uint32_t range_total = 0;                         // wave-uniform
+  bool overflow = false;                            // wave-uniform
+  if (t_begin < t_end) issue(t_begin, 0);
+  uint32_t slot = 0;
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) { issue(t + 1, slot ^ 1u); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+    const uint4* p = reinterpret_cast<const uint4*>(ring + slot * kTile + lane * 64);
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+    uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    uint32_t a0, a1, a2, a3, a4, b0, b1, b2, b3, b4, xa[8], xb[8];
+    masks32_planes_x<false>(d, pc, xa, a0, a1, a2, a3, a4);
+    masks32_planes_x<false>(d + 8, pc, xb, b0, b1, b2, b3, b4);
+    uint64_t NL = ~((uint64_t)a0 | ((uint64_t)b0 << 32));
+    if (want_cr) {
+      const uint64_t CR = ~((uint64_t)plane_ne<0x0D>(xa) | ((uint64_t)plane_ne<0x0D>(xb) << 32));
+      cr_seen |= ((CR << 1) & NL) | (CR >> 63);
+    }
+    if (!(t >= full_lo && t < full_hi)) {     // first / last tile of the input: only bytes inside [B, E) exist
+      const uint64_t ts = A0 + (uint64_t)t * kTile;
+      const int64_t ls = (int64_t)(ts + (uint64_t)lane * 64);
+      int64_t lo = (int64_t)B - ls, hi = (int64_t)E - ls;
+      lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
+      hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
+      const uint64_t mhi = (hi >= 64) ? ~0ull : ((1ull << hi) - 1);
+      const uint64_t mlo = (lo >= 64) ? ~0ull : ((1ull << lo) - 1);
+      NL &= mhi & ~mlo;
+    }
+    const uint32_t cnt = popc64(NL);
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t* out = reinterpret_cast<uint32_t*>(a.pos + (uint64_t)t * kPosCap);      // (256-byte aligned: a slot is 128 x 2 bytes)
+    if (total < kPosCap) {                    // wave-uniform
+      // the lanes put their positions into the wave's 256 bytes of LDS, in order, and the wave stores the slot's used part as whole
+      // dwords, coalesced (stored straight from the lanes — 2-byte stores to scattered entries, three store instructions per tile —
+      // the kernel was SLOWER than the mask form, 2.03 against 1.90 ms, with a third of its writes)
+      if (lane == 0) stage[0] = (uint16_t)total;
+      uint32_t o = incl - cnt + 1u;
+      uint64_t x = NL;
+      while (__builtin_amdgcn_ballot_w64(x != 0) != 0) {      // as many rounds as the fullest lane holds newlines (two or three for FASTQ)
+        if (x) {
+          stage[o++] = (uint16_t)((uint32_t)lane * 64u + (uint32_t)__builtin_ctzll(x));
+          x &= x - 1;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order; nothing is read before they have)
+      if ((uint32_t)lane < (total + 2u) / 2u) __builtin_nontemporal_store(reinterpret_cast<const uint32_t*>(stage)[lane], &out[lane]);
+      asm volatile("" ::: "memory");
+    } else {
+      overflow = true;
+      if (lane == 0) out[0] = 0xFFFFu;
+    }
+    range_total += total;
+    slot ^= 1u;
+  }
+  if (lane == 0) a.counts[range] = range_total;
+  // (a look before each atomic: on a "\r\n" input EVERY wave would otherwise queue one on the same word)
+  uint32_t bits = (want_cr && __builtin_amdgcn_ballot_w64(cr_seen != 0) != 0) ? 1u : 0u;
+  if (overflow) bits |= 2u;
+  if (bits && lane == 0 && (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(a.flags, bits);
+}
+
+struct IndexExpandPosArgs {
+  const uint16_t* pos;        // fq_index_pos
+  const uint32_t* flags;      // ... bit 1: some tile overflowed, nothing is written here (the caller runs the mask form)
+  uint64_t lead;              // bytes between the first tile's start and the input's first byte (B - A0)
+  uint32_t n_tiles;
+  uint32_t tiles_per_range;
+  uint64_t n_ranges;
+  const uint64_t* first_ord;  // fq_nl_prefix over the ranges' counts
+  uint64_t* line_off;         // [cap]
+  uint64_t cap;
+  uint64_t off_base;
+};
+
+// one wave per range, tile by tile: lane j holds entries j and 64 + j of the tile (entry 0 is the count), entry j is line ord + j - 1
+__global__ __launch_bounds__(256) void fq_index_expand_pos(IndexExpandPosArgs a) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t range = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (range >= a.n_ranges) return;
+  if (*a.flags & 2u) return;
+  const uint32_t t_begin = (uint32_t)(range * a.tiles_per_range);
+  uint32_t t_end = t_begin + a.tiles_per_range;
+  if (t_end > a.n_tiles) t_end = a.n_tiles;
+  uint64_t ord = a.first_ord[range];
+  static_assert(kPosCap == 128, "two entries per lane");
+  const uint16_t* s = a.pos + (uint64_t)t_begin * kPosCap;
+  // (the first half of the next tile's entries is requested before this tile's offsets are written; the second half only by a tile
+  // that has that many: 46 newlines per tile in 150 bp FASTQ)
+  uint32_t v0 = t_begin < t_end ? s[lane] : 0u;
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    const uint16_t* cur = s;
+    s += kPosCap;
+    const uint32_t n0 = t + 1 < t_end ? s[lane] : 0u;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)v0, 0);
+    const uint64_t tile_off = a.off_base + ((uint64_t)t * kTile - a.lead) + 1;      // offset of the byte AFTER the tile's byte 0
+    if (lane >= 1u && lane <= total) { const uint64_t o = ord + lane - 1u; if (o < a.cap) a.line_off[o] = tile_off + v0; }
+    if (total >= 64u) {      // wave-uniform
+      const uint32_t v1 = cur[64 + lane];
+      if (64u + lane <= total) { const uint64_t o = ord + 63u + lane; if (o < a.cap) a.line_off[o] = tile_off + v1; }
+    }
+    ord += total;
+    v0 = n0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Diagnostic (NOT the product path): the load structure of fq_scan_tiles alone -- same ranges, same 2-slot
 // non-temporal LDS-DMA ring, one ds_read per lane and tile, no classification or accounting.  Its time is the
 // practical ceiling the scan kernel is compared with on the same device (bench.py "stream_ceiling").

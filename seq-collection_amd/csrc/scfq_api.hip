@@ -2217,7 +2217,8 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
 }
 
 // ---- K5: line index of a device-resident input ------------------------------------------------------------------
-// One pass over the input (fq_index_masks keeps one bit per byte, fq_index_expand turns the bits into offsets);
+// One pass over the input (fq_index_pos keeps the newline positions of every tile, fq_index_expand_pos turns them into offsets; the
+// mask form — fq_index_masks keeps one bit per byte, fq_index_expand walks the bits — for inputs with 128+ newlines in a 4 KiB tile);
 // SCFQ_INDEX_TWO_PASS=1 keeps the first form (K1 + K2 count, prefix kernel, second pass over the input) for comparison.
 static int index_lines_two_pass(Ctx* c, const uint8_t* base, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out);
 
@@ -2252,57 +2253,104 @@ int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint
   if (n_tiles >= (1ull << 32)) { std::snprintf(g_err, sizeof g_err, "a single index launch covers at most 16 TiB"); return SCFQ_EARG; }
   const uint32_t tpr = pick_tiles_per_range(c, n_tiles);
   const uint64_t n_ranges = (n_tiles + tpr - 1) / tpr;
-  // scratch: [n_tiles * 64] masks | [n_ranges] counts | [n_ranges + 1] first ordinals | flags
-  const uint64_t words = n_tiles * 64 + 2 * n_ranges + 8;
-  if (words > c->cap_first_ord) {
-    HIPCHK(hipStreamSynchronize(c->compute));
-    if (c->d_first_ord) HIPCHK(hipFree(c->d_first_ord));
-    c->d_first_ord = nullptr;
-    c->cap_first_ord = 0;
-    const uint64_t want = words + words / 8;
-    HIPCHK(hipMalloc(&c->d_first_ord, want * sizeof(uint64_t)));
-    c->cap_first_ord = want;
-  }
-  uint64_t* d_masks = c->d_first_ord;
-  uint64_t* d_counts = d_masks + n_tiles * 64;
-  uint64_t* d_ord = d_counts + n_ranges;
-  uint32_t* d_flags = reinterpret_cast<uint32_t*>(d_ord + n_ranges + 1);
   const bool write = d_line_off && cap >= 1;
-  if (flags_out) HIPCHK(hipMemsetAsync(d_flags, 0, 8, c->compute));
-  if (write) HIPCHK(hipMemsetAsync(d_line_off, 0, sizeof(uint64_t), c->compute));          // line 0 starts at offset 0
-  scfq::IndexMaskArgs ma;
-  ma.base = base;
-  ma.n = n;
-  ma.tiles_per_range = tpr;
-  ma.n_ranges = n_ranges;
-  ma.masks = d_masks;
-  ma.counts = d_counts;
-  ma.flags_out = flags_out ? d_flags : nullptr;
-  const unsigned grid = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
-  hipLaunchKernelGGL(scfq::fq_index_masks, dim3(grid), dim3(64 * scfq::kWavesPerBlock), scfq::kWavesPerBlock * 2 * scfq::kTile, c->compute, ma);
-  HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(scfq::fq_nl_prefix, dim3(1), dim3(1024), 0, c->compute, d_counts, n_ranges, (uint64_t)0, d_ord, 1u);
-  HIPCHK(hipGetLastError());
-  if (write) {
-    scfq::IndexExpandArgs ea;
-    ea.masks = d_masks;
-    ea.lead = B - A0;
-    ea.n_tiles = (uint32_t)n_tiles;
-    ea.tiles_per_range = tpr;
-    ea.n_ranges = n_ranges;
-    ea.first_ord = d_ord;
-    ea.line_off = d_line_off;
-    ea.cap = cap;
-    ea.off_base = 0;
-    hipLaunchKernelGGL(scfq::fq_index_expand, dim3((unsigned)((n_ranges + 3) / 4)), dim3(256), 0, c->compute, ea);
+  // The compact form first (fq_index_pos: 16-bit newline positions per tile, 256 B of scratch per tile), the mask form (a bit per
+  // byte, 512 B per tile) when a tile holds more newlines than its slot — lines shorter than 33 bytes on average — or
+  // SCFQ_INDEX_COMPACT=0 says so.  scratch: [n_tiles * (32 | 64)] positions or masks | [n_ranges] counts | [n_ranges + 1] first ordinals | flags
+  static const bool compact_on = env_int("SCFQ_INDEX_COMPACT", 1) != 0;
+  uint64_t* d_ord = nullptr;
+  uint32_t* d_flags = nullptr;
+  bool have_state = false;      // the compact form has brought the line count, the last byte and the flags back already
+  for (int form = compact_on ? 0 : 1; form < 2; ++form) {
+    const uint64_t per_tile = form == 0 ? scfq::kPosCap / 4 : 64;
+    const uint64_t words = n_tiles * per_tile + 2 * n_ranges + 8;
+    if (words > c->cap_first_ord) {
+      HIPCHK(hipStreamSynchronize(c->compute));
+      if (c->d_first_ord) HIPCHK(hipFree(c->d_first_ord));
+      c->d_first_ord = nullptr;
+      c->cap_first_ord = 0;
+      const uint64_t want = words + words / 8;
+      HIPCHK(hipMalloc(&c->d_first_ord, want * sizeof(uint64_t)));
+      c->cap_first_ord = want;
+    }
+    uint64_t* d_tiles = c->d_first_ord;
+    uint64_t* d_counts = d_tiles + n_tiles * per_tile;
+    d_ord = d_counts + n_ranges;
+    d_flags = reinterpret_cast<uint32_t*>(d_ord + n_ranges + 1);
+    HIPCHK(hipMemsetAsync(d_flags, 0, 8, c->compute));
+    if (write) HIPCHK(hipMemsetAsync(d_line_off, 0, sizeof(uint64_t), c->compute));          // line 0 starts at offset 0
+    const unsigned grid = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
+    if (form == 0) {
+      scfq::IndexPosArgs pa;
+      pa.base = base;
+      pa.n = n;
+      pa.tiles_per_range = tpr;
+      pa.n_ranges = n_ranges;
+      pa.pos = reinterpret_cast<uint16_t*>(d_tiles);
+      pa.counts = d_counts;
+      pa.flags = d_flags;
+      pa.want_cr = flags_out ? 1u : 0u;
+      hipLaunchKernelGGL(scfq::fq_index_pos, dim3(grid), dim3(64 * scfq::kWavesPerBlock), scfq::kIndexPosLds, c->compute, pa);
+    } else {
+      scfq::IndexMaskArgs ma;
+      ma.base = base;
+      ma.n = n;
+      ma.tiles_per_range = tpr;
+      ma.n_ranges = n_ranges;
+      ma.masks = d_tiles;
+      ma.counts = d_counts;
+      ma.flags_out = flags_out ? d_flags : nullptr;
+      hipLaunchKernelGGL(scfq::fq_index_masks, dim3(grid), dim3(64 * scfq::kWavesPerBlock), scfq::kWavesPerBlock * 2 * scfq::kTile, c->compute, ma);
+    }
     HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(scfq::fq_nl_prefix, dim3(1), dim3(1024), 0, c->compute, d_counts, n_ranges, (uint64_t)0, d_ord, 1u);
+    HIPCHK(hipGetLastError());
+    if (write && form == 0) {
+      scfq::IndexExpandPosArgs ea;
+      ea.pos = reinterpret_cast<const uint16_t*>(d_tiles);
+      ea.flags = d_flags;
+      ea.lead = B - A0;
+      ea.n_tiles = (uint32_t)n_tiles;
+      ea.tiles_per_range = tpr;
+      ea.n_ranges = n_ranges;
+      ea.first_ord = d_ord;
+      ea.line_off = d_line_off;
+      ea.cap = cap;
+      ea.off_base = 0;
+      hipLaunchKernelGGL(scfq::fq_index_expand_pos, dim3((unsigned)((n_ranges + 3) / 4)), dim3(256), 0, c->compute, ea);
+      HIPCHK(hipGetLastError());
+    } else if (write) {
+      scfq::IndexExpandArgs ea;
+      ea.masks = d_tiles;
+      ea.lead = B - A0;
+      ea.n_tiles = (uint32_t)n_tiles;
+      ea.tiles_per_range = tpr;
+      ea.n_ranges = n_ranges;
+      ea.first_ord = d_ord;
+      ea.line_off = d_line_off;
+      ea.cap = cap;
+      ea.off_base = 0;
+      hipLaunchKernelGGL(scfq::fq_index_expand, dim3((unsigned)((n_ranges + 3) / 4)), dim3(256), 0, c->compute, ea);
+      HIPCHK(hipGetLastError());
+    }
+    if (form == 1) break;
+    // (the compact form's one question to the device: did every tile fit its slot?  Answered together with the line count below when
+    // it did; a file of very short lines pays this wait and a second pass)
+    HIPCHK(hipMemcpyAsync(c->h_state + 2, d_flags, 4, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipMemcpyAsync(c->h_state, d_ord + n_ranges, sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipMemcpyAsync(c->h_state + 1, base + n - 1, 1, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+    if (!(c->h_state[2] & 2u)) { have_state = true; break; }
+    trace("line index: a tile with more newlines than the compact form's slot holds, the mask form runs");
   }
   // first_ord[n_ranges] = 1 + number of '\n'
-  HIPCHK(hipMemcpyAsync(c->h_state, d_ord + n_ranges, sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
-  HIPCHK(hipMemcpyAsync(c->h_state + 1, base + n - 1, 1, hipMemcpyDeviceToHost, c->compute));
-  if (flags_out) HIPCHK(hipMemcpyAsync(c->h_state + 2, d_flags, 4, hipMemcpyDeviceToHost, c->compute));
-  HIPCHK(hipStreamSynchronize(c->compute));
-  if (flags_out) *flags_out = (uint32_t)(c->h_state[2] & 0xFFFFFFFFu);
+  if (!have_state) {
+    HIPCHK(hipMemcpyAsync(c->h_state, d_ord + n_ranges, sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipMemcpyAsync(c->h_state + 1, base + n - 1, 1, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipMemcpyAsync(c->h_state + 2, d_flags, 4, hipMemcpyDeviceToHost, c->compute));
+    HIPCHK(hipStreamSynchronize(c->compute));
+  }
+  if (flags_out) *flags_out = (uint32_t)(c->h_state[2] & 1u);
   c->h_state[0] -= 1;
   const uint64_t nl = c->h_state[0];
   const bool open_end = (uint8_t)(c->h_state[1] & 0xFF) != (uint8_t)'\n';

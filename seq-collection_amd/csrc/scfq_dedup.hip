@@ -6,7 +6,7 @@
 // pre-filter (a false positive is still echoed on its first occurrence), so stdout is exactly "drop each record whose
 // header line equals an earlier header line".  Here the whole (inflated) input sits in HBM (288 GB per GPU) and that
 // definition is computed directly, with no probabilistic structure:
-//   K5  line index            (fq_scan_kernels.hpp: fq_index_masks + fq_index_expand, one pass over the input; it also says whether the input
+//   K5  line index            (fq_scan_kernels.hpp: fq_index_pos + fq_index_expand_pos, one pass over the input; it also says whether the input
 //                             holds "\r\n" line ends at all: without them no kernel below looks behind a newline)
 //   D1  dd_hash_headers       64-bit hash of every header line (line 4i, EOL stripped as Nim readLine does)
 //   D2  radix sort            (hash, record) pairs, rocprim::radix_sort_pairs; stable, so equal hashes stay in file order

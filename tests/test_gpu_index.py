@@ -47,3 +47,25 @@ def test_line_index_synthetic(gpu, scfq):
         assert np.array_equal(buf.cpu().numpy().view(np.uint64), starts)
         # every 4th line is a header
         assert bool((a[starts[:-1:4].astype(np.int64)] == ord("@")).all())
+
+
+def test_line_index_slot_boundary(gpu, scfq):
+    """The compact form keeps up to 127 newline positions per 4 KiB tile; one tile with more sends the call to the mask form: the same
+    index on either side of the limit (126 .. 129 newlines in one tile, the others sparse), at aligned and unaligned starts."""
+    torch = gpu
+    rng = np.random.default_rng(7)
+    for k in (0, 1, 126, 127, 128, 129, 4096):
+        for offset in (0, 17):
+            a = rng.integers(65, 91, 3 * 4096 + 100, dtype=np.uint8)
+            a[100] = 10
+            # tile 1 of the buffer as the kernel sees it begins at byte 4096 - offset of the input
+            lo = 4096 - offset
+            where = rng.choice(4096, size=k, replace=False) if k < 4096 else np.arange(4096)
+            a[lo + where] = 10
+            t, ptr = to_dev(torch, a, offset)
+            lines, starts = expected_index(a)
+            buf = torch.full((lines + 2,), 0x5555555555555555, dtype=torch.int64, device="cuda")
+            assert scfq.index_lines_device(ptr, a.size, buf.data_ptr(), lines + 1) == lines
+            got = buf.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got[:lines + 1], starts), (k, offset)
+            assert got[lines + 1] == 0x5555555555555555
