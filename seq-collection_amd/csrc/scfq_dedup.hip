@@ -414,23 +414,18 @@ __global__ __launch_bounds__(256) void dd_record_lengths(const uint8_t* base, ui
 // number of bytes in and out: no '\r' stripped, no '\n' added, nothing dropped) it is ONE contiguous copy of ~11 KB;
 // a group that is dropped entirely costs two loads.  Mixed groups go record by record, a record that is not verbatim line by line.
 //
-// The copy keeps EIGHT 16-byte loads per lane in flight before the first store (r4: with one load, one wait and one store per step a
-// wave had 1 KB on its way, the device 8 MB: the kernel ran at 4.96 TB/s of reads + writes).
-// NT: the stores go out non-temporal (measured r4: 8 % slower; SCFQ_DEDUP_NT=1)
-template <bool NT>
-__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint64_t len, uint32_t lane, uint32_t dst_align) {
+// The copy keeps EIGHT 16-byte loads per lane in flight before the first store.  Measured r4 and left out again: non-temporal stores
+// (8 % slower here, though 2 % faster in the aligned copy micro-benchmark), the body aligned to 64 or 128 bytes of the destination
+// instead of 16 (no difference): profiles/r04/dedup_ab.txt, copy_shapes.txt — the gather runs at what a copy reaches on this device.
+__device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint64_t len, uint32_t lane) {
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-  // dst_align (16, 64 or 128): the 16-byte stores of a step cover whole lines of the destination when the body starts on a line
-  uint64_t head = (dst_align - ((uintptr_t)dst & (dst_align - 1))) & (dst_align - 1);
+  uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
   if (head > len) head = len;
-  for (uint64_t t = lane; t < head; t += 64) dst[t] = src[t];
+  if (lane < head) dst[lane] = src[lane];
   const uint64_t body = (len - head) / 16;
   const uint8_t* sp = src + head;
   uint8_t* dp = dst + head;
-  auto put = [&](const v4u& v, uint64_t k) {
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dp + k * 16));
-    else *reinterpret_cast<v4u*>(dp + k * 16) = v;
-  };
+  auto put = [&](const v4u& v, uint64_t k) { *reinterpret_cast<v4u*>(dp + k * 16) = v; };
   uint64_t k = lane;
   for (; k + 7 * 64 < body; k += 8 * 64) {
     v4u v[8];
@@ -457,9 +452,8 @@ __device__ __forceinline__ void wave_copy(uint8_t* dst, const uint8_t* src, uint
   for (uint64_t t = head + body * 16 + lane; t < len; t += 64) dst[t] = src[t];
 }
 
-template <bool NT>
 __global__ __launch_bounds__(256) void dd_gather(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t lines,
-                                                uint64_t n_hdr, const uint64_t* group_off, const uint64_t* out_len, uint8_t* out, uint32_t dst_align) {
+                                                uint64_t n_hdr, const uint64_t* group_off, const uint64_t* out_len, uint8_t* out) {
   const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t i0 = g * kGatherGroup;
@@ -469,7 +463,7 @@ __global__ __launch_bounds__(256) void dd_gather(const uint8_t* base, uint64_t n
   if (o1 == o0) return;                                       // every record of the group was dropped
   const uint64_t jl = (4 * i1 < lines) ? 4 * i1 : lines;
   const uint64_t s0 = line_off[4 * i0], s1 = line_off[jl];
-  if (s1 - s0 == o1 - o0 && s1 <= n) { wave_copy<NT>(out + o0, base + s0, o1 - o0, lane, dst_align); return; }
+  if (s1 - s0 == o1 - o0 && s1 <= n) { wave_copy(out + o0, base + s0, o1 - o0, lane); return; }
   uint64_t at = o0;                                            // where the next kept record of the group goes
   for (uint64_t i = i0; i < i1; ++i) {
     const uint64_t len = out_len[i];
@@ -478,7 +472,7 @@ __global__ __launch_bounds__(256) void dd_gather(const uint8_t* base, uint64_t n
     at += len;
     const uint64_t j0 = 4 * i, j1 = (j0 + 4 < lines) ? j0 + 4 : lines;
     const uint64_t r0 = line_off[j0], r1 = line_off[j1];
-    if (r1 - r0 == len && r1 <= n) { wave_copy<NT>(dst, base + r0, len, lane, 16u); continue; }
+    if (r1 - r0 == len && r1 <= n) { wave_copy(dst, base + r0, len, lane); continue; }
     uint64_t w = 0;
     for (uint64_t j = j0; j < j1; ++j) {
       uint64_t s, e;
@@ -587,15 +581,12 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
                                rocprim::plus<uint64_t>(), stream));
   mark2("lengths + scan enqueued");
   uint64_t h[3] = {0, 0, 0};
-  static const bool gather_nt = [] { const char* e = std::getenv("SCFQ_DEDUP_NT"); return e ? std::atoi(e) != 0 : false; }();
-  static const uint32_t dst_align = [] { const char* e = std::getenv("SCFQ_DEDUP_DST_ALIGN"); const int v = e ? std::atoi(e) : 128; return (uint32_t)(v == 16 || v == 64 ? v : 128); }();
-  const auto gather_kernel = gather_nt ? dd_gather<true> : dd_gather<false>;
   // a caller's buffer that holds the whole input holds any result: the gather goes out behind the scan at once, and the one
   // wait of the call is the one at the end (otherwise the size has to come back first — the result is allocated to fit)
   const bool gather_first = !sized_only && user_out && user_cap >= n;
   if (gather_first) {
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
-                       group_off.as<uint64_t>(), out_len.as<uint64_t>(), user_out, dst_align);
+    hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                       group_off.as<uint64_t>(), out_len.as<uint64_t>(), user_out);
     DCHK(hipGetLastError());
   }
   mark2("gather enqueued");
@@ -619,8 +610,8 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   } else if (user_cap < h[0]) {
     return SCFQ_EARG;
   }
-  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
-                     group_off.as<uint64_t>(), out_len.as<uint64_t>(), o, dst_align);
+  hipLaunchKernelGGL(dd_gather, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), lines, n_hdr,
+                     group_off.as<uint64_t>(), out_len.as<uint64_t>(), o);
   DCHK(hipGetLastError());
   DCHK(hipStreamSynchronize(stream));
   mark("gather");
