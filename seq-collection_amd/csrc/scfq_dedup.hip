@@ -19,6 +19,7 @@
 //   D6  dd_gather             one wave per group: one contiguous copy, eight 16 B loads per lane in flight, when the group is kept verbatim
 // Everything is integer / byte work bound by HBM traffic; there is no CPU fallback.
 #include "../../include/sc_fqcount.h"
+#include "scfq_hdrhash.hpp"
 
 #include <cstring>        // (rocprim's texture iterator calls memset from host code)
 #include <hip/hip_runtime.h>
@@ -150,13 +151,6 @@ __device__ __forceinline__ void line_span(const uint8_t* base, uint64_t n, const
   if (has_cr && nlpos < n && e > s && base[e - 1] == '\r') --e;      // (has_cr: kernel-uniform, from the index pass)
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return x;
-}
-
 // Word k (bytes [8k, 8k + 8)) of the header that starts at s and is len bytes long, bytes past the header zeroed; addresses are
 // clamped to stay inside the input.
 __device__ __forceinline__ uint64_t load_head_word(const uint8_t* base, uint64_t n, uint64_t s, uint64_t len, uint32_t k) {
@@ -177,28 +171,26 @@ __device__ __forceinline__ void load_head64(const uint8_t* base, uint64_t n, uin
   for (int k = 0; k < 8; ++k) w[k] = load_head_word(base, n, s, len, (uint32_t)k);
 }
 
-__device__ __forceinline__ uint64_t hash_words(uint64_t seed, uint64_t len, const uint64_t w[8]) {
-  uint64_t h = seed ^ (len * 0x9E3779B97F4A7C15ull);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) h = mix64(h ^ w[k]) + 0x9E3779B97F4A7C15ull;
-  return h;
-}
-
 // D1: one thread per header line, the first 64 bytes fetched COOPERATIVELY: the headers of a wave are ~360 B apart, so eight
 // loads per thread touched 64 cache lines per instruction (512 line look-ups per wave for ~100 distinct lines).  Instead lane l
 // fetches word l & 7 of header 8 j + (l >> 3) in step j — eight consecutive lanes read 64 consecutive bytes — and the words go
-// through LDS back to the lane that owns the header.  Same hash as a per-thread fetch.
+// through LDS back to the lane that owns the header.  Same hash as a per-thread fetch (scfq_hdrhash.hpp: a sum over the words).
+// only_unknown: the line index has hashed the headers it had in LDS (fq_index_pos) and left kUnknownKey for the others — headers that
+// cross a tile, very long ones, the input's first line: only those are fetched and hashed here, (start, length) included.
 // K: the type the sorted hash is kept in (uint32_t when SCFQ_DEDUP_HASH_BITS <= 32: 4 radix passes over 8-byte pairs; else uint64_t)
 template <typename K>
 __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
-                                                      uint64_t seed, uint32_t hash_bits, K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
+                                                      uint64_t seed, uint32_t hash_bits, K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr,
+                                                      bool only_unknown) {
   __shared__ uint64_t sh_s[4][64];
   __shared__ uint32_t sh_len[4][64];
   __shared__ uint64_t sh_w[4][64][9];                   // (9: the owner's eight 8-byte reads of consecutive lanes spread over the banks)
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool mine = i < n_hdr && (!only_unknown || i == 0 || keys[i] == (K)~(K)0);
+  if (only_unknown && __syncthreads_or(mine ? 1 : 0) == 0) return;      // (block-uniform: most blocks have nothing to do)
   uint64_t s = 0, e = 0;
-  if (i < n_hdr) line_span(base, n, line_off, 4 * i, s, e, has_cr);
+  if (mine) line_span(base, n, line_off, 4 * i, s, e, has_cr);
   const uint64_t len = e - s;
   sh_s[wv][lane] = s;
   sh_len[wv][lane] = (uint32_t)(len < 64 ? len : 64);
@@ -206,22 +198,24 @@ __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
     const uint32_t h = 8u * j + (lane >> 3), k = lane & 7u;
-    sh_w[wv][h][k] = load_head_word(base, n, sh_s[wv][h], sh_len[wv][h], k);
+    sh_w[wv][h][k] = load_head_word(base, n, sh_s[wv][h], sh_len[wv][h], k);      // (no load for a word past the header's end)
   }
   __syncthreads();
-  if (i >= n_hdr) return;
+  if (!mine) return;
   hdr[i] = s | ((len < 0xFFFFFFull ? len : 0xFFFFFFull) << 40);      // start (40 bits: inputs up to 1 TiB) | length, saturated
-  uint64_t w[8];
+  uint32_t A = 0, B = 0;
+  const uint64_t n_words = (len + 7) / 8;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) w[k] = sh_w[wv][lane][k];
-  uint64_t h = hash_words(seed, len, w);
-  for (uint64_t p = s + 64; p < e; p += 8) {         // headers longer than 64 bytes: the rest, 8 bytes per step
-    uint64_t v = 0;
-    if (p + 8 <= e) __builtin_memcpy(&v, base + p, 8);
-    else for (uint64_t b = 0; p + b < e; ++b) v |= (uint64_t)base[p + b] << (8 * b);
-    h = mix64(h ^ v) + 0x9E3779B97F4A7C15ull;
+  for (int k = 0; k < 8; ++k) {
+    const uint64_t w = sh_w[wv][lane][k];
+    if ((uint64_t)k < n_words) scfq_hdrhash::hh_word((uint32_t)w, (uint32_t)(w >> 32), (uint32_t)k, A, B);
   }
-  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // (32 or 40 by default; the tests force collisions with 4)
+  for (uint64_t k = 8; k < n_words; ++k) {           // headers longer than 64 bytes: the rest, a word per step
+    const uint64_t w = load_head_word(base, n, s, len, (uint32_t)k);
+    scfq_hdrhash::hh_word((uint32_t)w, (uint32_t)(w >> 32), (uint32_t)k, A, B);
+  }
+  uint64_t h = scfq_hdrhash::hh_final(A, B, len, seed);
+  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // (32 by default; the tests force collisions with 4)
   keys[i] = (K)h;
   idx[i] = (uint32_t)i;
 }
@@ -552,7 +546,7 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   auto hash_sort_mark = [&](auto key_tag) -> int {
     using K = decltype(key_tag);
     hipLaunchKernelGGL(dd_hash_headers<K>, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
-                       0x5CF0DED0B1A5ull, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
+                       0x5CF0DED0B1A5ull, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr, /*only_unknown=*/false);
     DCHK(hipGetLastError());
     mark("hash headers");
     size_t tmp_bytes = 0;
