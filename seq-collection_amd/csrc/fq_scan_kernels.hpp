@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "scfq_hdrhash.hpp"
+
 #ifndef SCFQ_ABLATE
 #define SCFQ_ABLATE 0   // diagnostic timing-only builds (make ablate): 1 = no classifier, 2 = no segment accounting, 3 = neither
 #endif
@@ -1659,7 +1661,69 @@ __global__ __launch_bounds__(256) void fq_index_expand(IndexExpandArgs a) {
 // Algorithmic bytes: input x (1 + 2 x ~0.023) + 8 B per line = 1.14 x input for 150 bp reads (mask form: 1.34 x).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kPosCap = 128;     // uint16 entries per tile: [0] the count, [1 ..] the positions
-constexpr uint32_t kIndexPosLds = kWavesPerBlock * (2 * kTile + 2 * kPosCap);      // fq_index_pos: the waves' tile rings + their staging slots
+constexpr uint32_t kPosHashCap = 32;  // hashed lines per tile (fq-dedup): a tile of 150 bp FASTQ holds 11 or 12 headers
+constexpr uint32_t kPosStage = 2 * kPosCap + 4 * kPosHashCap + 8 * kPosHashCap;      // a wave's staging: the slot, the (start, length) list, the hashes
+constexpr uint32_t kIndexPosLds = kWavesPerBlock * (2 * kTile + kPosStage);      // fq_index_pos: the waves' tile rings + their staging areas
+
+// fq-dedup rides along (IndexPosArgs::hash_at): the lines of this tile that start with '@', begin behind one of its newlines and end at
+// the next are hashed HERE, where their bytes are in LDS — lane j looks at the line behind newline j (entries j and j + 1 of the staged
+// positions); the lines found are listed, and four lanes take a line each round, every fourth 8-byte word per lane, summed over the four
+// with two cross-lane steps: the hash is a sum over words (scfq_hdrhash.hpp).
+// The hash kernel of fq-dedup read 1.4 lines of 128 bytes per 57-byte header — 4 - 5 GB for 10 GB of input — to do the same.
+__device__ __forceinline__ void index_hash_lines(const uint8_t* tile, uint16_t* stage, uint32_t* hl, uint64_t* hout, uint32_t total, int lane,
+                                                 uint64_t* out) {
+  const uint32_t j = (uint32_t)lane;
+  bool cand = j >= 1u && j + 1u <= total;
+  uint32_t S = 0, len = 0;
+  if (cand) {
+    const uint32_t p0 = stage[j], p1 = stage[j + 1u];
+    S = p0 + 1u;
+    uint32_t e = p1;
+    if (S < e && tile[e - 1u] == '\r') --e;       // (Nim's readLine: "\r\n" ends a line as "\n" does)
+    len = e - S;
+    cand = S < p1 && tile[S] == '@' && len <= scfq_hdrhash::kMaxLen;
+  }
+  const uint64_t hmask = __builtin_amdgcn_ballot_w64(cand);
+  if (hmask == 0) return;
+  const uint32_t rank = (uint32_t)__builtin_popcountll(hmask & ((1ull << lane) - 1ull));
+  cand = cand && rank < kPosHashCap;
+  if (cand) { hl[rank] = S | len << 16; stage[j] = (uint16_t)(stage[j] | 0x8000u); }
+  uint32_t n_h = (uint32_t)__builtin_popcountll(hmask);
+  if (n_h > kPosHashCap) n_h = kPosHashCap;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const uint32_t k0 = (uint32_t)lane & 3u;
+  for (uint32_t r0 = 0; r0 < n_h; r0 += 16u) {      // wave-uniform: sixteen lines a round, four lanes each (words k0, k0 + 4, ...)
+    const uint32_t hh = r0 + ((uint32_t)lane >> 2);
+    uint32_t A = 0, B = 0, ln = 0;
+    if (hh < n_h) {
+      const uint32_t v = hl[hh];
+      const uint32_t Sl = v & 0xFFFFu;
+      ln = v >> 16;
+      const uint32_t n_words = (ln + 7u) >> 3;
+      for (uint32_t kk = k0; kk < n_words; kk += 4u) {
+        // the word's eight bytes from LDS: three aligned dwords and two byte alignments (the line starts anywhere)
+        const uint32_t at = Sl + 8u * kk;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(tile + (at & ~3u));
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];      // (may reach past the tile's end: still this workgroup's LDS, masked below)
+        const uint32_t sh = at & 3u;
+        uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const uint32_t valid = ln - 8u * kk;                 // >= 1
+        if (valid < 4u) { lo &= (1u << (8u * valid)) - 1u; hi = 0; }
+        else if (valid == 4u) hi = 0;
+        else if (valid < 8u) hi &= (1u << (8u * (valid - 4u))) - 1u;
+        scfq_hdrhash::hh_word(lo, hi, kk, A, B);
+      }
+    }
+    // the four lanes of a line add up (DPP quad permutes: the neighbour in the pair, then the other pair); the mixing of the sums is
+    // left to the kernel that hands the keys out (fq_index_expand_pos: one lane per header there)
+    A += (uint32_t)__builtin_amdgcn_mov_dpp((int)A, 0xB1, 0xF, 0xF, true); B += (uint32_t)__builtin_amdgcn_mov_dpp((int)B, 0xB1, 0xF, 0xF, true);
+    A += (uint32_t)__builtin_amdgcn_mov_dpp((int)A, 0x4E, 0xF, 0xF, true); B += (uint32_t)__builtin_amdgcn_mov_dpp((int)B, 0x4E, 0xF, 0xF, true);
+    if (hh < n_h && k0 == 0u) hout[hh] = (uint64_t)A | (uint64_t)(B & 0xFFFFFFu) << 32 | (uint64_t)ln << scfq_hdrhash::kHashBits;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((uint32_t)lane < n_h) out[lane] = hout[lane];
+  asm volatile("" ::: "memory");
+}
 
 struct IndexPosArgs {
   const uint8_t* base;        // first byte of the input (any alignment)
@@ -1670,6 +1734,11 @@ struct IndexPosArgs {
   uint64_t* counts;           // [n_ranges]
   uint32_t* flags;            // bit 0: the input may hold a '\r' directly before a '\n' (as fq_index_masks; only when want_cr); bit 1: a tile overflowed
   uint32_t want_cr;
+  // fq-dedup (optional): the hashes of the lines that start with '@' and lie inside ONE tile (start behind a newline of the tile, end
+  // at the next one, at most 255 bytes), in tile order, at most kPosHashCap per tile: [n_tiles][kPosHashCap] of A | (B & 2^24 - 1) << 32 |
+  // length << 56 (scfq_hdrhash.hpp: the sums over the line's words); the entry of the newline in front of such a line carries bit 15
+  uint64_t* hash_at;
+  uint64_t hash_seed;
 };
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_pos(IndexPosArgs a) {
@@ -1677,7 +1746,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_pos(IndexPosArgs
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint8_t* ring = smem + wave * (2 * kTile);
-  uint16_t* stage = reinterpret_cast<uint16_t*>(smem + kWavesPerBlock * (2 * kTile) + wave * (2 * kPosCap));      // (launch: kIndexPosLds bytes)
+  uint16_t* stage = reinterpret_cast<uint16_t*>(smem + kWavesPerBlock * (2 * kTile) + wave * kPosStage);      // (launch: kIndexPosLds bytes)
+  uint32_t* hl = reinterpret_cast<uint32_t*>(stage + kPosCap);                 // fq-dedup: (start | length << 16) of the lines to hash
+  uint64_t* hout = reinterpret_cast<uint64_t*>(hl + kPosHashCap);              // ... and their hashes
+  const bool want_hash = (bool)__builtin_amdgcn_readfirstlane(a.hash_at != nullptr ? 1 : 0);
   const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
   const uint64_t range = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
   if (range >= a.n_ranges) return;
@@ -1759,6 +1831,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fq_index_pos(IndexPosArgs
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order; nothing is read before they have)
+      if (want_hash && total >= 2u) index_hash_lines(ring + slot * kTile, stage, hl, hout, total, lane, a.hash_at + (uint64_t)t * kPosHashCap);
       if ((uint32_t)lane < (total + 2u) / 2u) __builtin_nontemporal_store(reinterpret_cast<const uint32_t*>(stage)[lane], &out[lane]);
       asm volatile("" ::: "memory");
     } else {
@@ -1786,7 +1859,30 @@ struct IndexExpandPosArgs {
   uint64_t* line_off;         // [cap]
   uint64_t cap;
   uint64_t off_base;
+  // fq-dedup (optional; hash_at as written by fq_index_pos): line 4r is record r's header — its key (the hash's low hash_bits, or all
+  // ones = "not hashed by the index pass": dd_hash_headers does those), its number, and its (start | length << 40)
+  const uint64_t* hash_at;
+  void* keys;                 // uint32_t[cap_records] (key_bytes == 4) or uint64_t[cap_records]
+  uint32_t* idx;
+  uint64_t* hdr;
+  uint64_t cap_records;
+  uint32_t key_bytes;
+  uint32_t hash_bits;
+  uint64_t hash_seed;
+  uint32_t* unk;              // [n_tiles][kPosUnk]: the records of the tile that got the all-ones key (0: none) ...
+  uint32_t* flags_rw;         // ... bit 2 of the index's flag word: a tile had more of them, or 64+ newlines: the list is not complete
 };
+constexpr uint32_t kPosUnk = 4;
+
+__device__ __forceinline__ void index_put_record(const IndexExpandPosArgs& a, uint64_t r, uint64_t start, bool hashed, uint64_t stored) {
+  if (r >= a.cap_records) return;
+  const uint64_t len = hashed ? stored >> scfq_hdrhash::kHashBits : 0xFFFFFFull;      // (saturated: looked up again through the line index)
+  const uint64_t h = scfq_hdrhash::hh_final((uint32_t)stored, (uint32_t)(stored >> 32) & 0xFFFFFFu, len, a.hash_seed);
+  const uint64_t key = hashed ? (a.hash_bits < 64 ? h & ((1ull << a.hash_bits) - 1ull) : h) : ~0ull;
+  if (a.key_bytes == 4) static_cast<uint32_t*>(a.keys)[r] = (uint32_t)key; else static_cast<uint64_t*>(a.keys)[r] = key;
+  a.idx[r] = (uint32_t)r;
+  a.hdr[r] = start | len << 40;
+}
 
 // one wave per range, tile by tile: lane j holds entries j and 64 + j of the tile (entry 0 is the count), entry j is line ord + j - 1
 __global__ __launch_bounds__(256) void fq_index_expand_pos(IndexExpandPosArgs a) {
@@ -1803,20 +1899,52 @@ __global__ __launch_bounds__(256) void fq_index_expand_pos(IndexExpandPosArgs a)
   // (the first half of the next tile's entries is requested before this tile's offsets are written; the second half only by a tile
   // that has that many: 46 newlines per tile in 150 bp FASTQ)
   uint32_t v0 = t_begin < t_end ? s[lane] : 0u;
+  // (fq-dedup: the tile's hashes come with its entries — lane l holds hash l & 31 — so that no load waits for a rank)
+  const uint64_t* hs = a.keys ? a.hash_at + (uint64_t)t_begin * kPosHashCap : nullptr;
+  uint64_t h0 = (hs && t_begin < t_end) ? hs[lane & 31u] : 0;
+  bool unk_over = false;      // wave-uniform
   for (uint32_t t = t_begin; t < t_end; ++t) {
     const uint16_t* cur = s;
     s += kPosCap;
     const uint32_t n0 = t + 1 < t_end ? s[lane] : 0u;
+    uint64_t hn = 0;
+    if (hs) { hs += kPosHashCap; if (t + 1 < t_end) hn = hs[lane & 31u]; }
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)v0, 0);
     const uint64_t tile_off = a.off_base + ((uint64_t)t * kTile - a.lead) + 1;      // offset of the byte AFTER the tile's byte 0
-    if (lane >= 1u && lane <= total) { const uint64_t o = ord + lane - 1u; if (o < a.cap) a.line_off[o] = tile_off + v0; }
+    const bool mine = lane >= 1u && lane <= total;
+    const uint32_t pos = v0 & 0x7FFFu;                                              // (bit 15: the line behind this newline was hashed)
+    if (mine) { const uint64_t o = ord + lane - 1u; if (o < a.cap) a.line_off[o] = tile_off + pos; }
+    if (a.keys) {      // kernel-uniform
+      const bool hashed = mine && (v0 & 0x8000u);
+      const uint64_t hm = __builtin_amdgcn_ballot_w64(hashed);
+      const uint32_t rank = (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull)) & 31u;
+      const uint64_t stored = (uint64_t)(uint32_t)__shfl((int)(uint32_t)h0, (int)rank, 64) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(h0 >> 32), (int)rank, 64) << 32;
+      const uint64_t o = ord + lane - 1u;
+      const bool head = mine && (o & 3u) == 0;
+      if (head) index_put_record(a, o >> 2, tile_off + pos, hashed, stored);
+      if (a.unk) {
+        const bool un = head && !hashed;
+        const uint64_t um = __builtin_amdgcn_ballot_w64(un);
+        const uint32_t n_un = (uint32_t)__builtin_popcountll(um);
+        uint32_t* u = a.unk + (uint64_t)t * kPosUnk;
+        if (un) { const uint32_t ur = (uint32_t)__builtin_popcountll(um & ((1ull << lane) - 1ull)); if (ur < kPosUnk) u[ur] = (uint32_t)(o >> 2); }
+        if (lane < kPosUnk && lane >= n_un) u[lane] = 0u;
+        if (n_un > kPosUnk || total >= 64u) unk_over = true;
+      }
+    }
     if (total >= 64u) {      // wave-uniform
-      const uint32_t v1 = cur[64 + lane];
-      if (64u + lane <= total) { const uint64_t o = ord + 63u + lane; if (o < a.cap) a.line_off[o] = tile_off + v1; }
+      const uint32_t v1 = cur[64 + lane] & 0x7FFFu;
+      if (64u + lane <= total) {
+        const uint64_t o = ord + 63u + lane;
+        if (o < a.cap) a.line_off[o] = tile_off + v1;
+        if (a.keys && (o & 3u) == 0) index_put_record(a, o >> 2, tile_off + v1, false, 0);
+      }
     }
     ord += total;
     v0 = n0;
+    h0 = hn;
   }
+  if (unk_over && lane == 0u && !(__hip_atomic_load(a.flags_rw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u)) atomicOr(a.flags_rw, 4u);
 }
 
 // ------------------------------------------------------------------------------------------------

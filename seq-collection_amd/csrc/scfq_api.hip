@@ -2224,13 +2224,36 @@ static int index_lines_two_pass(Ctx* c, const uint8_t* base, uint64_t n, uint64_
 
 // internal (fq-dedup): the index plus flags — bit 0: the input may hold "\r\n" line ends
 int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out);
+// ... and, with `aux`, the records' header hashes on the way (scfq_hdrhash.hpp; the compact form only: `filled` says whether they were
+// written — record r of every header line behind a newline: key or all ones, number, start | length << 40)
+struct scfq_index_aux {
+  void* keys;             // device: uint32_t[cap_records] (key_bytes == 4) or uint64_t[cap_records]
+  uint32_t* idx;          // device
+  uint64_t* hdr;          // device
+  uint64_t cap_records;
+  uint32_t key_bytes;
+  uint32_t hash_bits;     // <= 56
+  uint64_t seed;
+  uint32_t* unk;          // device, optional: [unk_tiles][4] record numbers that got the all-ones key, tile by tile (0: none)
+  uint64_t unk_tiles;     // capacity of unk in tiles
+  int filled;             // out
+  int unk_complete;       // out: unk lists every such record (but record 0)
+  uint64_t n_tiles;       // out
+};
+int scfq_index_lines_ex2(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out, scfq_index_aux* aux);
 
 int scfq_index_lines(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out) {
   return scfq_index_lines_ex(dptr, n, d_line_off, cap, lines_out, nullptr);
 }
 
 int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out) {
+  return scfq_index_lines_ex2(dptr, n, d_line_off, cap, lines_out, flags_out, nullptr);
+}
+
+int scfq_index_lines_ex2(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out, scfq_index_aux* aux) {
   if ((!dptr && n) || !lines_out) return SCFQ_EARG;
+  if (aux) { aux->filled = 0; aux->unk_complete = 0; aux->n_tiles = 0; }
+  if (aux && (!aux->keys || !aux->idx || !aux->hdr || (aux->key_bytes != 4 && aux->key_bytes != 8) || aux->hash_bits > 56 || !d_line_off)) return SCFQ_EARG;
   if (flags_out) *flags_out = 1u;            // unknown until the one-pass kernel says otherwise
   Ctx* c = nullptr;
   SessionLock sl;
@@ -2262,7 +2285,8 @@ int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint
   uint32_t* d_flags = nullptr;
   bool have_state = false;      // the compact form has brought the line count, the last byte and the flags back already
   for (int form = compact_on ? 0 : 1; form < 2; ++form) {
-    const uint64_t per_tile = form == 0 ? scfq::kPosCap / 4 : 64;
+    const bool with_hash = form == 0 && aux && write;
+    const uint64_t per_tile = form == 0 ? scfq::kPosCap / 4 + (with_hash ? scfq::kPosHashCap : 0) : 64;
     const uint64_t words = n_tiles * per_tile + 2 * n_ranges + 8;
     if (words > c->cap_first_ord) {
       HIPCHK(hipStreamSynchronize(c->compute));
@@ -2281,7 +2305,9 @@ int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint
     if (write) HIPCHK(hipMemsetAsync(d_line_off, 0, sizeof(uint64_t), c->compute));          // line 0 starts at offset 0
     const unsigned grid = (unsigned)((n_ranges + scfq::kWavesPerBlock - 1) / scfq::kWavesPerBlock);
     if (form == 0) {
-      scfq::IndexPosArgs pa;
+      scfq::IndexPosArgs pa{};
+      pa.hash_at = with_hash ? d_tiles + n_tiles * (scfq::kPosCap / 4) : nullptr;      // (behind the position slots)
+      pa.hash_seed = aux ? aux->seed : 0;
       pa.base = base;
       pa.n = n;
       pa.tiles_per_range = tpr;
@@ -2306,7 +2332,14 @@ int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint
     hipLaunchKernelGGL(scfq::fq_nl_prefix, dim3(1), dim3(1024), 0, c->compute, d_counts, n_ranges, (uint64_t)0, d_ord, 1u);
     HIPCHK(hipGetLastError());
     if (write && form == 0) {
-      scfq::IndexExpandPosArgs ea;
+      scfq::IndexExpandPosArgs ea{};
+      if (with_hash) {
+        ea.hash_at = d_tiles + n_tiles * (scfq::kPosCap / 4);
+        ea.keys = aux->keys; ea.idx = aux->idx; ea.hdr = aux->hdr;
+        ea.cap_records = aux->cap_records; ea.key_bytes = aux->key_bytes; ea.hash_bits = aux->hash_bits; ea.hash_seed = aux->seed;
+        ea.unk = (aux->unk && aux->unk_tiles >= n_tiles) ? aux->unk : nullptr;
+        ea.flags_rw = d_flags;
+      }
       ea.pos = reinterpret_cast<const uint16_t*>(d_tiles);
       ea.flags = d_flags;
       ea.lead = B - A0;
@@ -2340,7 +2373,11 @@ int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint
     HIPCHK(hipMemcpyAsync(c->h_state, d_ord + n_ranges, sizeof(uint64_t), hipMemcpyDeviceToHost, c->compute));
     HIPCHK(hipMemcpyAsync(c->h_state + 1, base + n - 1, 1, hipMemcpyDeviceToHost, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));
-    if (!(c->h_state[2] & 2u)) { have_state = true; break; }
+    if (!(c->h_state[2] & 2u)) {
+      have_state = true;
+      if (with_hash) { aux->filled = 1; aux->n_tiles = n_tiles; aux->unk_complete = (aux->unk && aux->unk_tiles >= n_tiles && !(c->h_state[2] & 4u)) ? 1 : 0; }
+      break;
+    }
     trace("line index: a tile with more newlines than the compact form's slot holds, the mask form runs");
   }
   // first_ord[n_ranges] = 1 + number of '\n'

@@ -8,7 +8,9 @@
 // definition is computed directly, with no probabilistic structure:
 //   K5  line index            (fq_scan_kernels.hpp: fq_index_pos + fq_index_expand_pos, one pass over the input; it also says whether the input
 //                             holds "\r\n" line ends at all: without them no kernel below looks behind a newline)
-//   D1  dd_hash_headers       64-bit hash of every header line (line 4i, EOL stripped as Nim readLine does)
+//   D1  header hashes         of every header line (line 4i, EOL stripped as Nim readLine does; scfq_hdrhash.hpp): computed by the index pass itself
+//                             for the headers it has whole in LDS (r4), by dd_hash_listed for the few it leaves (dd_hash_headers: all of them,
+//                             when the index pass could not: its mask form, SCFQ_DEDUP_FUSED_HASH=0)
 //   D2  radix sort            (hash, record) pairs, rocprim::radix_sort_pairs; stable, so equal hashes stay in file order
 //   D3  dd_mark_duplicates    a record is a duplicate iff an EARLIER record of its equal-hash run has the same bytes:
 //                             exact string compare, so hash collisions cost time, never correctness (dd_count_marks: the statistics,
@@ -26,6 +28,22 @@
 #include <rocprim/rocprim.hpp>
 
 extern "C" int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out);   // scfq_api.hip
+struct scfq_index_aux {       // (scfq_api.hip: the header hashes ride on the index pass)
+  void* keys;
+  uint32_t* idx;
+  uint64_t* hdr;
+  uint64_t cap_records;
+  uint32_t key_bytes;
+  uint32_t hash_bits;
+  uint64_t seed;
+  uint32_t* unk;
+  uint64_t unk_tiles;
+  int filled;
+  int unk_complete;
+  uint64_t n_tiles;
+};
+extern "C" int scfq_index_lines_ex2(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out, scfq_index_aux* aux);
+constexpr uint64_t kHashSeed = 0x5CF0DED0B1A5ull;
 
 #include <unistd.h>
 
@@ -175,20 +193,16 @@ __device__ __forceinline__ void load_head64(const uint8_t* base, uint64_t n, uin
 // loads per thread touched 64 cache lines per instruction (512 line look-ups per wave for ~100 distinct lines).  Instead lane l
 // fetches word l & 7 of header 8 j + (l >> 3) in step j — eight consecutive lanes read 64 consecutive bytes — and the words go
 // through LDS back to the lane that owns the header.  Same hash as a per-thread fetch (scfq_hdrhash.hpp: a sum over the words).
-// only_unknown: the line index has hashed the headers it had in LDS (fq_index_pos) and left kUnknownKey for the others — headers that
-// cross a tile, very long ones, the input's first line: only those are fetched and hashed here, (start, length) included.
 // K: the type the sorted hash is kept in (uint32_t when SCFQ_DEDUP_HASH_BITS <= 32: 4 radix passes over 8-byte pairs; else uint64_t)
 template <typename K>
 __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t n_hdr,
-                                                      uint64_t seed, uint32_t hash_bits, K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr,
-                                                      bool only_unknown) {
+                                                      uint64_t seed, uint32_t hash_bits, K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
   __shared__ uint64_t sh_s[4][64];
   __shared__ uint32_t sh_len[4][64];
   __shared__ uint64_t sh_w[4][64][9];                   // (9: the owner's eight 8-byte reads of consecutive lanes spread over the banks)
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool mine = i < n_hdr && (!only_unknown || i == 0 || keys[i] == (K)~(K)0);
-  if (only_unknown && __syncthreads_or(mine ? 1 : 0) == 0) return;      // (block-uniform: most blocks have nothing to do)
+  const bool mine = i < n_hdr;
   uint64_t s = 0, e = 0;
   if (mine) line_span(base, n, line_off, 4 * i, s, e, has_cr);
   const uint64_t len = e - s;
@@ -216,6 +230,75 @@ __global__ __launch_bounds__(256) void dd_hash_headers(const uint8_t* base, uint
   }
   uint64_t h = scfq_hdrhash::hh_final(A, B, len, seed);
   if (hash_bits < 64) h &= (1ull << hash_bits) - 1;     // (32 by default; the tests force collisions with 4)
+  keys[i] = (K)h;
+  idx[i] = (uint32_t)i;
+}
+
+// D1b (the index pass has hashed most headers: fq_index_pos): the records it left with the all-ones key — headers that cross a tile
+// of the index pass, very long ones, the input's first line — listed (2048 positions and ONE atomic per block, as dd_find_equal) ...
+template <typename K>
+__global__ __launch_bounds__(256) void dd_find_unknown(const K* keys, uint64_t n_hdr, uint32_t* list, uint32_t* n_list) {
+  __shared__ uint32_t wave_cnt[8][4], block_base;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t base = (uint64_t)blockIdx.x * 2048;
+  uint64_t bal[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint64_t p = base + 256u * j + threadIdx.x;
+    const bool un = p < n_hdr && (p == 0 || keys[p] == (K)~(K)0);
+    bal[j] = __builtin_amdgcn_ballot_w64(un);
+    if (lane == 0) wave_cnt[j][w] = (uint32_t)__popcll(bal[j]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int j = 0; j < 8; ++j) for (int k = 0; k < 4; ++k) tot += wave_cnt[j][k];
+    block_base = tot ? atomicAdd(n_list, tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t before = block_base;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    for (uint32_t k = 0; k < w; ++k) before += wave_cnt[j][k];
+    if ((bal[j] >> lane) & 1ull) list[before + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1))] = (uint32_t)(base + 256u * j + threadIdx.x);
+    for (uint32_t k = w; k < 4; ++k) before += wave_cnt[j][k];
+  }
+}
+
+// ... and hashed, a thread each: all of a header's first eight words requested before any is used.  n_list == nullptr: the list is
+// the index pass's own, four entries per tile, 0 = no record — and record 0, which it never lists, is thread 0's
+template <typename K>
+__global__ __launch_bounds__(256) void dd_hash_listed(const uint8_t* base, uint64_t n, const uint64_t* line_off, const uint32_t* list, const uint32_t* n_list,
+                                                     uint64_t n_entries, uint64_t n_hdr, uint64_t seed, uint32_t hash_bits, K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t i;
+  if (n_list) {
+    if (t >= *n_list) return;
+    i = list[t];
+  } else {
+    if (t > n_entries) return;
+    i = t == 0 ? 0 : list[t - 1];
+    if (t != 0 && i == 0) return;
+  }
+  // (the index pass numbers the line BEHIND every newline: behind the input's last one there is none — "record" n_hdr of an input whose
+  // line count is a multiple of four)
+  if (i >= n_hdr) return;
+  uint64_t s, e;
+  line_span(base, n, line_off, 4 * i, s, e, has_cr);
+  const uint64_t len = e - s;
+  hdr[i] = s | ((len < 0xFFFFFFull ? len : 0xFFFFFFull) << 40);
+  uint64_t w[8];
+  load_head64(base, n, s, len, w);
+  uint32_t A = 0, B = 0;
+  const uint64_t n_words = (len + 7) / 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if ((uint64_t)k < n_words) scfq_hdrhash::hh_word((uint32_t)w[k], (uint32_t)(w[k] >> 32), (uint32_t)k, A, B);
+  for (uint64_t k = 8; k < n_words; ++k) {
+    const uint64_t v = load_head_word(base, n, s, len, (uint32_t)k);
+    scfq_hdrhash::hh_word((uint32_t)v, (uint32_t)(v >> 32), (uint32_t)k, A, B);
+  }
+  uint64_t h = scfq_hdrhash::hh_final(A, B, len, seed);
+  if (hash_bits < 64) h &= (1ull << hash_bits) - 1;
   keys[i] = (K)h;
   idx[i] = (uint32_t)i;
 }
@@ -501,21 +584,44 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   // than 24 bytes on average — and only a wrong guess costs a second pass with the exact size
   int rc = SCFQ_OK;
   uint32_t index_flags = 1;
-  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, group_len, group_off, counters, tmp, hdr, cand;
+  DevBuf line_off, keys, keys2, idx, idx2, dup, out_len, group_len, group_off, counters, tmp, hdr, cand, unk;
+  // 32 bits of hash in 32-bit keys: the radix sort makes 4 passes over 8-byte (key, record) pairs — 0.93 ms for 28 M records against
+  // 1.29 ms for 40 bits in 64-bit keys — and the exact compare behind the sort makes collisions (n^2 / 2^33 pairs: 88 K among 28 M
+  // records) a matter of time, never of correctness.  (r2 - r3 kept 40 bits: the colliding pairs cost the compare kernel 0.48 ms —
+  // which was the atomic each of them did on one statistics counter, not the compares; r4 sums the statistics per block.)
+  static const int hash_bits_env = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); return e ? std::min(64, std::max(1, std::atoi(e))) : 0; }();
+  const uint32_t hash_bits = hash_bits_env ? (uint32_t)hash_bits_env : 32u;
+  // The header hashes ride on the index pass (fq_index_pos has every header in LDS: scfq_hdrhash.hpp, SCFQ_DEDUP_FUSED_HASH=0 keeps the
+  // hash kernel for all of them): keys, numbers and (start, length) are then sized by the index's guess, before the line count is known
+  static const bool fused_env = [] { const char* e = std::getenv("SCFQ_DEDUP_FUSED_HASH"); return e ? std::atoi(e) != 0 : true; }();
+  const bool fused = fused_env && hash_bits <= 56;
+  const uint32_t key_bytes = hash_bits <= 32 ? 4u : 8u;
+  scfq_index_aux aux{};
   {
     uint64_t cap = n / 24 + 1024;
-    if ((rc = line_off.alloc(cap * 8, stream))) return rc;
-    mark("alloc line offsets");
-    DCHK(hipStreamSynchronize(stream));       // scfq_index_lines works on the library's own stream
-    mark("wait for the caller's stream");
-    rc = scfq_index_lines_ex(d_in, n, line_off.as<uint64_t>(), cap, &lines, &index_flags);
-    if (rc) return rc;
-    if (lines + 1 > cap) {
-      (void)hipFreeAsync(line_off.release(), stream);
-      if ((rc = line_off.alloc((lines + 1) * 8, stream))) return rc;
-      DCHK(hipStreamSynchronize(stream));
-      rc = scfq_index_lines_ex(d_in, n, line_off.as<uint64_t>(), lines + 1, &lines, &index_flags);
+    for (int round = 0; round < 2; ++round) {
+      if ((rc = line_off.alloc(cap * 8, stream))) return rc;
+      if (fused) {
+        const uint64_t cap_records = cap / 4 + 2;
+        if ((rc = keys.alloc(cap_records * 8, stream)) || (rc = idx.alloc(cap_records * 4, stream)) || (rc = hdr.alloc(cap_records * 8, stream))) return rc;
+        aux.keys = keys.p; aux.idx = idx.as<uint32_t>(); aux.hdr = hdr.as<uint64_t>();
+        aux.cap_records = cap_records; aux.key_bytes = key_bytes; aux.hash_bits = hash_bits; aux.seed = kHashSeed;
+        if (!unk.p) {
+          aux.unk_tiles = n / 4096 + 2;      // (the index pass's tiles are 4 KiB, the first one may be a partial one)
+          if ((rc = unk.alloc(aux.unk_tiles * 4 * sizeof(uint32_t), stream))) return rc;
+          aux.unk = unk.as<uint32_t>();
+        }
+      }
+      mark("alloc line offsets");
+      DCHK(hipStreamSynchronize(stream));       // scfq_index_lines works on the library's own stream
+      mark("wait for the caller's stream");
+      rc = scfq_index_lines_ex2(d_in, n, line_off.as<uint64_t>(), cap, &lines, &index_flags, fused ? &aux : nullptr);
       if (rc) return rc;
+      if (lines + 1 <= cap) break;
+      // the guess was too small (lines shorter than 24 bytes on average): once more with the exact size
+      (void)hipFreeAsync(line_off.release(), stream);
+      if (fused) { (void)hipFreeAsync(keys.release(), stream); (void)hipFreeAsync(idx.release(), stream); (void)hipFreeAsync(hdr.release(), stream); }
+      cap = lines + 1;
     }
   }
   const bool has_cr = (index_flags & 1u) != 0;
@@ -525,28 +631,37 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
   if (n_hdr == 0) return SCFQ_OK;
   mark("line index (K5, one pass)");
   const uint64_t n_groups = (n_hdr + kGatherGroup - 1) / kGatherGroup;
-  if ((rc = keys.alloc(n_hdr * 8, stream)) || (rc = keys2.alloc(n_hdr * 8, stream)) || (rc = idx.alloc(n_hdr * 4, stream)) ||
+  if (!fused && ((rc = keys.alloc(n_hdr * 8, stream)) || (rc = idx.alloc(n_hdr * 4, stream)) || (rc = hdr.alloc(n_hdr * 8, stream)))) return rc;
+  if ((rc = keys2.alloc(n_hdr * 8, stream)) ||
       (rc = idx2.alloc(n_hdr * 4, stream)) || (rc = dup.alloc(n_hdr, stream)) || (rc = out_len.alloc(n_hdr * 8, stream)) ||
-      (rc = group_len.alloc((n_groups + 1) * 8, stream)) || (rc = group_off.alloc((n_groups + 1) * 8, stream)) || (rc = counters.alloc(32, stream)) || (rc = hdr.alloc(n_hdr * 8, stream)) ||
+      (rc = group_len.alloc((n_groups + 1) * 8, stream)) || (rc = group_off.alloc((n_groups + 1) * 8, stream)) || (rc = counters.alloc(32, stream)) ||
       (rc = cand.alloc(n_hdr * 4, stream)))
     return rc;
   mark("alloc scratch");
   DCHK(hipMemsetAsync(counters.p, 0, 32, stream));
   const unsigned blocks = (unsigned)((n_hdr + 255) / 256);
-  // 32 bits of hash in 32-bit keys: the radix sort makes 4 passes over 8-byte (key, record) pairs — 0.93 ms for 28 M records against
-  // 1.29 ms for 40 bits in 64-bit keys — and the exact compare behind the sort makes collisions (n^2 / 2^33 pairs: 88 K among 28 M
-  // records) a matter of time, never of correctness.  (r2 - r3 kept 40 bits: the colliding pairs cost the compare kernel 0.48 ms —
-  // which was the atomic each of them did on one statistics counter, not the compares; r4 sums the statistics per block.)
-  static const int hash_bits_env = [] { const char* e = std::getenv("SCFQ_DEDUP_HASH_BITS"); return e ? std::min(64, std::max(1, std::atoi(e))) : 0; }();
-  const uint32_t hash_bits = hash_bits_env ? (uint32_t)hash_bits_env : 32u;
   size_t scan_bytes = 0;
   DCHK(rocprim::exclusive_scan(nullptr, scan_bytes, group_len.as<uint64_t>(), group_off.as<uint64_t>(), (uint64_t)0, (size_t)(n_groups + 1),
                                rocprim::plus<uint64_t>(), stream));
   uint32_t* n_cand = reinterpret_cast<uint32_t*>(counters.as<unsigned long long>() + 2);
   auto hash_sort_mark = [&](auto key_tag) -> int {
     using K = decltype(key_tag);
-    hipLaunchKernelGGL(dd_hash_headers<K>, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
-                       0x5CF0DED0B1A5ull, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr, /*only_unknown=*/false);
+    if (fused && aux.filled && aux.unk_complete) {
+      // (the index pass left few — ~2 % of the records of a 150 bp file: the headers that cross one of its 4 KiB tiles — and listed them)
+      const uint64_t n_entries = aux.n_tiles * 4;
+      hipLaunchKernelGGL(dd_hash_listed<K>, dim3((unsigned)((n_entries + 1 + 255) / 256)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), unk.as<uint32_t>(),
+                         (const uint32_t*)nullptr, n_entries, n_hdr, kHashSeed, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
+    } else if (fused && aux.filled) {
+      // (its list is not complete — a tile with five of them, or with 64+ lines: short reads — they are looked for)
+      uint32_t* n_list = reinterpret_cast<uint32_t*>(counters.as<unsigned long long>() + 3);
+      hipLaunchKernelGGL(dd_find_unknown<K>, dim3((unsigned)((n_hdr + 2047) / 2048)), dim3(256), 0, stream, keys.as<K>(), n_hdr, cand.as<uint32_t>(), n_list);
+      DCHK(hipGetLastError());
+      hipLaunchKernelGGL(dd_hash_listed<K>, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), cand.as<uint32_t>(), n_list,
+                         (uint64_t)0, n_hdr, kHashSeed, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
+    } else {
+      hipLaunchKernelGGL(dd_hash_headers<K>, dim3(blocks), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), n_hdr,
+                         kHashSeed, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
+    }
     DCHK(hipGetLastError());
     mark("hash headers");
     size_t tmp_bytes = 0;

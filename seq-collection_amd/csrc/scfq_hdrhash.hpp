@@ -13,7 +13,7 @@
 
 namespace scfq_hdrhash {
 
-// the index pass hands a header's hash over in 56 bits, its length (<= kMaxLen) in the 8 above them
+// the index pass hands a header's two sums over in 56 bits (A, 24 bits of B), its length (<= kMaxLen) in the 8 above them
 constexpr uint32_t kHashBits = 56;
 constexpr uint32_t kMaxLen = 255;
 
@@ -28,12 +28,17 @@ __host__ __device__ __forceinline__ void hh_word(uint32_t lo, uint32_t hi, uint3
   B += b + (a << 11 | a >> 21);
 }
 
+// the two sums, the length and the seed mixed into 64 bits with 32-bit full-rate operations and four 32-bit multiplies (the finaliser
+// of a 32-bit avalanche hash on each half, the halves crossed in between)
+// (of B its low 24 bits: the index pass hands the sums over as A | B << 32 | length << 56 and leaves the mixing to the kernel behind it)
 __host__ __device__ __forceinline__ uint64_t hh_final(uint32_t A, uint32_t B, uint64_t len, uint64_t seed) {
-  uint64_t x = ((uint64_t)A << 32 | B) ^ seed ^ (len * 0x9E3779B97F4A7C15ull);
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return x;
+  uint32_t a = A ^ (uint32_t)seed ^ ((uint32_t)len * 0x9E3779B1u);
+  uint32_t b = (B & 0xFFFFFFu) ^ (uint32_t)(seed >> 32) ^ (uint32_t)(len >> 32);
+  a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13;
+  b += a; b ^= b >> 15; b *= 0xC2B2AE35u; b ^= b >> 16;
+  a += b; a ^= a >> 13; a *= 0x27D4EB2Fu; a ^= a >> 16;
+  b ^= a; b *= 0x165667B1u; b ^= b >> 15;
+  return (uint64_t)a << 32 | b;
 }
 
 }  // namespace scfq_hdrhash

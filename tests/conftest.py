@@ -48,8 +48,7 @@ def _build_oracle():
     return so
 
 
-@pytest.fixture(scope="session")
-def oracle():
+def make_oracle():
     """The CPU restatement (oracle/): test infrastructure, the checker the HIP path is compared with."""
     L = ctypes.CDLL(_build_oracle())
     L.oracle_count_lines.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(OracleCounts)]
@@ -110,6 +109,14 @@ def oracle():
             return b.value.decode()
 
     return O
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return make_oracle()
+
+
+_oracle_for_subprocess = make_oracle      # (tests that run their cases in a child process with another environment)
 
 
 def golden_rows():

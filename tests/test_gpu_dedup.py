@@ -157,3 +157,51 @@ def test_large_input_properties(gpu, scfq):
     assert nb2 == nb1 and st2.duplicates == 0 and torch.equal(again[:nb2], out1[:nb1])     # idempotent
     # the generator's IDs are nearly unique: what is dropped from a single copy is a handful of chance repeats
     assert st1.duplicates < plan.records // 1000
+
+
+def _records(rng, n, hdr_len, read_len, at_quality=False, crlf=False):
+    """n records with headers of hdr_len bytes (unique: a counter inside), reads of read_len, optionally quality lines that start with '@'"""
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        tag = b"@r%d/" % i
+        hdr = tag + bytes(rng.integers(97, 123, max(0, hdr_len - len(tag)), dtype=np.uint8))      # lowercase filler
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), read_len))
+        q = bytes(rng.integers(35, 75, read_len, dtype=np.uint8))
+        if at_quality and read_len:
+            q = b"@" + q[1:]
+        out.append(hdr + eol + seq + eol + b"+" + eol + q + eol)
+    return out
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_header_hashes_from_the_index_pass(gpu, fused):
+    """The line index hashes the headers it has in LDS (scfq_hdrhash.hpp); what it cannot do goes to the hash kernel: headers that cross
+    a 4 KiB tile, headers longer than 255 bytes, files of short lines (64+ newlines in a tile: its list of left-over records is not
+    complete then), the input's first line, the "line" behind the last newline.  Every shape against the oracle, with the fused path
+    (default) and without it (SCFQ_DEDUP_FUSED_HASH=0): same bytes, same statistics."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import scfq, conftest\n"
+        "from test_gpu_dedup import _records, check\n"
+        "oracle = conftest._oracle_for_subprocess()\n"
+        "rng = np.random.default_rng(11)\n"
+        "shapes = [dict(hdr_len=57, read_len=150), dict(hdr_len=57, read_len=150, crlf=True), dict(hdr_len=300, read_len=100),\n"
+        "          dict(hdr_len=255, read_len=40), dict(hdr_len=256, read_len=40), dict(hdr_len=20, read_len=25), dict(hdr_len=12, read_len=8),\n"
+        "          dict(hdr_len=57, read_len=150, at_quality=True), dict(hdr_len=64, read_len=64), dict(hdr_len=65, read_len=1)]\n"
+        "for sh in shapes:\n"
+        "    recs = _records(rng, 6000, **sh)\n"
+        "    dup = [recs[int(k)] for k in rng.integers(0, len(recs), 1500)]\n"
+        "    allr = recs + dup\n"
+        "    order = rng.permutation(len(allr))\n"
+        "    data = b''.join(allr[int(k)] for k in order)\n"
+        "    st = check(scfq, oracle, data, sh)\n"
+        "    assert st.duplicates == 1500, (sh, st.duplicates)\n"
+        "    for cut in (1, 2, 7):\n"
+        "        check(scfq, oracle, data[:-cut], (sh, 'cut', cut))\n"
+        "    check(scfq, oracle, b'x' * 4090 + data, (sh, 'shifted'))\n"
+        "print('fused cases ok')\n"
+    ) % (os.path.join(os.path.dirname(HERE), "seq-collection_amd", "pyhost"), HERE)
+    env = dict(os.environ, SCFQ_DEDUP_FUSED_HASH=fused)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "fused cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
