@@ -265,21 +265,35 @@ __global__ __launch_bounds__(256) void dd_find_unknown(const K* keys, uint64_t n
   }
 }
 
+template <typename K>
+__device__ __forceinline__ void hash_one(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t i, uint64_t n_hdr, uint64_t seed, uint32_t hash_bits,
+                                         K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr);
+
 // ... and hashed, a thread each: all of a header's first eight words requested before any is used.  n_list == nullptr: the list is
 // the index pass's own, four entries per tile, 0 = no record — and record 0, which it never lists, is thread 0's
 template <typename K>
 __global__ __launch_bounds__(256) void dd_hash_listed(const uint8_t* base, uint64_t n, const uint64_t* line_off, const uint32_t* list, const uint32_t* n_list,
                                                      uint64_t n_entries, uint64_t n_hdr, uint64_t seed, uint32_t hash_bits, K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  uint64_t i;
-  if (n_list) {
-    if (t >= *n_list) return;
-    i = list[t];
-  } else {
-    if (t > n_entries) return;
-    i = t == 0 ? 0 : list[t - 1];
-    if (t != 0 && i == 0) return;
+  if (!n_list) {
+    // a thread per TILE of the index pass: its four entries in one load, nearly always four zeros
+    if (t > n_entries / 4) return;
+    if (t == 0) { hash_one<K>(base, n, line_off, 0, n_hdr, seed, hash_bits, keys, idx, hdr, has_cr); return; }
+    const uint4 q = reinterpret_cast<const uint4*>(list)[t - 1];
+    if ((q.x | q.y | q.z | q.w) == 0) return;
+    if (q.x) hash_one<K>(base, n, line_off, q.x, n_hdr, seed, hash_bits, keys, idx, hdr, has_cr);
+    if (q.y) hash_one<K>(base, n, line_off, q.y, n_hdr, seed, hash_bits, keys, idx, hdr, has_cr);
+    if (q.z) hash_one<K>(base, n, line_off, q.z, n_hdr, seed, hash_bits, keys, idx, hdr, has_cr);
+    if (q.w) hash_one<K>(base, n, line_off, q.w, n_hdr, seed, hash_bits, keys, idx, hdr, has_cr);
+    return;
   }
+  if (t >= *n_list) return;
+  hash_one<K>(base, n, line_off, list[t], n_hdr, seed, hash_bits, keys, idx, hdr, has_cr);
+}
+
+template <typename K>
+__device__ __forceinline__ void hash_one(const uint8_t* base, uint64_t n, const uint64_t* line_off, uint64_t i, uint64_t n_hdr, uint64_t seed, uint32_t hash_bits,
+                                         K* keys, uint32_t* idx, uint64_t* hdr, bool has_cr) {
   // (the index pass numbers the line BEHIND every newline: behind the input's last one there is none — "record" n_hdr of an input whose
   // line count is a multiple of four)
   if (i >= n_hdr) return;
@@ -649,7 +663,7 @@ int dedup_device(const uint8_t* d_in, uint64_t n, uint8_t* user_out, uint64_t us
     if (fused && aux.filled && aux.unk_complete) {
       // (the index pass left few — ~2 % of the records of a 150 bp file: the headers that cross one of its 4 KiB tiles — and listed them)
       const uint64_t n_entries = aux.n_tiles * 4;
-      hipLaunchKernelGGL(dd_hash_listed<K>, dim3((unsigned)((n_entries + 1 + 255) / 256)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), unk.as<uint32_t>(),
+      hipLaunchKernelGGL(dd_hash_listed<K>, dim3((unsigned)((aux.n_tiles + 1 + 255) / 256)), dim3(256), 0, stream, d_in, n, line_off.as<uint64_t>(), unk.as<uint32_t>(),
                          (const uint32_t*)nullptr, n_entries, n_hdr, kHashSeed, hash_bits, keys.as<K>(), idx.as<uint32_t>(), hdr.as<uint64_t>(), has_cr);
     } else if (fused && aux.filled) {
       // (its list is not complete — a tile with five of them, or with 64+ lines: short reads — they are looked for)
