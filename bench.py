@@ -670,15 +670,16 @@ def main():
         # (non-headline: a failure here — no room for the files, a host short of memory — is reported in the object, never allowed to take
         # the headline line with it)
         try:
-            out["dedup"] = dedup_row(scfq, torch)
-        except BaseException as e:      # noqa: BLE001
-            out["dedup"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        torch.cuda.empty_cache()
-        try:
             out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes), int(min(args.ingest_bgzf_bytes, args.ingest_bytes)))
         except BaseException as e:      # noqa: BLE001
             import traceback
             out["ingest"] = {"error": "%s: %s" % (type(e).__name__, e), "traceback_tail": traceback.format_exc()[-1500:]}
+        # (behind the ingest legs: its pool keeps the scratch of a 10 GB call, which the legs' processes need not find in their way)
+        torch.cuda.empty_cache()
+        try:
+            out["dedup"] = dedup_row(scfq, torch)
+        except BaseException as e:      # noqa: BLE001
+            out["dedup"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out))
     if exchange:
