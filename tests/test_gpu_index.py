@@ -69,3 +69,9 @@ def test_line_index_slot_boundary(gpu, scfq):
             got = buf.cpu().numpy().view(np.uint64)
             assert np.array_equal(got[:lines + 1], starts), (k, offset)
             assert got[lines + 1] == 0x5555555555555555
+            # a buffer that is too small gets the first `cap` entries and nothing behind them; the count is the whole input's
+            cap = max(1, lines // 2)
+            small = torch.full((cap + 1,), 0x5555555555555555, dtype=torch.int64, device="cuda")
+            assert scfq.index_lines_device(ptr, a.size, small.data_ptr(), cap) == lines
+            got = small.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got[:cap], starts[:cap]) and got[cap] == 0x5555555555555555, (k, offset, "small")
