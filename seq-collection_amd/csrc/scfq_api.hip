@@ -17,6 +17,7 @@
 #include "bgzf_inflate_kernel.hpp"
 #include "gz_inflate_kernels.hpp"
 #include "scfq_arena.hpp"
+#include "scfq_index_aux.hpp"
 
 #include <fcntl.h>
 #include <functional>
@@ -2222,25 +2223,7 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
 // SCFQ_INDEX_TWO_PASS=1 keeps the first form (K1 + K2 count, prefix kernel, second pass over the input) for comparison.
 static int index_lines_two_pass(Ctx* c, const uint8_t* base, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out);
 
-// internal (fq-dedup): the index plus flags — bit 0: the input may hold "\r\n" line ends
-int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out);
-// ... and, with `aux`, the records' header hashes on the way (scfq_hdrhash.hpp; the compact form only: `filled` says whether they were
-// written — record r of every header line behind a newline: key or all ones, number, start | length << 40)
-struct scfq_index_aux {
-  void* keys;             // device: uint32_t[cap_records] (key_bytes == 4) or uint64_t[cap_records]
-  uint32_t* idx;          // device
-  uint64_t* hdr;          // device
-  uint64_t cap_records;
-  uint32_t key_bytes;
-  uint32_t hash_bits;     // <= 56
-  uint64_t seed;
-  uint32_t* unk;          // device, optional: [unk_tiles][4] record numbers that got the all-ones key, tile by tile (0: none)
-  uint64_t unk_tiles;     // capacity of unk in tiles
-  int filled;             // out
-  int unk_complete;       // out: unk lists every such record (but record 0)
-  uint64_t n_tiles;       // out
-};
-int scfq_index_lines_ex2(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out, scfq_index_aux* aux);
+// internal (fq-dedup): csrc/scfq_index_aux.hpp
 
 int scfq_index_lines(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out) {
   return scfq_index_lines_ex(dptr, n, d_line_off, cap, lines_out, nullptr);

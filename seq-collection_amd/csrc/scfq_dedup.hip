@@ -27,22 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
-extern "C" int scfq_index_lines_ex(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out);   // scfq_api.hip
-struct scfq_index_aux {       // (scfq_api.hip: the header hashes ride on the index pass)
-  void* keys;
-  uint32_t* idx;
-  uint64_t* hdr;
-  uint64_t cap_records;
-  uint32_t key_bytes;
-  uint32_t hash_bits;
-  uint64_t seed;
-  uint32_t* unk;
-  uint64_t unk_tiles;
-  int filled;
-  int unk_complete;
-  uint64_t n_tiles;
-};
-extern "C" int scfq_index_lines_ex2(const void* dptr, uint64_t n, uint64_t* d_line_off, uint64_t cap, uint64_t* lines_out, uint32_t* flags_out, scfq_index_aux* aux);
+#include "scfq_index_aux.hpp"      // scfq_index_lines_ex2: the index, and the header hashes on its way
 constexpr uint64_t kHashSeed = 0x5CF0DED0B1A5ull;
 
 #include <unistd.h>
