@@ -590,6 +590,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     return SCFQ_OK;
   };
 
+  static const bool stop_at_border = env_int("SCFQ_GZ_DEVICE_STOP_AT_BORDER", 1) != 0;
   // ---- stage B(k): the segments of batch k (its last one stops at the first start of batch k + 1), decode ---------------------
   auto stage_b = [&](uint32_t k) -> int {
     GzSlot& sl = g.slot[k % n_slots];
@@ -598,7 +599,10 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     const uint32_t np = (uint32_t)(p1_of(k) - p0_of(k));
     const uint64_t limit = copy_end_of(k) * 8;
     uint64_t next_first = (k + 1 < nb) ? byte1_of(k) * 8 : end_bit;     // where the last segment stops
-    if (k + 1 < nb) {
+    // (SCFQ_GZ_DEVICE_STOP_AT_BORDER=1: always at the batch's border — the wave runs on to the end of the block that crosses it, which
+    // is where the next batch's first segment starts when the search found that block start; the walk checks it and fills a gap
+    // otherwise.  The decode of batch k then does not wait for the copy and the search of batch k + 1.)
+    if (k + 1 < nb && !stop_at_border) {
       const uint64_t* nf = reinterpret_cast<const uint64_t*>(g.h_search[(k + 1) % 4] + off_found);
       const uint32_t npn = (uint32_t)(p1_of(k + 1) - p0_of(k + 1));
       for (uint32_t s = 0; s < npn; ++s)
@@ -1146,6 +1150,23 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
 
   // ---- the pipeline -----------------------------------------------------------------------------------------------------------
   int fail = SCFQ_OK;
+  if (stop_at_border) {
+    // the same stages, the decode of a batch one iteration earlier: A(0), wait, B(0) before anything of batch 1 is waited for
+    for (uint32_t it = 0; it < nb + 1 && !fail; ++it) {
+      { const auto t0 = clk::now();
+        if (it == 0) fail = stage_a(0);
+        if (!fail && it >= 1 && it + 1 < nb) fail = stage_a(it + 1);
+        if (!fail && it < nb) fail = stage_a_wait(it);
+        stage_ms[0] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
+      { const auto t0 = clk::now(); if (it < nb) fail = stage_b(it); stage_ms[1] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
+      if (it == 0 && nb > 1) { fail = stage_a(1); if (fail) break; }
+      if (it >= 1) {
+        { const auto t0 = clk::now(); fail = stage_c(it - 1); stage_ms[2] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+        if (fail) break;
+        if (finished) break;
+      }
+    }
+  } else
   for (uint32_t it = 0; it < nb + 2 && !fail; ++it) {
     auto timed = [&](int which, int r) { return r; };
     (void)timed;
