@@ -336,6 +336,19 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       (void)hipGetLastError();
     });
   }
+  // the pinned ring (below) is allocated on a helper thread when it has to grow: pinning 2 x 128 MiB is 25 - 40 ms of a process's first
+  // call, spent under the allocation of the device buffers instead of behind it
+  const uint64_t want_piece = gz_ring_piece(comp, c->n_sessions <= 1);
+  int ring_rc = SCFQ_OK;
+  struct RingHelper { std::thread th; ~RingHelper() { if (th.joinable()) th.join(); } } ring_helper;
+  static const bool ring_on_helper = env_int("SCFQ_GZ_DEVICE_RING_HELPER", 1) != 0;
+  if (ring_on_helper && c->stage_cap < want_piece) {
+    const int dev = c->dev;
+    ring_helper.th = std::thread([c, want_piece, dev, &ring_rc] {
+      if (hipSetDevice(dev) != hipSuccess) { ring_rc = SCFQ_EHIP; return; }
+      ring_rc = ensure_staging(c, want_piece, true);
+    });
+  }
   const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
   const uint64_t comp_pad = 256;
   const uint64_t end_bit = stretch_to ? sx->stop_bit : fsize * 8;
@@ -403,8 +416,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // decode waves of two batches on the device a piece crosses PCIe at 26 - 30 GB/s instead of 55, every piece costs the copier a
   // round of eight memcpy threads, and the orchestrating thread waited for the copier 94 / 75 / 39 ms of a 10 GB file's 187 / 169 /
   // 156 ms with pieces of 16 / 64 / 128 MiB (profiles/r03/gz_device_variants.txt); pinning 2 x 128 MiB costs a process 40 ms.
-  const uint64_t want_piece = gz_ring_piece(comp, c->n_sessions <= 1);
-  rc = ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
+  if (ring_helper.th.joinable()) ring_helper.th.join();
+  rc = ring_rc ? ring_rc : ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
   if (rc) return rc;
   trace("gzip engine: pinned ring ready");
   const uint64_t pin_chunk = std::max<uint64_t>(want_piece, comp > (256ull << 20) ? std::min<uint64_t>(c->stage_cap, 64ull << 20) : 0);
