@@ -23,6 +23,7 @@ import ctypes
 import json
 import os
 import sys
+import subprocess
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -623,7 +624,12 @@ def main():
         try:
             with open(pmc) as f:
                 j = json.load(f)
-            if int(j.get("bytes_per_launch", -1)) == shard_n:
+            # the committed counters belong to ONE kernel instance at ONE range geometry: attach them only to a run of exactly that
+            # (SCFQ_RING / SCFQ_NT / SCFQ_TILES_PER_RANGE change the load structure, and with it what may be re-read)
+            ran = scfq.debug_last_scan_kernel()
+            out["roofline"]["kernel_instance"] = ran
+            same_kernel = ran.split(" tiles_per_range=")[0] == j.get("kernel") and ran.endswith("tiles_per_range=%s" % j.get("tiles_per_range"))
+            if int(j.get("bytes_per_launch", -1)) == shard_n and same_kernel:
                 out["roofline"]["traffic"] = j.get("hbm_bytes_per_launch")
                 out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (offline rocprofv3 --pmc passes over this same workload and kernel: %s; not measured in this run)" % j.get("source", "")
         except Exception:
@@ -664,27 +670,41 @@ def main():
         out["cpu_all_cores"] = {"value": round(oc.bases / all_s / 1e9, 3), "unit": "Gbases/s", "threads": threads,
                                 "note": "optimised CPU restatement: byte-range shards + the same ordered fold, byte-serial scan per shard"}
         del host
+    side_leg_failed = False
     if rank == 0 and world == 1 and args.ingest_bytes > 0 and kind == 0 and args.flags == 0:
         del buf          # (the 10 GB workload: the ingest legs measure processes of their own, beside a parent that holds little)
         torch.cuda.empty_cache()
         # (non-headline: a failure here — no room for the files, a host short of memory — is reported in the object, never allowed to take
         # the headline line with it)
+        # Only RESOURCE trouble is forgiven; the legs' assertions are correctness checks (counters == generator tallies, dedup idempotent):
+        # a wrong result is recorded in the object too, the line is still printed, and the run then ends non-zero.
+        forgiven = (OSError, MemoryError, subprocess.SubprocessError, torch.OutOfMemoryError)
         try:
             out["ingest"] = ingest_rows(scfq, int(args.ingest_bytes), int(min(args.ingest_bgzf_bytes, args.ingest_bytes)))
-        except BaseException as e:      # noqa: BLE001
+        except forgiven as e:
             import traceback
             out["ingest"] = {"error": "%s: %s" % (type(e).__name__, e), "traceback_tail": traceback.format_exc()[-1500:]}
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            out["ingest"] = {"error": "%s: %s" % (type(e).__name__, e), "traceback_tail": traceback.format_exc()[-1500:], "fatal": True}
+            side_leg_failed = True
         # (behind the ingest legs: its pool keeps the scratch of a 10 GB call, which the legs' processes need not find in their way)
         torch.cuda.empty_cache()
         try:
             out["dedup"] = dedup_row(scfq, torch)
-        except BaseException as e:      # noqa: BLE001
+        except forgiven as e:
             out["dedup"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        except Exception as e:      # noqa: BLE001
+            out["dedup"] = {"error": "%s: %s" % (type(e).__name__, e), "fatal": True}
+            side_leg_failed = True
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if exchange:
         exchanger.close()
         dist.destroy_process_group()
+    if side_leg_failed:
+        sys.stderr.write("bench.py: a non-headline leg produced a WRONG RESULT or an unexpected error (see the line's \"fatal\" object): exit 1\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,9 @@ int scfq_debug_gz_shard_fix(scfq_partial* p, uint64_t* hist, int true_prev, int 
  * `sc fq-count --stats` prints the array; bench.py's cold-process legs carry it. */
 int64_t scfq_debug_stages(char* buf, uint64_t cap);
 void scfq_debug_stage_mark(const char* what);
+/* The scan kernel instance and range geometry of the calling thread's last scan launch, e.g.
+ * "fq_scan_tiles<false, 0, 2, true, false> tiles_per_range=100" (same contract as scfq_debug_stages: returns the length, writes when it fits). */
+int64_t scfq_debug_last_scan_kernel(char* buf, uint64_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,9 @@
 #!/bin/bash
 # fq-dedup A/B on the GPU box: the pipeline's knobs against each other, then its host-clock stage times and a kernel timeline.
 # usage: scripts/gpu_dedup_ab.sh <out-subdir>
-OUT=gpurun_out/${1:-dedup}; mkdir -p $OUT
+TAG=${1:-dedup}
+ROOT=$(cd "$(dirname "$0")/.." && pwd); cd $ROOT
+OUT=gpurun_out/$TAG; mkdir -p $OUT
 one() { # name, env...
   n=$1; shift
   env SCFQ_NOOP=1 "$@" timeout -k 10 200 python scripts/bench_dedup.py 10e9 0.2 6 2>$OUT/$n.err | tail -1 > $OUT/$n.json || { echo "$n FAILED"; tail -3 $OUT/$n.err; return 1; }
@@ -15,11 +17,11 @@ for round in 1 2; do
 done
 SCFQ_DEDUP_TRACE=2 timeout -k 10 200 python scripts/bench_dedup.py 10e9 0.2 2 2>$OUT/trace2.err >/dev/null; echo "host enqueue times (no synchronisation between the marks):" | tee -a $OUT/summary.txt; grep "scfq dedup" $OUT/trace2.err | sed -n 22,33p | tee -a $OUT/summary.txt
 SCFQ_DEDUP_TRACE=1 timeout -k 10 200 python scripts/bench_dedup.py 10e9 0.2 2 2>$OUT/trace.err >/dev/null; grep "scfq dedup" $OUT/trace.err | tail -14 | tee -a $OUT/summary.txt
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof/dedup_$1 -o dd -- python3 $GRAFT_REPO_ROOT/scripts/bench_dedup.py 10e9 0.2 2 > /dev/null 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/prof/dedup_$TAG -o dd -- python3 $ROOT/scripts/bench_dedup.py 10e9 0.2 2 > /dev/null 2>&1)
 python3 - <<PY | tee $OUT/timeline.txt
 import csv, glob
 rows=[]
-for f in glob.glob("gpurun_out/prof/dedup_$1/**/*kernel_trace.csv", recursive=True):
+for f in glob.glob("gpurun_out/prof/dedup_$TAG/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # the last 10 GB call: find the last fq_index_masks with a long duration

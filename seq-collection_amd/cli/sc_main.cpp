@@ -204,9 +204,16 @@ static FileResult fq_count_compute(const std::string& fastq, bool basename, bool
     r.extra += js;
     // where the process's time went up to this row: [name, ms since the library was loaded] (include/sc_fqcount_debug.h)
     scfq_debug_stage_mark("sc: row computed");
-    std::string stages((size_t)scfq_debug_stages(nullptr, 0) + 1, '\0');
-    scfq_debug_stages(&stages[0], stages.size());
-    stages.resize(std::strlen(stages.c_str()));
+    // (with --jobs another session's thread may add a mark between the sizing call and the filling one: ask again until the
+    // text fits, and keep the row valid JSON whatever happens)
+    std::string stages;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      stages.assign((size_t)scfq_debug_stages(nullptr, 0) + 256, '\0');
+      const uint64_t need = scfq_debug_stages(&stages[0], stages.size());
+      if (need < stages.size()) { stages.resize(std::strlen(stages.c_str())); break; }
+      stages.clear();
+    }
+    if (stages.empty()) stages = "[]";
     r.extra += stages + "}\n";
   }
   return r;

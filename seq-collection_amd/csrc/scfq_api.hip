@@ -380,8 +380,15 @@ uint32_t pick_tiles_per_range(const Ctx* c, uint64_t n_tiles) {
   return (uint32_t)tpr;
 }
 
+// the scan kernel instance and range geometry of this thread's last launch (scfq_debug_last_scan_kernel: bench.py attaches committed PMC
+// traffic only to a run of the very kernel that was profiled)
+thread_local char g_last_scan[128] = "";
+
 template <bool S, int H, int RING, bool NT, bool GUESS = false>
 void launch_scan(const scfq::ScanArgs& a, unsigned blocks, hipStream_t st) {
+  if (!GUESS)
+    std::snprintf(g_last_scan, sizeof g_last_scan, "fq_scan_tiles<%s, %d, %d, %s, %s> tiles_per_range=%u", S ? "true" : "false", H, RING, NT ? "true" : "false",
+                  GUESS ? "true" : "false", a.tiles_per_range);
   constexpr int waves = (H == 1) ? scfq::kHistWaves : (H == 2) ? scfq::kQWaves : scfq::kWavesPerBlock;
   unsigned lds = waves * RING * scfq::kTile;
   if (H == 1) lds += waves * scfq::kHistWords * sizeof(uint32_t);
@@ -966,7 +973,10 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
       });
     }
     c->timing.h2d_bytes += (uint64_t)used;
-    if (it >= 3) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));       // device buffers b were consumed (chunk 0 had its own)
+    // device buffers b were consumed.  Chunk 0 had compressed / inflated buffers of its own but shares the block table d_blk[0] with
+    // chunk 2: the wait holds from the third chunk on (chunk 0's inflate finished long before — the wait costs nothing — but nothing
+    // else orders chunk 2's table copy behind chunk 0's kernel when the compute stream is held up by other sessions)
+    if (it >= 2) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_scanned[b], 0));
     if (timing) {
       while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
       HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
@@ -1081,6 +1091,11 @@ int64_t scfq_debug_stages(char* buf, uint64_t cap) {
   return (int64_t)js.size();
 }
 void scfq_debug_stage_mark(const char* what) { if (what) trace(what); }
+int64_t scfq_debug_last_scan_kernel(char* buf, uint64_t cap) {
+  const size_t n = std::strlen(g_last_scan);
+  if (buf && cap > n) std::memcpy(buf, g_last_scan, n + 1);
+  return (int64_t)n;
+}
 
 uint64_t scfq_device_bytes_high_water(void) { return g_dev_high.load(); }
 uint64_t scfq_device_bytes_now(void) { return g_dev_bytes.load(); }

@@ -44,7 +44,7 @@ EXPORTS = [
     "scfq_comm_unique_id", "scfq_comm_init_rank", "scfq_comm_init_rendezvous", "scfq_comm_init_all", "scfq_comm_world",
     "scfq_comm_rank", "scfq_comm_is_broken", "scfq_prepare", "scfq_comm_transport", "scfq_comm_exchange", "scfq_comm_exchange_start", "scfq_comm_exchange_finish",
     "scfq_comm_allgather_u64", "scfq_comm_destroy", "scfq_comm_error_detail", "scfq_debug_stages", "scfq_debug_stage_mark",
-    "scfq_debug_gz_member_boundary", "scfq_debug_gz_shard_fix",
+    "scfq_debug_gz_member_boundary", "scfq_debug_gz_shard_fix", "scfq_debug_last_scan_kernel",
 ]
 
 
@@ -455,6 +455,17 @@ def debug_read_file(path, cap, chunk_bytes=0):
 def debug_stream_ms(dev_ptr, n, reps=5):
     """diagnostic: ms for the scan kernel's load structure alone (4 KiB-aligned device pointer)"""
     return lib().scfq_debug_stream_ms(ctypes.c_void_p(dev_ptr), n, reps)
+
+
+def debug_last_scan_kernel():
+    """diagnostic: the scan kernel instance + range geometry of this thread's last launch, e.g.
+    'fq_scan_tiles<false, 0, 2, true, false> tiles_per_range=100'"""
+    L = lib()
+    L.scfq_debug_last_scan_kernel.restype = ctypes.c_int64
+    L.scfq_debug_last_scan_kernel.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+    buf = ctypes.create_string_buffer(256)
+    L.scfq_debug_last_scan_kernel(buf, 256)
+    return buf.value.decode()
 
 
 def combine(acc, b, hist_acc=None, hist_b=None):

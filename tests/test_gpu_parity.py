@@ -64,7 +64,8 @@ def test_golden_files_through_count_file(gpu, scfq, oracle):
 
 @pytest.mark.parametrize("kind", ["uniform", "ascii", "dense_nl", "sparse_nl", "crlf"])
 def test_random_buffers_device_resident(gpu, scfq, oracle, kind):
-    rng = np.random.default_rng(hash(kind) % 2**32)
+    # (a fixed seed per kind: Python's string hash is randomised per process, and a failure must be reproducible on the next box)
+    rng = np.random.default_rng({"uniform": 20260501, "ascii": 20260502, "dense_nl": 20260503, "sparse_nl": 20260504, "crlf": 20260505}[kind])
     sizes = [0, 1, 2, 15, 16, 17, 63, 64, 65, 255, 1023, 4095, 4096, 4097, 8191, 12288, 12289, 40000, 70001, 300000, 1 << 20]
     for n in sizes:
         for offset in (0, 1, 17, 63, 64, 1000, 4095):
