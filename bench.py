@@ -502,16 +502,27 @@ def main():
         done = None
         if len(pending) >= 2:
             pending.pop(0)
-            done = exchanger.wait()
+            done = timed_wait()
         exchanger.submit(p)
         pending.append(1)
         return done, t, pending
+
+    xwait = {"ms": 0.0, "n": 0, "max_ms": 0.0}      # this rank's time inside exchanger.wait(): what the exchange costs the scanning thread
+
+    def timed_wait():
+        t0 = time.perf_counter()
+        r = exchanger.wait()
+        ms = (time.perf_counter() - t0) * 1e3
+        xwait["ms"] += ms
+        xwait["n"] += 1
+        xwait["max_ms"] = max(xwait["max_ms"], ms)
+        return r
 
     def drain(pending):
         out = None
         while pending:
             pending.pop(0)
-            out = exchanger.wait()
+            out = timed_wait()
         return out
 
     def barrier():
@@ -527,6 +538,7 @@ def main():
     if pending:
         counts = drain(pending)
     barrier()
+    xwait.update(ms=0.0, n=0, max_ms=0.0)      # (the warm-up's waits do not count)
     t_start = time.perf_counter()
     kern_ms = 0.0
     fold_ms = 0.0
@@ -543,10 +555,22 @@ def main():
         seen.add((counts.reads, counts.gc_bases, counts.n_bases, counts.bases, counts.lines))
     barrier()
     elapsed = time.perf_counter() - t_start
+    own_elapsed = elapsed
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+    # every rank's own view of the timed region, gathered on the control plane: a curve that bends must say WHERE (a slow shard
+    # generation is not in it, a slow kernel on one device or a rank waiting for the exchange is)
+    mine = {"rank": rank, "device": local_rank, "elapsed_s": round(own_elapsed, 5), "avg_kernel_ms": round(kern_ms / max(1, args.steps), 4),
+            "avg_fold_ms": round(fold_ms / max(1, args.steps), 4), "exchange_wait_ms_per_step": round(xwait["ms"] / max(1, args.steps), 4),
+            "exchange_wait_ms_max": round(xwait["max_ms"], 3), "exchanges_waited_for": xwait["n"], "shard_bytes": shard_n, "generation_s": round(gen_s, 2),
+            "exchange_path": ("none" if not exchange else "library" if isinstance(exchanger, LibExchange) else "torch mirror"),
+            "transport": (exchanger.comm.transport if exchange and isinstance(exchanger, LibExchange) else (args.backend if exchange else "none"))}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     assert len(seen) == 1, ("steps disagree with each other", seen)   # every timed step produced the same counters
     # ---- correctness outside the timed region: generator tallies (independent of the scan) -------------
@@ -609,6 +633,11 @@ def main():
     }
     if exchange_note:
         out["config"]["exchange_note"] = exchange_note
+    if exchange:
+        out["config"]["per_rank"] = per_rank
+    # `--exchange lib` is what the product ships; a rank that ended up on the Python mirror means the library's communicator did not come
+    # up — the line is printed (its numbers are real), and the run then ends non-zero so that nobody reads it as the library's result
+    mirror_fallback = bool(exchange and args.exchange == "lib" and any(r["exchange_path"] != "library" for r in per_rank))
     # the same device's read-stream ceiling: the scan kernel's load structure with no compute (diagnostic kernel)
     al = (-shard_ptr) % 4096
     if shard_n > al + (1 << 20):
@@ -702,6 +731,9 @@ def main():
     if exchange:
         exchanger.close()
         dist.destroy_process_group()
+    if mirror_fallback:
+        sys.stderr.write("bench.py: --exchange lib was asked for and at least one rank ran the torch.distributed mirror (%s): exit 1\n" % (exchange_note or "see config.per_rank"))
+        sys.exit(1)
     if side_leg_failed:
         sys.stderr.write("bench.py: a non-headline leg produced a WRONG RESULT or an unexpected error (see the line's \"fatal\" object): exit 1\n")
         sys.exit(1)

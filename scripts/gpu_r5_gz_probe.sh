@@ -5,7 +5,7 @@
 #   2. the same call with the whole file as ONE batch (SCFQ_GZ_DEVICE_BATCH_SEGMENTS=40000): one decode dispatch of ~37000 segments,
 #      longest first, on 5120 wave slots — what the decode reaches when the device never runs out of waves -> one_batch.txt
 #   3. walls of schedule variants, unprofiled (SCFQ_VERBOSE phases): variants.jsonl
-# usage: scripts/gpu_r5_gz_probe.sh <tag> [inflated bytes] [steps: trace,one,variants]
+# usage: [VARIANTS="name|ENV=..;name2|ENV=.. ENV2=.."] scripts/gpu_r5_gz_probe.sh <tag> [inflated bytes] [steps: trace,one,variants]
 TAG=${1:-r05_gz_probe}; N=${2:-10e9}; STEPS=${3:-trace,one,variants}
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
@@ -29,7 +29,7 @@ trace_one() {      # $1 = sub-directory, further arguments: environment assignme
   find $OUT/$d -name '*.csv' -size +2M -delete
 }
 case ",$STEPS," in *,trace,*)
-  trace_one trace_default SCFQ_NOTHING=1
+  trace_one trace_default ${TRACE_ENV:-SCFQ_NOTHING=1}
   head -c 5000 $OUT/trace_default.txt;;
 esac
 case ",$STEPS," in *,one,*)
@@ -37,10 +37,10 @@ case ",$STEPS," in *,one,*)
   head -c 3000 $OUT/trace_one_batch.txt;;
 esac
 case ",$STEPS," in *,variants,*)
-  for v in "default|SCFQ_NOTHING=1" "slots3|SCFQ_GZ_DEVICE_SLOTS=3" "one_batch|SCFQ_GZ_DEVICE_BATCH_SEGMENTS=40000" "batch2048|SCFQ_GZ_DEVICE_BATCH_SEGMENTS=2048" \
-           "batch2048_slots3|SCFQ_GZ_DEVICE_BATCH_SEGMENTS=2048 SCFQ_GZ_DEVICE_SLOTS=3" "batch8192|SCFQ_GZ_DEVICE_BATCH_SEGMENTS=8192" "default_again|SCFQ_NOTHING=1"; do
+  IFS=';' read -ra VLIST <<< "${VARIANTS:-default|SCFQ_NOTHING=1;slots3|SCFQ_GZ_DEVICE_SLOTS=3;one_batch|SCFQ_GZ_DEVICE_BATCH_SEGMENTS=40000;default_again|SCFQ_NOTHING=1}"
+  for v in "${VLIST[@]}"; do
     name=${v%%|*}; envs=${v#*|}
-    ( export $envs SCFQ_VERBOSE=1; timeout -k 10 200 python3 /tmp/r5_count.py $R $GZ 4 > $OUT/var_$name.out 2> $OUT/var_$name.err )
+    ( export $envs SCFQ_VERBOSE=1; timeout -k 10 200 python3 /tmp/r5_count.py $R $GZ ${REPS:-4} > $OUT/var_$name.out 2> $OUT/var_$name.err )
     echo "== $name ($envs): $(tr '\n' ' ' < $OUT/var_$name.out)" | tee -a $OUT/variants.txt
     grep -E "copy to HBM|segment decode|window chain|wall|copier thread|batch\(es\)|high water" $OUT/var_$name.err | tail -8 >> $OUT/variants.txt
   done;;

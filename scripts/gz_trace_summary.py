@@ -36,25 +36,28 @@ print("# runtime blit kernels in the call (device-to-device one-byte parks etc.)
 dec = [(s, e) for s, e, n, q in call_k if "segment_decode" in n]
 def overlap(a, b):
     return sum(max(0, min(b, e) - max(a, s)) for s, e in dec)
-print("# H2D pieces >= 1 MiB: start ms, ms, MB, GB/s, share of the copy's time with a decode kernel running, agents src->dst")
-big = [c for c in call_c if c[3] >= (1 << 20) and "HOST_TO_DEVICE" in c[2].upper().replace(" ", "_")]
-if not big:
-    big = [c for c in call_c if c[3] >= (1 << 20)]
-tot_b = tot_t = 0
-alone_b = alone_t = beside_b = beside_t = 0
-for s, e, dr, b, sa, da, st in big:
-    ov = overlap(s, e) / max(1, e - s)
-    print("%9.3f %8.3f %8.1f %7.1f  %4.0f %%  %s->%s  %s" % ((s - t0) / 1e6, (e - s) / 1e6, b / 1e6, b / max(1, e - s), 100 * ov, sa, da, dr))
-    tot_b += b; tot_t += e - s
-    if ov > 0.8: beside_b += b; beside_t += e - s
-    elif ov < 0.2: alone_b += b; alone_t += e - s
-if big:
-    span = max(c[1] for c in big) - min(c[0] for c in big)
-    print("# H2D total %.1f MB in %.1f ms of copy time = %.1f GB/s while a copy runs; first start to last end %.1f ms = %.1f GB/s" % (tot_b / 1e6, tot_t / 1e6, tot_b / max(1, tot_t), span / 1e6, tot_b / max(1, span)))
-    if alone_t: print("#   pieces with no decode kernel beside them (<20 %% overlap): %.1f GB/s over %.1f MB" % (alone_b / alone_t, alone_b / 1e6))
-    if beside_t: print("#   pieces beside decode kernels (>80 %% overlap):            %.1f GB/s over %.1f MB" % (beside_b / beside_t, beside_b / 1e6))
-small = [c for c in call_c if c[3] < (1 << 20)]
-print("# %d small copies (< 1 MiB), %.2f ms of copy time in all" % (len(small), sum(e - s for s, e, *_ in small) / 1e6))
+# (this rocprofv3's memory-copy trace carries no byte count: the ring piece's size is given on the command line — SCFQ_VERBOSE prints
+# it — and applies to the pieces whose duration is within 35 % of the median; a batch's last piece is shorter)
+piece_mb = float(sys.argv[2]) if len(sys.argv) > 2 else 128.0
+h2d = [c for c in call_c if "HOST_TO_DEVICE" in c[2].upper() and (c[1] - c[0]) > 300_000]
+print("# H2D copies longer than 0.3 ms (the ring's pieces; agents %s): start ms, ms, GB/s if a full piece of %.0f MiB, share of its time with a decode kernel running" % (sorted(set(c[4] + "->" + c[5] for c in h2d)), piece_mb))
+if h2d:
+    durs = sorted(c[1] - c[0] for c in h2d)
+    med = durs[len(durs) // 2]
+    alone, beside = [], []
+    for s_, e_, dr, b, sa, da, st in h2d:
+        ov = overlap(s_, e_) / max(1, e_ - s_)
+        full = abs((e_ - s_) - med) < 0.35 * med
+        rate = piece_mb * 1.048576e6 / (e_ - s_) if full else 0.0
+        print("%9.3f %8.3f %7s  %4.0f %%" % ((s_ - t0) / 1e6, (e_ - s_) / 1e6, ("%.1f" % rate) if full else "-", 100 * ov))
+        if full: (beside if ov > 0.8 else alone if ov < 0.2 else []).append(rate)
+    span = max(c[1] for c in h2d) - min(c[0] for c in h2d)
+    busy = sum(c[1] - c[0] for c in h2d)
+    print("# %d pieces, %.1f ms of copy time inside %.1f ms from the first piece's start to the last one's end (the engine idle %.1f ms of it)" % (len(h2d), busy / 1e6, span / 1e6, (span - busy) / 1e6))
+    if alone: print("#   full pieces with no decode kernel beside them: %d, %.1f GB/s on average" % (len(alone), sum(alone) / len(alone)))
+    if beside: print("#   full pieces beside decode kernels (> 80 %% of their time): %d, %.1f GB/s on average" % (len(beside), sum(beside) / len(beside)))
+small = [c for c in call_c if (c[1] - c[0]) <= 300_000]
+print("# %d short copies (tables, one-byte parks; <= 0.3 ms each), %.2f ms of copy time in all" % (len(small), sum(c[1] - c[0] for c in small) / 1e6))
 print("# every dispatch >= 0.2 ms, and the decode / search kernels: start ms, ms, kernel, queue")
 for s, e, n, q in call_k:
     if (e - s) > 200_000 or "decode" in n or "search" in n:

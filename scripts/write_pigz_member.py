@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Write the synthetic Illumina stream (BASELINE configs[1], seed 20260101) as ONE gzip member the way pigz does it: zlib level-6 raw
 deflate of 64 MiB pieces on 16 threads, every piece but the last ended with a sync flush, CRC-32 / ISIZE of the whole input.
-usage: write_pigz_member.py <inflated bytes> <out.gz> [--plain out.fq]     prints one JSON line: records, tallies, sizes."""
+usage: write_pigz_member.py <inflated bytes> <out.gz> [--plain out.fq] [--bgzf]     prints one JSON line: records, tallies, sizes.
+--bgzf: the same bytes as a BGZF file instead (members of 65280 bytes, level 6, with the empty end-of-file member)."""
 import json, os, sys, time, zlib
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +23,23 @@ else:
 if "--plain" in sys.argv:
     data.tofile(sys.argv[sys.argv.index("--plain") + 1])
 t0 = time.time()
+if "--bgzf" in sys.argv:
+    import struct
+    def block(b):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = co.compress(b) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(payload) + 8 - 1) + payload +
+                struct.pack("<II", zlib.crc32(b) & 0xFFFFFFFF, len(b)))
+    def span(i):
+        a = data[i:i + (32 << 20)]
+        return b"".join(block(a[o:o + 65280].tobytes()) for o in range(0, a.size, 65280))
+    with ThreadPoolExecutor(16) as ex, open(out, "wb") as f:
+        for s_ in ex.map(span, range(0, data.size, 32 << 20)):
+            f.write(s_)
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    print(json.dumps({"records": plan.records, "gc_bases": info.gc_bases, "n_bases": info.n_bases, "bases": info.bases, "inflated_bytes": int(data.size),
+                      "gz_bytes": os.path.getsize(out), "compress_s": round(time.time() - t0, 1), "format": "bgzf"}))
+    sys.exit(0)
 step = 64 << 20
 cuts = list(range(0, data.size, step))
 def piece(i):

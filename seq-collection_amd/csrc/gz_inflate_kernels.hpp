@@ -42,8 +42,9 @@ __device__ __forceinline__ uint64_t bits64_at(WP words, uint64_t bit) {
 }
 
 constexpr uint32_t kSyncThreads = 256;
-constexpr uint32_t kSyncChunkBits = 32768;      // positions examined between two looks at the survivor list
-constexpr uint32_t kSyncListCap = 1024;
+constexpr uint32_t kSyncChunkBits = 65536;      // positions examined between two looks at the survivor list (r5: twice r2's — see sync_deep_tab)
+constexpr uint32_t kSyncListCap = 512;          // (0.09 % of the positions get that far: ~60 per chunk)
+constexpr uint32_t kSyncDeepSlots = 64;         // candidates of one round of the deep test: one per lane of the workgroup's first wave, 128 bytes of LDS each
 
 // A dynamic block's header at position p: BFINAL, BTYPE = 10, HLIT <= 29, HDIST <= 29, HCLEN, then HCLEN + 4 three-bit code
 // lengths that must form a complete code.  The cheap tests for 32 consecutive positions at once (bit i of the result: position
@@ -57,16 +58,22 @@ __device__ __forceinline__ uint32_t sync_fields32(WP words, uint64_t bit) {
   m &= ~((x >> 9) & (x >> 10) & (x >> 11) & (x >> 12));                  // HDIST <= 29
   return (uint32_t)m;
 }
-// the code-length code of a position that passed sync_fields32: complete (zlib rejects anything else for this code)
+// the code-length code of a position that passed sync_fields32: complete (zlib rejects anything else for this code).
+// The Kraft sum of the HCLEN + 4 three-bit lengths WITHOUT a loop (r5): the 61 bits behind position + 13 come in one fetch; b0 / b1 / b2 hold
+// bit 0 / 1 / 2 of every length at the field's first bit, the seven non-zero values are seven AND patterns of them, and a length v weighs
+// 128 >> v: seven population counts.  The loop it replaces ran HCLEN + 4 = 4 .. 19 times per candidate, each lane of a wave with a
+// different count — a fifth of all bit positions get here, and this sum was two thirds of the search's time.
 template <typename WP>
 __device__ __forceinline__ bool sync_kraft(WP words, uint64_t bit) {
-  const uint32_t hclen = (uint32_t)(bits64_at(words, bit + 13) & 15u) + 4u;
-  const uint64_t w2 = bits64_at(words, bit + 17);
-  uint32_t kraft = 0;
-  for (uint32_t k = 0; k < hclen; ++k) {
-    const uint32_t l = (uint32_t)(w2 >> (3u * k)) & 7u;
-    kraft += l ? (128u >> l) : 0u;
-  }
+  const uint64_t w = bits64_at(words, bit + 13);
+  const uint32_t hclen = ((uint32_t)w & 15u) + 4u;
+  const uint64_t fm = 0x1249249249249249ull & ((1ull << (3u * hclen)) - 1ull);       // first bit of each of the HCLEN + 4 fields (3 x 19 = 57 bits at most)
+  const uint64_t w2 = w >> 4;
+  const uint64_t b0 = w2 & fm, b1 = (w2 >> 1) & fm, b2 = (w2 >> 2) & fm;
+  const uint64_t n0 = ~b0, n1 = ~b1, n2 = ~b2;
+  const uint32_t kraft = 64u * (uint32_t)__popcll(b0 & n1 & n2) + 32u * (uint32_t)__popcll(n0 & b1 & n2) + 16u * (uint32_t)__popcll(b0 & b1 & n2) +
+                         8u * (uint32_t)__popcll(n0 & n1 & b2) + 4u * (uint32_t)__popcll(b0 & n1 & b2) + 2u * (uint32_t)__popcll(n0 & b1 & b2) +
+                         (uint32_t)__popcll(b0 & b1 & b2);
   return kraft == 128u;
 }
 
@@ -147,16 +154,117 @@ __device__ inline bool sync_deep(WP words, uint64_t bit, uint64_t end_bit, uint3
   return kraft_d == 32768u || n_d == 0 || (n_d == 1 && max_d == 1);
 }
 
+// The deep test, r5 form.  Cycle stamps over the r2 kernel (make sprof; profiles/r05/gz_search_cycles.txt) put 87 % of a search's
+// time HERE although only 30 of a chunk's 32768 positions get this far: a lane walks its candidate's code lengths one canonical bit
+// at a time behind a 133-step sort of the 19 code-length symbols, seven lanes of a wave at work, the wave as slow as its slowest.
+// Now: (1) the code-length code becomes a 128-entry byte table in LDS, indexed by the next 7 bits MSB-first — canonical codes of one
+// symbol are then a contiguous, aligned run, written with at most four wide stores; (2) a code length costs one table read; (3) the
+// stream comes through a 64-bit buffer refilled every few codes; (4) the candidates of a chunk twice as long go through ONE round on
+// the lanes of the first wave (the other three wait at the barrier and cost nothing).  Same accept / reject decisions as sync_deep.
+// inverse of kClOrder: the field (0 .. 18) of the HCLEN list that holds the length of code-length symbol s
+constexpr uint8_t kClField[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
+template <typename WP>
+__device__ inline bool sync_deep_tab(WP words, uint64_t bit, uint64_t end_bit, uint32_t lit_mask, uint8_t* tab /* 128 bytes of LDS, this lane's */) {
+  const uint64_t w = bits64_at(words, bit);
+  const uint32_t hlit = (uint32_t)((w >> 3) & 31u) + 257u, hdist = (uint32_t)((w >> 8) & 31u) + 1u, hclen = (uint32_t)((w >> 13) & 15u) + 4u;
+  const uint64_t w2 = bits64_at(words, bit + 17) & ((1ull << (3u * hclen)) - 1ull);        // fields behind HCLEN + 4 read as length 0
+  // symbols per code length (the population counts of sync_kraft), first code of every length
+  uint32_t nc[8];
+  {
+    const uint64_t fm = 0x1249249249249249ull;
+    const uint64_t b0 = w2 & fm, b1 = (w2 >> 1) & fm, b2 = (w2 >> 2) & fm, n0 = ~b0 & fm, n1 = ~b1 & fm, n2 = ~b2 & fm;
+    const uint32_t c1 = (uint32_t)__popcll(b0 & n1 & n2), c2 = (uint32_t)__popcll(n0 & b1 & n2), c3 = (uint32_t)__popcll(b0 & b1 & n2), c4 = (uint32_t)__popcll(n0 & n1 & b2),
+                   c5 = (uint32_t)__popcll(b0 & n1 & b2), c6 = (uint32_t)__popcll(n0 & b1 & b2);
+    nc[1] = 0; nc[2] = c1 << 1; nc[3] = (nc[2] + c2) << 1; nc[4] = (nc[3] + c3) << 1; nc[5] = (nc[4] + c4) << 1; nc[6] = (nc[5] + c5) << 1; nc[7] = (nc[6] + c6) << 1;
+  }
+  // (the code is complete — sync_kraft — so the runs below tile the 128 entries exactly)
+  uint64_t ncp = 0;                                        // next code of length l in bits [8 l, 8 l + 8)
+#pragma unroll
+  for (int l = 1; l <= 7; ++l) ncp |= (uint64_t)nc[l] << (8 * l);
+#pragma unroll
+  for (int sy = 0; sy < 19; ++sy) {
+    const uint32_t l = (uint32_t)(w2 >> (3u * kClField[sy])) & 7u;
+    if (l) {
+      const uint32_t code = (uint32_t)(ncp >> (8u * l)) & 0xFFu;
+      ncp += 1ull << (8u * l);
+      const uint32_t run = 128u >> l, at = code << (7u - l);                   // entries [at, at + run), at a multiple of run
+      const uint32_t e = ((uint32_t)sy << 3) | l, e4 = e * 0x01010101u;
+      if (run >= 16u) {
+        for (uint32_t o = 0; o < run; o += 16u) *reinterpret_cast<uint4*>(tab + at + o) = make_uint4(e4, e4, e4, e4);
+      } else if (run == 8u) {
+        *reinterpret_cast<uint2*>(tab + at) = make_uint2(e4, e4);
+      } else if (run == 4u) {
+        *reinterpret_cast<uint32_t*>(tab + at) = e4;
+      } else if (run == 2u) {
+        *reinterpret_cast<uint16_t*>(tab + at) = (uint16_t)e4;
+      } else {
+        tab[at] = (uint8_t)e;
+      }
+    }
+  }
+  uint64_t base = bit + 17 + 3u * hclen;                  // the stream: 64 bits at `base`, `used` of them taken
+  if (base + 128 > end_bit) return false;
+  uint64_t bb = bits64_at(words, base);
+  uint32_t used = 0;
+  const uint32_t total = hlit + hdist;
+  uint32_t k = 0, prev = 0, kraft_l = 0, kraft_d = 0, n_d = 0, max_d = 0, len256 = 0;
+  while (k < total) {
+    if (used > 48u) {                                      // (a code and its extra bits take 14 bits at most)
+      base += used; used = 0;
+      if (base + 128 > end_bit) return false;
+      bb = bits64_at(words, base);
+    }
+    const uint32_t x = (uint32_t)(bb >> used);
+    const uint32_t e = tab[__builtin_bitreverse32(x) >> 25];
+    const uint32_t cl = e & 7u, sym = e >> 3;
+    const uint32_t xb = x >> cl;
+    uint32_t rep = 1, val = sym, take = cl;
+    if (sym == 16) { if (k == 0) return false; val = prev; rep = 3 + (xb & 3u); take += 2; }
+    else if (sym == 17) { val = 0; rep = 3 + (xb & 7u); take += 3; }
+    else if (sym == 18) { val = 0; rep = 11 + (xb & 127u); take += 7; }
+    used += take;
+    if (k + rep > total) return false;
+    if (val) {
+      // the run [k, k + rep) may straddle the literal/length | distance border
+      const uint32_t in_l = k >= hlit ? 0u : (k + rep <= hlit ? rep : hlit - k), in_d = rep - in_l;
+      kraft_l += in_l * (32768u >> val);
+      kraft_d += in_d * (32768u >> val);
+      if (kraft_l > 32768u || kraft_d > 32768u) return false;          // over-subscribed: no need to read on
+      if (k <= 256u && 256u < k + rep) len256 = val;
+      if (lit_mask && k < 256u) {
+        // literals [k, min(k + rep, 256)) get a code: none of them may lie in a masked 32-value class
+        const uint32_t hi = (k + rep < 256u ? k + rep : 256u) - 1u, c0 = k >> 5, c1 = hi >> 5;
+        const uint32_t span = (c1 >= 31u ? 0xFFFFFFFFu : ((2u << c1) - 1u)) & ~((1u << c0) - 1u);
+        if (lit_mask & span) return false;
+      }
+      if (in_d) { n_d += in_d; max_d = val > max_d ? val : max_d; }
+    }
+    k += rep;
+    prev = val;
+  }
+  if (len256 == 0 || kraft_l != 32768u) return false;
+  return kraft_d == 32768u || n_d == 0 || (n_d == 1 && max_d == 1);
+}
+
 // found[s] = first bit position >= from[s] (and < from[s] + max_bits, < end_bit) that passes; ~0 when none does.
 // Every chunk of 32768 positions is first STAGED in LDS (4.7 KiB: the chunk and the longest block header behind its last
 // position), one coalesced pass, and both tests read it from there: straight from global memory each of the 128 steps of the
 // quick test and each code length of the deep one was a memory round trip (6.2 ms for 4096 searches over 0.5 GB).
-constexpr uint32_t kSyncStageWords = 600;       // 512 words of positions + 1 (the chunk starts inside a word) + 4600 bits of header + spare
+#ifdef SCFQ_SPROF      // measurement builds only (make sprof): where the search's cycles go, summed over all workgroups (thread 0's clock)
+__device__ unsigned long long g_sprof[8];      // stage, fields + Kraft, deep test, chunks, list entries, workgroups
+#define SCFQ_SP_T(var_) const uint64_t var_ = __builtin_readcyclecounter()
+#define SCFQ_SP_ADD(slot_, v_) do { if (threadIdx.x == 0) atomicAdd(&g_sprof[slot_], (unsigned long long)(v_)); } while (0)
+#else
+#define SCFQ_SP_T(var_) do {} while (0)
+#define SCFQ_SP_ADD(slot_, v_) do {} while (0)
+#endif
+constexpr uint32_t kSyncStageWords = kSyncChunkBits / 64 + 80;       // the chunk's words + 1 (the chunk starts inside a word) + 4600 bits of header + 128 bits of look-ahead + spare
 __global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* __restrict__ words, uint64_t end_bit, const uint64_t* __restrict__ from,
                                                               uint32_t n_seg, uint64_t max_bits, uint64_t* __restrict__ found, uint32_t lit_mask) {
   __shared__ uint32_t list[kSyncListCap];
   __shared__ uint32_t n_list, best;
   __shared__ uint64_t stage[kSyncStageWords];
+  __shared__ __attribute__((aligned(16))) uint8_t dtab[kSyncDeepSlots * 128];
   typedef __attribute__((address_space(3))) const uint64_t* lds_words;
   const lds_words sw = (lds_words)(uintptr_t)(uint32_t)(uintptr_t)stage;
   const uint32_t s = blockIdx.x;
@@ -167,9 +275,11 @@ __global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* _
   uint64_t result = ~0ull;
   for (uint64_t c0 = base; c0 < limit; c0 += kSyncChunkBits) {
     const uint64_t w0 = c0 >> 6, bit0 = w0 << 6;                         // staged word k = words[w0 + k]; a position p is bit p - bit0 of the stage
+    SCFQ_SP_T(sp0);
     if (threadIdx.x == 0) { n_list = 0; best = 0xFFFFFFFFu; }
     for (uint32_t k = threadIdx.x; k < kSyncStageWords; k += kSyncThreads) stage[k] = w0 + k <= last_word ? words[w0 + k] : 0ull;
     __syncthreads();
+    SCFQ_SP_T(sp1);
     const uint64_t rel_end = end_bit - bit0 < (uint64_t)(kSyncStageWords - 2) * 64u ? end_bit - bit0 : (uint64_t)(kSyncStageWords - 2) * 64u;
     for (uint32_t j = threadIdx.x; j < kSyncChunkBits / 32u; j += kSyncThreads) {
       const uint64_t p0 = c0 + 32u * j;
@@ -187,12 +297,18 @@ __global__ __launch_bounds__(kSyncThreads) void gz_sync_search(const uint64_t* _
       }
     }
     __syncthreads();
+    SCFQ_SP_T(sp2);
     const uint32_t n = n_list < kSyncListCap ? n_list : kSyncListCap;
     // (a list that overflowed lost some LATER candidates of this chunk at worst out of order: every kept one is still
     // tested, the minimum over them is taken, and a missed earlier true block only makes this segment a gap for the host)
-    for (uint32_t t = threadIdx.x; t < n; t += kSyncThreads)
-      if (sync_deep(sw, c0 + list[t] - bit0, rel_end, lit_mask)) atomicMin(&best, list[t]);
+    // (the first wave only: one candidate per lane and round, its table in the lane's own 128 bytes; the other waves go straight to
+    // the barrier — spread over all four, each wave ran the whole walk for a handful of lanes)
+    if (threadIdx.x < kSyncDeepSlots)
+      for (uint32_t t = threadIdx.x; t < n; t += kSyncDeepSlots)
+        if (sync_deep_tab(sw, c0 + list[t] - bit0, rel_end, lit_mask, dtab + threadIdx.x * 128u)) atomicMin(&best, list[t]);
     __syncthreads();
+    SCFQ_SP_T(sp3);
+    SCFQ_SP_ADD(0, sp1 - sp0); SCFQ_SP_ADD(1, sp2 - sp1); SCFQ_SP_ADD(2, sp3 - sp2); SCFQ_SP_ADD(3, 1); SCFQ_SP_ADD(4, n);
     if (best != 0xFFFFFFFFu) { result = c0 + best; break; }       // block-uniform
     __syncthreads();
   }

@@ -59,6 +59,7 @@ thread_local char g_err[512] = "";
 // first 256 of a process: a mark is a clock read and a push) and handed out by scfq_debug_stages() — `sc fq-count --stats` prints them,
 // bench.py's cold legs carry them —, and SCFQ_VERBOSE=1 also writes each one to stderr as it happens.
 const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();
+inline int env_int_early(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
 inline bool trace_on() { static const bool v = std::getenv("SCFQ_VERBOSE") != nullptr; return v; }
 struct StageLog { std::mutex mu; std::vector<std::pair<std::string, double>> v; };
 inline StageLog& stage_log() { static StageLog* g = new StageLog; return *g; }      // (leaked on purpose: marks may come from exit paths)
@@ -92,13 +93,14 @@ struct GzSlot {            // one batch being decoded: symbols + its segment tab
 };
 // Kept between calls, sized by what the batches turn out to need, and never one allocation of tens of GB (scfq_arena.hpp: that was
 // 1.5 - 2.6 s of every first call in round 2).
+constexpr int kGzMaxComp = 8, kGzMaxSlots = 6, kGzDecodeStreams = 3;
 struct GzDevBuffers {
-  DevBuf comp[4];                                                                           // compressed bytes of the four batches in flight (copy + search one ahead of the decode)
-  GzSlot slot[3];                                                                           // symbols of the batches being decoded / resolved (SCFQ_GZ_DEVICE_SLOTS)
-  uint8_t* d_tables = nullptr;  uint64_t tables_cap = 0;        // every table of both slots: one device allocation ...
+  DevBuf comp[kGzMaxComp];                                // compressed bytes of the batches in flight: slots + 2 (copy and search run ahead of the decode)
+  GzSlot slot[kGzMaxSlots];                               // symbols of the batches being decoded / resolved (SCFQ_GZ_DEVICE_SLOTS)
+  uint8_t* d_tables = nullptr;  uint64_t tables_cap = 0;        // every table of all slots: one device allocation ...
   uint8_t* h_tables = nullptr;  uint64_t htables_cap = 0;       // ... and one pinned one (+ the tile CRCs' mirror)
-  uint8_t* d_pmeta[3] = {nullptr, nullptr, nullptr};            // chain, work lists, gap searches of a batch
-  uint8_t* h_pmeta[3] = {nullptr, nullptr, nullptr};
+  uint8_t* d_pmeta[kGzMaxSlots] = {};                     // chain, work lists, gap searches of a batch
+  uint8_t* h_pmeta[kGzMaxSlots] = {};
   DevBuf out;                                             // inflated bytes of one batch (kStagePad in front)
   DevBuf win;                                             // the window in front of every chain entry of one batch
   uint8_t* d_wcarry = nullptr; uint64_t wcarry_cap = 0;  // the window that crosses a batch border (two, alternating)
@@ -108,14 +110,16 @@ struct GzDevBuffers {
   uint8_t* h_crc = nullptr;
   std::vector<void*> retired;                             // buffers replaced by bigger ones during a call: freed when it ends
   bool decode_warmed = false;                             // the decode kernel's first (empty) launch has set the device's scratch up
-  hipStream_t s_search = nullptr, s_gap = nullptr, s_decode[2] = {nullptr, nullptr};
-  hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr}, ev_found[4] = {nullptr, nullptr, nullptr, nullptr}, ev_dec[3] = {nullptr, nullptr, nullptr}, ev_post[3] = {nullptr, nullptr, nullptr};
-  uint8_t* d_search[4] = {nullptr, nullptr, nullptr, nullptr};       // from | found of a batch's block-start search (slices of the tables)
-  uint8_t* h_search[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t s_search = nullptr, s_gap = nullptr, s_decode[kGzDecodeStreams] = {};
+  hipEvent_t ev_copy[kGzMaxComp] = {}, ev_found[kGzMaxComp] = {}, ev_dec[kGzMaxSlots] = {}, ev_post[kGzMaxSlots] = {};
+  uint8_t* d_search[kGzMaxComp] = {};                     // from | found of a batch's block-start search (slices of the tables)
+  uint8_t* h_search[kGzMaxComp] = {};
+  uint8_t* h_ring = nullptr; uint64_t ring_piece = 0;     // the engine's own pinned ring (two pieces) the compressed bytes cross in: ingest_gz_device_batches
+  hipEvent_t ev_ring[2] = {};
   uint64_t held() const {
     uint64_t t = out.cap + win.cap + maps.cap + gwin.cap + crc.cap + wcarry_cap + tables_cap;
-    for (int b = 0; b < 4; ++b) t += comp[b].cap;
-    for (int b = 0; b < 3; ++b) t += slot[b].sym.bytes();
+    for (int b = 0; b < kGzMaxComp; ++b) t += comp[b].cap;
+    for (int b = 0; b < kGzMaxSlots; ++b) t += slot[b].sym.bytes();
     return t;
   }
 };
@@ -276,7 +280,15 @@ int new_ctx(int dev, std::unique_ptr<Ctx>* out) {
   // under another name until a path has a second chunk to move (want_copy_stream()).
   // (r4, measured and dropped: the second stream and the pinned ring created on helper threads beside the first stream — the
   // runtime serialises the three, the context came up in 64 ms instead of 56; profiles/r04/cold_stages_parallel_bringup.jsonl)
-  HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+  {
+    // (SCFQ_COMPUTE_PRIORITY=1: the context's compute stream above the default priority — an A/B knob of the device gzip path, whose
+    // window / resolve / scan kernels share the device with decode kernels on streams of default priority)
+    int least = 0, greatest = 0;
+    if (env_int_early("SCFQ_COMPUTE_PRIORITY", 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      HIPCHK(hipStreamCreateWithPriority(&c->compute, hipStreamNonBlocking, greatest));
+    else
+      HIPCHK(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+  }
   c->copy = c->compute;
   c->copy_is_alias = true;
   trace("  compute stream created");
@@ -1691,6 +1703,9 @@ int scfq_count_file_sharded(const char* path, const scfq_opts* opts, scfq_comm* 
           size_t free_b = 0, total_b = 0;
           const uint64_t lo_b = c_lo.byte, hi_b = c_hi.byte;
           if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+          // (SCFQ_TEST_DEVICE_FREE_GB: the tests' way of putting a rank on a device that is short of memory)
+          static const int test_free_gb = env_int("SCFQ_TEST_DEVICE_FREE_GB", -1);
+          if (test_free_gb >= 0) free_b = std::min<size_t>(free_b, (size_t)test_free_gb << 30);
           if ((hi_b > lo_b ? hi_b - lo_b : 0) * 12 + (16ull << 30) > (uint64_t)free_b) keep_on = false;
         }
         uint64_t out1 = 0;

@@ -20,13 +20,14 @@
 // one half of the pinned ring the compressed bytes of a file cross in (see ingest_gz_device_batches: "the pinned ring")
 inline uint64_t gz_ring_piece(uint64_t comp_bytes, bool context_is_new) {
   static const int ring_env = env_int("SCFQ_GZ_DEVICE_RING_MB", 0);
-  // (r4: files of up to 1 GiB compressed cross in 16 MiB pieces.  Pinning 2 x 64 MiB costs a process 26 ms, 2 x 16 MiB 5 ms — for a
-  // 0.5 GB file the bigger pieces saved 6 ms of copying.  Beyond 1 GiB: 64 MiB pieces in a context's FIRST session — a process's
-  // only one: 2 x 128 MiB were 62 of a 10 GB file's 510 ms — and 128 MiB from its second session on, which is a long-running host,
-  // for which the pieces' size is worth 13 ms per 10 GB: profiles/r04/cold_stages*.jsonl, profiles/r03/gz_device_variants.txt.
-  // A context whose ring is bigger already uses what it has.)
+  // Files of up to 1 GiB compressed cross in 16 MiB pieces (r4: pinning 2 x 64 MiB costs a process 26 ms, 2 x 16 MiB 5 ms — for a 0.5 GB file
+  // the bigger pieces saved 6 ms of copying).  Beyond 1 GiB: 128 MiB pieces — but not in a context's FIRST session, a process's only one,
+  // which stays on the context's 2 x 16 MiB (r5): a process over the 10 GB member takes the same 190 - 260 ms from "context up" to "folded"
+  // with pieces of 16, 32 or 64 MiB (profiles/r05/cold_ring_ab.txt; its pipeline is not bound by the copy), the runtime does nothing else
+  // while it pins — not even queue another thread's copies (profiles/r05/cold_marks.txt) — and a second pinned allocation is 22 - 30 ms.
+  // A long-running host's later sessions get the big pieces, worth 13 ms per 10 GB once everything else is warm.
   return ring_env > 0 ? ((uint64_t)std::min(256, std::max(4, ring_env)) << 20)
-                      : comp_bytes > (1ull << 30) ? (context_is_new ? (64ull << 20) : (128ull << 20)) : (16ull << 20);
+                      : (comp_bytes > (1ull << 30) && !context_is_new) ? (128ull << 20) : (16ull << 20);
 }
 
 inline bool gz_device_enabled() {
@@ -83,14 +84,14 @@ inline void gz_free_retired(GzDevBuffers* g) {
 inline void gz_free(GzDevBuffers* g) {
   note_dev_bytes(-(int64_t)g->held());
   gz_free_retired(g);
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < kGzMaxComp; ++b) {
     g->comp[b].release();
     if (g->ev_copy[b]) (void)hipEventDestroy(g->ev_copy[b]);
     if (g->ev_found[b]) (void)hipEventDestroy(g->ev_found[b]);
     g->ev_copy[b] = g->ev_found[b] = nullptr;
     g->d_search[b] = g->h_search[b] = nullptr;
   }
-  for (int b = 0; b < 3; ++b) {
+  for (int b = 0; b < kGzMaxSlots; ++b) {
     g->slot[b].sym.release();
     g->slot[b].d_meta = g->slot[b].h_meta = nullptr;
     g->d_pmeta[b] = g->h_pmeta[b] = nullptr;
@@ -98,10 +99,13 @@ inline void gz_free(GzDevBuffers* g) {
     if (g->ev_post[b]) (void)hipEventDestroy(g->ev_post[b]);
     g->ev_dec[b] = g->ev_post[b] = nullptr;
   }
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < kGzDecodeStreams; ++b) {
     if (g->s_decode[b]) (void)hipStreamDestroy(g->s_decode[b]);
     g->s_decode[b] = nullptr;
   }
+  if (g->h_ring) (void)hipHostFree(g->h_ring);
+  g->h_ring = nullptr; g->ring_piece = 0;
+  for (int b = 0; b < 2; ++b) { if (g->ev_ring[b]) (void)hipEventDestroy(g->ev_ring[b]); g->ev_ring[b] = nullptr; }
   if (g->d_tables) (void)hipFree(g->d_tables);
   if (g->h_tables) (void)hipHostFree(g->h_tables);
   g->d_tables = g->h_tables = g->h_crc = nullptr;
@@ -190,20 +194,24 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // the last segment's block is whole)
   const uint64_t lim_byte = stretch_to ? std::min<uint64_t>(fsize, (sx->stop_bit >> 3) + 1) : fsize;
   int rc;
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < kGzMaxComp; ++b) {
     if (!g.ev_copy[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[b], hipEventDisableTiming));
     if (!g.ev_found[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_found[b], hipEventDisableTiming));
   }
-  for (int b = 0; b < 3; ++b) {
+  for (int b = 0; b < kGzMaxSlots; ++b) {
     if (!g.ev_dec[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_dec[b], hipEventDisableTiming));
     if (!g.ev_post[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_post[b], hipEventDisableTiming));
   }
-  // Two sets of symbols (SCFQ_GZ_DEVICE_SLOTS=3: three).  With two, the decode of batch k + 1 waits for the resolve of batch k - 1, whose
-  // window kernels need 76 KiB of LDS on a CU that decode workgroups still hold (7 - 10 ms): the decode kernels run one after the other
-  // (profiles/r03/gz_timeline.txt).  A third set lets batch k + 1 start behind batch k at once — measured: 157.6 ms against 157.3 for the
-  // 10 GB file with 15.8 instead of 11.5 GB held: the decode kernels overlap, their sum grows from 140 to 185 ms, the call does not get
-  // shorter.  The device is busy either way.
-  static const uint32_t n_slots = env_int("SCFQ_GZ_DEVICE_SLOTS", 2) == 3 ? 3u : 2u;
+  // SETS OF SYMBOLS in flight (SCFQ_GZ_DEVICE_SLOTS = 2 .. 6).  A set is held from a batch's decode to its resolve; the decode of batch k + slots
+  // waits for the resolve of batch k.  The decode kernels are what a warm call consists of, and a decode kernel alone leaves the device
+  // half empty: a batch is ~3700 waves on 5120 slots and lasts as long as its slowest wave (one or two deflate blocks per segment) — the
+  // whole 10 GB member as ONE dispatch of 37066 segments, longest first, takes 53.7 ms where ten batch dispatches one after the other take
+  // 73 (profiles/r05/gz_one_batch.txt).  With the event-driven schedule below, every further set lets one more decode kernel be queued
+  // behind the running ones, so retiring waves are replaced at once; what it costs is 2.4 GB of device memory per set, which a PROCESS
+  // pays for when it exits (the driver wipes what is freed) — so a context's first session, a process's only one, takes fewer sets.
+  static const int slots_env = env_int("SCFQ_GZ_DEVICE_SLOTS", 0);
+  const uint32_t n_slots = (uint32_t)std::min<int>(kGzMaxSlots, std::max(2, slots_env > 0 ? slots_env : (c->n_sessions <= 1 ? env_int("SCFQ_GZ_DEVICE_SLOTS_FIRST", 3) : 3)));
+  const uint32_t n_comp = std::min<uint32_t>(kGzMaxComp, n_slots + 2);      // compressed-byte buffers: the copy and the search run two batches ahead of the decodes
 
   // ---- plan ----------------------------------------------------------------------------------------------------------------
   const uint64_t data0 = (uint64_t)h0;
@@ -264,8 +272,9 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   {
     const uint64_t n_batches = (n_plan + batch_segs - 1) / batch_segs, per = (n_plan + n_batches - 1) / n_batches;
     for (uint64_t at = 0; at < n_plan;) { at = std::min<uint64_t>(n_plan, at + per); bstart.push_back(at); }
-    // (SCFQ_GZ_DEVICE_FIRST_BATCH_DIV=4: the first batch cut in two, a quarter and the rest, so that the device starts sooner — measured
-    // r3: 160.6 ms against 156.4 for the 10 GB file, the decode is what the call waits for: off)
+    // The first batch cut in two, a quarter and the rest (SCFQ_GZ_DEVICE_FIRST_BATCH_DIV=1: not): the first decode starts after 64 MiB have
+    // crossed PCIe instead of 256.  A warm call is bound by the copy and does not notice (r3 / r4 measured it slightly slower with their
+    // schedules: 160.6 against 156.4 ms); a process's first call, whose pipeline starts 50 ms of setup late, gets its first kernel ~8 ms sooner.
     static const int first_div = std::max(1, env_int("SCFQ_GZ_DEVICE_FIRST_BATCH_DIV", 1));
     if (n_batches >= 3 && first_div > 1 && bstart[1] / first_div >= 64) bstart.insert(bstart.begin() + 1, bstart[1] / first_div);
   }
@@ -275,7 +284,13 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // engine's three were half of what a small file's first call paid.  Files of several batches get the engine's own streams: the
   // search of batch k + 1, the decodes of two batches and the post-processing of a third overlap.
   if (nb > 1 && (rc = want_copy_stream(c))) return rc;      // (a file of one batch is a chain: the context's one stream carries all of it)
-  hipStream_t s_search = c->copy, s_dec[2] = {c->compute, c->compute};
+  // ONE decode stream to begin with (SCFQ_GZ_DEVICE_DECODE_STREAMS = 1 .. 3): the batches arrive at the rate the compressed bytes cross PCIe, one per
+  // 7 ms, which is what a decode kernel lasts — in order on one stream they run back to back; on two or three streams (r4: two) the call
+  // is no shorter (88 - 93 ms either way on one box, profiles/r05/gz_schedule_ab.txt) and a process pays 10 - 20 ms per stream it creates.
+  // (a context's first session: one; later sessions add a second, so that a faster link than this box's finds the decode kernels overlapping)
+  static const int dec_env = env_int("SCFQ_GZ_DEVICE_DECODE_STREAMS", 0);
+  const uint32_t n_dec_streams = (uint32_t)std::min<int>(kGzDecodeStreams, std::max(1, dec_env > 0 ? dec_env : (c->n_sessions <= 1 ? 1 : 2)));
+  hipStream_t s_search = c->copy, s_dec[kGzDecodeStreams] = {c->compute, c->compute, c->compute};
   if (nb > 1) {
     if (!g.s_search) {
       // the search's workgroups are small and short, and the decode of the next batch cannot be cut into segments before they are
@@ -285,7 +300,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) HIPCHK(hipStreamCreateWithPriority(&g.s_search, hipStreamNonBlocking, greatest));
       else HIPCHK(hipStreamCreateWithFlags(&g.s_search, hipStreamNonBlocking));
     }
-    for (int b = 0; b < 2; ++b) {
+    for (uint32_t b = 0; b < n_dec_streams; ++b) {
       if (!g.s_decode[b]) {
         // The decode kernels fill the device with waves that run for tens of milliseconds, and whatever else the pipeline launches
         // meanwhile (copies, search, window chain, resolve, CRC, scan) has to get in between.  SCFQ_GZ_DEVICE_RESERVE_CUS=n keeps
@@ -314,6 +329,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       }
       s_dec[b] = g.s_decode[b];
     }
+    for (uint32_t b = n_dec_streams; b < (uint32_t)kGzDecodeStreams; ++b) s_dec[b] = s_dec[b % n_dec_streams];
     s_search = g.s_search;
   }
 
@@ -336,19 +352,41 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       (void)hipGetLastError();
     });
   }
-  // the pinned ring (below) is allocated on a helper thread when it has to grow: pinning 2 x 128 MiB is 25 - 40 ms of a process's first
-  // call, spent under the allocation of the device buffers instead of behind it
+  // ---- the pinned ring the compressed bytes cross in (two pieces: one is filled while the other crosses PCIe).  It belongs to the ENGINE and
+  // its pieces grow with the file (gz_ring_piece: 16 MiB up to 1 GiB compressed, 64 MiB beyond that in a context's first session, 128 MiB
+  // from its second on) — and pinning 2 x 64 MiB costs a process 22 - 34 ms.  Round 4 pinned it on a helper thread under the device
+  // buffers' allocation and then WAITED for it in front of the first copy: 22 of the 50 ms between "context up" and the first byte
+  // moving (profiles/r05/cold_marks_before.txt).  Now a process's first call starts on the context's small ring (2 x 16 MiB, 3 - 5 ms) and
+  // the copier changes over to the big one, between two pieces, as soon as the helper thread has pinned it.
   const uint64_t want_piece = gz_ring_piece(comp, c->n_sessions <= 1);
-  int ring_rc = SCFQ_OK;
-  struct RingHelper { std::thread th; ~RingHelper() { if (th.joinable()) th.join(); } } ring_helper;
-  static const bool ring_on_helper = env_int("SCFQ_GZ_DEVICE_RING_HELPER", 1) != 0;
-  if (ring_on_helper && c->stage_cap < want_piece) {
+  for (int b = 0; b < 2; ++b) if (!g.ev_ring[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_ring[b], hipEventDisableTiming));
+  struct RingMaker {
+    GzDevBuffers& g;
+    std::thread th;
+    std::atomic<int> state{0};           // 0: none asked for / being pinned, 1: ready, 2: refused
+    uint8_t* ring = nullptr;
+    uint64_t piece = 0;
+    void join() { if (th.joinable()) th.join(); }
+    // (on every way out: the thread joined, and a ring that was pinned belongs to the engine from then on — the copier has been joined
+    // by then, nothing reads the fields any more)
+    ~RingMaker() { join(); if (ring && state.load() == 1 && g.h_ring != ring) { if (!g.h_ring) { g.h_ring = ring; g.ring_piece = piece; } else (void)hipHostFree(ring); } }
+  } ring_maker{g};
+  auto start_ring_maker = [&] {
     const int dev = c->dev;
-    ring_helper.th = std::thread([c, want_piece, dev, &ring_rc] {
-      if (hipSetDevice(dev) != hipSuccess) { ring_rc = SCFQ_EHIP; return; }
-      ring_rc = ensure_staging(c, want_piece, true);
+    ring_maker.piece = want_piece;
+    RingMaker* rm = &ring_maker;
+    ring_maker.th = std::thread([rm, dev] {
+      void* p = nullptr;
+      if (hipSetDevice(dev) != hipSuccess || hipHostMalloc(&p, 2 * rm->piece, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); rm->state.store(2, std::memory_order_release); return; }
+      rm->ring = static_cast<uint8_t*>(p);
+      trace("gzip engine: the big pinned ring is there");
+      rm->state.store(1, std::memory_order_release);
     });
-  }
+  };
+  // (an engine whose ring is too small for this file — a long-running host that met a bigger file — waits for the new one below, as round 4
+  // did: pinned under the device buffers' allocation.  A process's FIRST ring is pinned only once those allocations are through — the
+  // runtime takes the two one after the other anyway: side by side, both were done 40 ms later than either alone)
+  if (g.h_ring && g.ring_piece < want_piece) start_ring_maker();
   const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
   const uint64_t comp_pad = 256;
   const uint64_t end_bit = stretch_to ? sx->stop_bit : fsize * 8;
@@ -383,12 +421,12 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
                  offp_gchain = offp_gfound + 8ull * max_seg, offp_gfirst = offp_gchain + sizeof(GzChain) * max_groups,
                  offp_mfirst = offp_gfirst + 4ull * (max_groups + 2), post_meta = offp_mfirst + 4ull * (max_groups + 2) + 64;
   const uint64_t res_crc = 4 * (16 + (comp * kMaxRatio) / kCrcTile + 2ull * n_plan + 4ull * nb + 8192);      // tiles of the whole file + a part per member and batch
-  for (uint32_t b = 0; b < std::min(nb, 4u); ++b) if ((rc = gz_buf(g, g.comp[b], batch_comp_max + comp_pad + 4096))) return rc;
+  for (uint32_t b = 0; b < std::min(nb, n_comp); ++b) if ((rc = gz_buf(g, g.comp[b], batch_comp_max + comp_pad + 4096))) return rc;
   if ((rc = gz_buf(g, g.win, (uint64_t)kGzWindow * max_seg)) || (rc = gz_buf(g, g.crc, res_crc))) return rc;
   trace("gzip engine: compressed-byte, window and CRC buffers allocated");
   {
     // the tables of both slots: ONE device and ONE pinned allocation (a pinned allocation costs milliseconds whatever its size)
-    const uint32_t ns = std::min(nb, n_slots), nq = std::min(nb, 4u);
+    const uint32_t ns = std::min(nb, n_slots), nq = std::min(nb, n_comp);
     const uint64_t per = ((slot_meta + post_meta + 255) & ~255ull), crc_room = (res_crc + 255) & ~255ull;
     const uint64_t t0 = g.tables_cap;
     if ((rc = gz_grow(&g.d_tables, &g.tables_cap, per * ns + search_meta * nq)) || (rc = gz_grow(&g.h_tables, &g.htables_cap, per * ns + search_meta * nq + crc_room, true))) return rc;
@@ -416,11 +454,23 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // decode waves of two batches on the device a piece crosses PCIe at 26 - 30 GB/s instead of 55, every piece costs the copier a
   // round of eight memcpy threads, and the orchestrating thread waited for the copier 94 / 75 / 39 ms of a 10 GB file's 187 / 169 /
   // 156 ms with pieces of 16 / 64 / 128 MiB (profiles/r03/gz_device_variants.txt); pinning 2 x 128 MiB costs a process 40 ms.
-  if (ring_helper.th.joinable()) ring_helper.th.join();
-  rc = ring_rc ? ring_rc : ensure_staging(c, std::max<uint64_t>(c->stage_cap, want_piece), true);
-  if (rc) return rc;
+  struct Ring { uint8_t* half[2] = {nullptr, nullptr}; uint64_t piece = 0; hipEvent_t ev[2] = {nullptr, nullptr}; uint32_t it = 0; };
+  Ring ring_start, ring_big;
+  if (g.ring_piece >= want_piece) {
+    ring_start.half[0] = g.h_ring; ring_start.half[1] = g.h_ring + g.ring_piece; ring_start.piece = g.ring_piece; ring_start.ev[0] = g.ev_ring[0]; ring_start.ev[1] = g.ev_ring[1];
+  } else {
+    if (g.h_ring) {
+      // (an engine whose ring is too small for this file — a long-running host that met a bigger file: wait for the new one, as round 4 did)
+      ring_maker.join();
+      if (ring_maker.state.load() == 1) { (void)hipHostFree(g.h_ring); g.h_ring = ring_maker.ring; g.ring_piece = want_piece; }
+      ring_start.half[0] = g.h_ring; ring_start.half[1] = g.h_ring + g.ring_piece; ring_start.piece = g.ring_piece; ring_start.ev[0] = g.ev_ring[0]; ring_start.ev[1] = g.ev_ring[1];
+    } else {
+      if ((rc = ensure_staging(c, std::max<uint64_t>(c->stage_cap, 16ull << 20), true))) return rc;
+      if (want_piece > c->stage_cap) start_ring_maker();      // (a file whose pieces are no bigger than the context's ring stays on that ring)
+      ring_start.half[0] = c->h_pin[0]; ring_start.half[1] = c->h_pin[1]; ring_start.piece = std::min<uint64_t>(c->stage_cap, want_piece); ring_start.ev[0] = c->ev_copied[0]; ring_start.ev[1] = c->ev_copied[1];
+    }
+  }
   trace("gzip engine: pinned ring ready");
-  const uint64_t pin_chunk = std::max<uint64_t>(want_piece, comp > (256ull << 20) ? std::min<uint64_t>(c->stage_cap, 64ull << 20) : 0);
 
   // ---- measurement aid (SCFQ_VERBOSE): device time of the stages, summed over the batches ---------------------------------------
   struct Span { hipEvent_t a = nullptr, b = nullptr; };
@@ -450,7 +500,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   const char* why = nullptr;             // why a batch was handed to the host (kFallbackRest)
   std::map<uint64_t, double> overflow_mult;      // start bit of a segment that ran out of room -> the multiple of the assumed room it was last given
   double fill_ms = 0, walk_ms = 0, h_copier_wait_ms = 0, h_search_wait_ms = 0, h_dec_wait_ms = 0, h_post_wait_ms = 0;
-  uint32_t pin_it = 0;                   // the pinned staging buffers alternate over the whole file
+  Ring* ring = &ring_start;              // (the copier thread's: the ring in use, its pieces alternating over the whole file)
   std::vector<uint32_t> n_seg_of(nb + 1, 0);
   std::vector<uint64_t> pool_used_of(nb + 1, 0);
   HIPCHK(hipMemsetAsync(g.crc.p, 0, 64, c->compute));          // word 0: the resolve kernels' error status for the whole file
@@ -476,7 +526,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    uint32_t enq = 0, allowed = 4;
+    uint32_t enq = 0, allowed = 4;      // (allowed: set to the number of compressed-byte buffers before the thread starts)
     bool stop = false;
     int rc = SCFQ_OK;
     std::string err;
@@ -500,28 +550,34 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   }
   auto copy_batch = [&](uint32_t k) -> int {       // (runs on the copier thread)
     const auto tf = clk::now();
-    const int cb = (int)(k % 4);
+    const int cb = (int)(k % n_comp);
     const uint64_t b0 = byte0_of(k), b1 = copy_end_of(k);
     if (verbose) { Span sp; (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b); (void)hipEventRecord(sp.a, c->copy); cp.spans.push_back(sp); }
-    for (uint64_t off = b0; off < b1; off += pin_chunk, ++pin_it) {
-      const int pb = (int)(pin_it & 1);
-      const uint64_t len = std::min(pin_chunk, b1 - off);
+    for (uint64_t off = b0, len = 0; off < b1; off += len) {
+      if (ring == &ring_start && !g.h_ring && ring_maker.state.load(std::memory_order_acquire) == 1) {
+        // the big ring is there: from this piece on (what is in flight out of the small one finishes by itself; nobody frees that ring)
+        ring_big.half[0] = ring_maker.ring; ring_big.half[1] = ring_maker.ring + want_piece; ring_big.piece = want_piece; ring_big.ev[0] = g.ev_ring[0]; ring_big.ev[1] = g.ev_ring[1];
+        ring = &ring_big;
+      }
+      const int pb = (int)(ring->it & 1);
+      len = std::min(ring->piece, b1 - off);
       auto t0 = clk::now();
-      if (pin_it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[pb]));
+      if (ring->it >= 2) HIPCHK(hipEventSynchronize(ring->ev[pb]));
       auto t1 = clk::now();
-      copy_file_bytes(fbytes, off, c->h_pin[pb], len);
+      copy_file_bytes(fbytes, off, ring->half[pb], len);
       auto t2 = clk::now();
       if (s_copy2 && len >= (8ull << 20)) {
         // two halves on two streams: two copy engines share the link (SCFQ_GZ_DEVICE_COPY_STREAMS=2, files of several batches)
         const uint64_t h1 = (len / 2 + 4095) & ~4095ull;
-        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)h1, hipMemcpyHostToDevice, c->copy));
-        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0) + h1, c->h_pin[pb] + h1, (size_t)(len - h1), hipMemcpyHostToDevice, s_copy2));
+        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), ring->half[pb], (size_t)h1, hipMemcpyHostToDevice, c->copy));
+        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0) + h1, ring->half[pb] + h1, (size_t)(len - h1), hipMemcpyHostToDevice, s_copy2));
         HIPCHK(hipEventRecord(ev_copy2, s_copy2));
         HIPCHK(hipStreamWaitEvent(c->copy, ev_copy2, 0));      // (everything behind this on the copy stream — and every event recorded there — covers both halves)
       } else {
-        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), c->h_pin[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
+        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), ring->half[pb], (size_t)len, hipMemcpyHostToDevice, c->copy));
       }
-      HIPCHK(hipEventRecord(c->ev_copied[pb], c->copy));
+      ++ring->it;
+      HIPCHK(hipEventRecord(ring->ev[pb], c->copy));
       auto t3 = clk::now();
       cp.evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
       cp.memcpy_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -535,6 +591,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     cp.fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     return SCFQ_OK;
   };
+  cp.allowed = n_comp;
   cp.th = std::thread([&] {
     if (hipSetDevice(c->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(cp.mu); cp.rc = SCFQ_EHIP; cp.err = "hipSetDevice on the copier thread"; cp.cv.notify_all(); return; }
     for (uint32_t k = 0; k < nb; ++k) {
@@ -558,12 +615,12 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     void now() { { std::lock_guard<std::mutex> lk(cp.mu); cp.stop = true; } cp.cv.notify_all(); if (cp.th.joinable()) cp.th.join(); }
     ~CopierJoin() { now(); }
   } copier_join{cp};
-  // the walk of batch k is through: batch k + 4 may take its buffer
-  auto release_comp = [&](uint32_t k) { { std::lock_guard<std::mutex> lk(cp.mu); cp.allowed = std::max(cp.allowed, k + 5); } cp.cv.notify_all(); };
+  // the walk of batch k is through: batch k + n_comp may take its buffer
+  auto release_comp = [&](uint32_t k) { { std::lock_guard<std::mutex> lk(cp.mu); cp.allowed = std::max(cp.allowed, k + n_comp + 1); } cp.cv.notify_all(); };
 
   // ---- stage A(k): the block-start search of batch k, queued behind its copy — launched one iteration before its results are waited for ----
   auto stage_a = [&](uint32_t k) -> int {
-    const int cb = (int)(k % 4);
+    const int cb = (int)(k % n_comp);
     const uint64_t b0 = byte0_of(k), b1 = copy_end_of(k);
     {
       auto t0 = clk::now();
@@ -596,32 +653,17 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     n_planned_total += np;
     return SCFQ_OK;
   };
-  auto stage_a_wait = [&](uint32_t k) -> int {
-    auto t0 = clk::now();
-    HIPCHK(hipEventSynchronize(g.ev_found[k % 4]));
-    h_search_wait_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
-    return SCFQ_OK;
-  };
-
-  static const bool stop_at_border = env_int("SCFQ_GZ_DEVICE_STOP_AT_BORDER", 1) != 0;
   // ---- stage B(k): the segments of batch k (its last one stops at the first start of batch k + 1), decode ---------------------
   auto stage_b = [&](uint32_t k) -> int {
     GzSlot& sl = g.slot[k % n_slots];
-    const uint64_t* h_found = reinterpret_cast<const uint64_t*>(g.h_search[k % 4] + off_found);
+    const uint64_t* h_found = reinterpret_cast<const uint64_t*>(g.h_search[k % n_comp] + off_found);
     GzSeg* h_segs = reinterpret_cast<GzSeg*>(sl.h_meta + off_segs);
     const uint32_t np = (uint32_t)(p1_of(k) - p0_of(k));
     const uint64_t limit = copy_end_of(k) * 8;
-    uint64_t next_first = (k + 1 < nb) ? byte1_of(k) * 8 : end_bit;     // where the last segment stops
-    // (SCFQ_GZ_DEVICE_STOP_AT_BORDER=1: always at the batch's border — the wave runs on to the end of the block that crosses it, which
-    // is where the next batch's first segment starts when the search found that block start; the walk checks it and fills a gap
-    // otherwise.  The decode of batch k then does not wait for the copy and the search of batch k + 1.)
-    if (k + 1 < nb && !stop_at_border) {
-      const uint64_t* nf = reinterpret_cast<const uint64_t*>(g.h_search[(k + 1) % 4] + off_found);
-      const uint32_t npn = (uint32_t)(p1_of(k + 1) - p0_of(k + 1));
-      for (uint32_t s = 0; s < npn; ++s)
-        if (nf[s] != ~0ull) { next_first = nf[s]; break; }
-      if (next_first + 4096 > limit) next_first = byte1_of(k) * 8;      // (too far: stop at the border and let the walk find the gap)
-    }
+    const uint64_t next_first = (k + 1 < nb) ? byte1_of(k) * 8 : end_bit;     // where the last segment stops
+    // (always at the batch's border: the wave runs on to the end of the block that crosses it, which is where the next batch's first
+    // segment starts when the search found that block start; the walk checks it and fills a gap otherwise.  The decode of batch k
+    // then does not wait for the copy and the search of batch k + 1.)
     uint32_t n_seg = 0;
     uint64_t last_start = 0, pool_used = 0;
     for (uint32_t s = 0; s < np; ++s) {
@@ -651,12 +693,12 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     }
     n_seg_of[k] = n_seg;
     pool_used_of[k] = pool_used;
-    hipStream_t sd = s_dec[k & 1];
+    hipStream_t sd = s_dec[k % kGzDecodeStreams];
     if (warm.th.joinable()) warm.th.join();
     if (k >= n_slots) HIPCHK(hipStreamWaitEvent(sd, g.ev_post[k % n_slots], 0));      // the slot's symbols were read by the resolve of the batch that had it before
-    HIPCHK(hipStreamWaitEvent(sd, g.ev_copy[k % 4], 0));
+    HIPCHK(hipStreamWaitEvent(sd, g.ev_copy[k % n_comp], 0));
     if (n_seg) {
-      const uint8_t* vbase = g.comp[k % 4].p - byte0_of(k);
+      const uint8_t* vbase = g.comp[k % n_comp].p - byte0_of(k);
       span_begin(sp_decode, sd);
       HIPCHK(hipMemcpyAsync(sl.d_meta + off_segs, h_segs, sizeof(GzSeg) * n_seg, hipMemcpyHostToDevice, sd));
       hipLaunchKernelGGL(gz_segment_decode, dim3((n_seg + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), kWavesPerWg * kGzWaveLdsBytes, sd,
@@ -816,7 +858,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     uint64_t* h_gfound = reinterpret_cast<uint64_t*>(g.h_pmeta[pp] + offp_gfound);
     uint32_t n_seg = n_seg_of[k];
     uint64_t pool_used = pool_used_of[k];
-    const uint8_t* vbase = g.comp[k % 4].p - byte0_of(k);
+    const uint8_t* vbase = g.comp[k % n_comp].p - byte0_of(k);
     const bool last_batch = k + 1 == nb;
     const uint64_t territory_end = last_batch ? end_bit : byte1_of(k) * 8, limit = copy_end_of(k) * 8;
     struct Entry { uint32_t seg; uint32_t member; };
@@ -1161,41 +1203,39 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     return SCFQ_OK;
   };
 
-  // ---- the pipeline -----------------------------------------------------------------------------------------------------------
+  // ---- the pipeline (r5: event-driven) ------------------------------------------------------------------------------------------------
+  // Three cursors over the batches: ns searches queued, nd decodes queued, nw batches walked.  Whatever CAN be queued is queued, in this
+  // order of urgency: a search as soon as the batch's compressed bytes are on their way (the copier runs n_comp batches ahead of the
+  // walk at most), a decode as soon as its search is through and a set of symbols is free (batch k's set is free once batch
+  // k - n_slots has been walked: its resolve is queued by then, and the decode waits for it on the device), the walk of the oldest batch once its
+  // decode is through.  Round 4's loop did one search, one decode and one walk per iteration in a fixed order, each stage waiting for
+  // its own event: at most two decode kernels were ever queued, and the second only once the first one's predecessor had been walked
+  // — the device ran decode kernels one after the other with gaps of 1 - 3 ms (profiles/r04/gz_timeline_after_border_stop.txt).
   int fail = SCFQ_OK;
-  if (stop_at_border) {
-    // the same stages, the decode of a batch one iteration earlier: A(0), wait, B(0) before anything of batch 1 is waited for
-    for (uint32_t it = 0; it < nb + 1 && !fail; ++it) {
-      { const auto t0 = clk::now();
-        if (it == 0) fail = stage_a(0);
-        if (!fail && it >= 1 && it + 1 < nb) fail = stage_a(it + 1);
-        if (!fail && it < nb) fail = stage_a_wait(it);
-        stage_ms[0] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
-      { const auto t0 = clk::now(); if (it < nb) fail = stage_b(it); stage_ms[1] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
-      if (it == 0 && nb > 1) { fail = stage_a(1); if (fail) break; }
-      if (it >= 1) {
-        { const auto t0 = clk::now(); fail = stage_c(it - 1); stage_ms[2] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
-        if (fail) break;
-        if (finished) break;
+  {
+    uint32_t ns = 0, nd = 0, nw = 0;
+    auto copy_queued = [&](uint32_t k) { std::lock_guard<std::mutex> lk(cp.mu); return cp.enq > k || cp.rc != SCFQ_OK; };
+    auto event_done = [&](hipEvent_t ev, int* err) {
+      const hipError_t e = hipEventQuery(ev);
+      if (e == hipSuccess) return true;
+      (void)hipGetLastError();             // (hipErrorNotReady is remembered as the thread's last error: the launches' checks must not see it)
+      if (e != hipErrorNotReady) { std::snprintf(g_err, sizeof g_err, "hipEventQuery -> %s", hipGetErrorString(e)); *err = SCFQ_EHIP; }
+      return false;
+    };
+    auto timed = [&](int which, auto&& f) { const auto t0 = clk::now(); const int r = f(); stage_ms[which] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); return r; };
+    while (!fail && !finished && nw < nb) {
+      bool progressed = false;
+      while (!fail && ns < nb && ns < nw + n_comp && copy_queued(ns)) { fail = timed(0, [&] { return stage_a(ns); }); ++ns; progressed = true; }
+      while (!fail && nd < ns && nd < nw + n_slots && event_done(g.ev_found[nd % n_comp], &fail)) { fail = timed(1, [&] { return stage_b(nd); }); ++nd; progressed = true; }
+      if (!fail && nw < nd && event_done(g.ev_dec[nw % n_slots], &fail)) { fail = timed(2, [&] { return stage_c(nw); }); ++nw; progressed = true; }
+      if (!fail && !progressed) {
+        // nothing to queue: the next thing to happen is a copy, a search or a decode finishing.  Short sleeps instead of a blocking
+        // wait — whichever of the three comes first is acted on within ~30 us (one host thread; a wait for one event would sit out the others)
+        const auto t0 = clk::now();
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        const double w = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        if (nw < nd) h_dec_wait_ms += w; else if (nd < ns) h_search_wait_ms += w; else h_copier_wait_ms += w;
       }
-    }
-  } else
-  for (uint32_t it = 0; it < nb + 2 && !fail; ++it) {
-    auto timed = [&](int which, int r) { return r; };
-    (void)timed;
-    // copy + search run ONE batch ahead of where their results are needed: the search of batch it + 1 is queued before the host waits
-    // for the search of batch it (launched an iteration ago), so that wait is short even when the decode waves of two batches fill
-    // the device and a search workgroup only gets the slots they leave
-    { const auto t0 = clk::now();
-      if (it == 0) fail = stage_a(0);
-      if (!fail && it + 1 < nb) fail = stage_a(it + 1);
-      if (!fail && it < nb) fail = stage_a_wait(it);
-      stage_ms[0] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
-    { const auto t0 = clk::now(); if (it >= 1 && it - 1 < nb) fail = stage_b(it - 1); stage_ms[1] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); if (fail) break; }
-    if (it >= 2) {
-      { const auto t0 = clk::now(); fail = stage_c(it - 2); stage_ms[2] += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
-      if (fail) break;
-      if (finished) break;              // (trailing garbage may leave batches behind the last member: nothing in them counts)
     }
   }
   copier_join.now();                                    // (batches behind the end of the last member are not copied any more; the ring is free for a hand-over)
@@ -1210,7 +1250,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     // gzread byte for byte, error text included.)
     static const bool resume_on = env_int("SCFQ_GZ_DEVICE_RESUME", 1) != 0;
     if (fail != kFallbackRest || total_out == 0 || !resume_on || sx) return SCFQ_GZ_DECLINE;
-    for (hipStream_t st : {c->copy, s_search, s_dec[0], s_dec[1], c->compute}) HIPCHK(hipStreamSynchronize(st));
+    for (hipStream_t st : {c->copy, s_search, s_dec[0], s_dec[1], s_dec[2], c->compute}) HIPCHK(hipStreamSynchronize(st));
     if ((rc = check_members())) return rc;
     std::vector<uint8_t> window(kGzWindow, 0);
     if (valid) HIPCHK(hipMemcpy(window.data(), g.d_wcarry + (uint64_t)wcarry * kGzWindow, kGzWindow, hipMemcpyDeviceToHost));
@@ -1289,7 +1329,7 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   c->timing.host_fill_ms += fill_ms;
   c->timing.ingest_wall_ms += std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
   if (verbose) {
-    for (hipStream_t st : {c->copy, s_search, s_dec[0], s_dec[1]}) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {c->copy, s_search, s_dec[0], s_dec[1], s_dec[2]}) (void)hipStreamSynchronize(st);
     auto sum = [](const std::vector<Span>& v) { double t = 0; for (const Span& s : v) { float ms = 0; if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) t += ms; } return t; };
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "copy to HBM", sum(sp_copy));
     std::fprintf(stderr, "scfq gzdev: %-28s %8.2f ms\n", "block-start search", sum(sp_search));
@@ -1307,6 +1347,13 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     std::fprintf(stderr, "scfq gzdev: %u batch(es), %u segments planned, %u decoded (%u gap rounds, %u segments given more room), %u on the chain, %zu member(s), %llu bytes inflated%s\n", nb,
                  n_planned_total, n_decoded_total, n_gap_rounds, n_overflows, n_chain_total, member_ends.size(), (unsigned long long)total_out, resumed ? " on the device, the rest on the host" : "");
     std::fprintf(stderr, "scfq gzdev: device memory high water %.2f GB (this path holds %.2f GB now)\n", (double)g_dev_high.load() / 1e9, (double)g.held() / 1e9);
+#ifdef SCFQ_SPROF
+    { unsigned long long w[8]; HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(scfq_dinflate::g_sprof), sizeof w));
+      const double ch = (double)std::max<unsigned long long>(1, w[3]);
+      std::fprintf(stderr, "sprof: %llu chunks of 65536 positions; cycles per chunk (thread 0's clock): stage %.0f, fields + Kraft %.0f, deep test %.0f; %.1f candidates reach the deep test per chunk\n",
+                   w[3], w[0] / ch, w[1] / ch, w[2] / ch, w[4] / ch);
+      unsigned long long z[8] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(scfq_dinflate::g_sprof), z, sizeof z)); }
+#endif
   }
   return SCFQ_OK;
 }
@@ -1338,7 +1385,7 @@ int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags,
   if (c->copy) (void)hipStreamSynchronize(c->copy);
   if (g.s_search) (void)hipStreamSynchronize(g.s_search);
   if (g.s_gap) (void)hipStreamSynchronize(g.s_gap);
-  for (int b = 0; b < 2; ++b) if (g.s_decode[b]) (void)hipStreamSynchronize(g.s_decode[b]);
+  for (int b = 0; b < kGzDecodeStreams; ++b) if (g.s_decode[b]) (void)hipStreamSynchronize(g.s_decode[b]);
   if (c->compute) (void)hipStreamSynchronize(c->compute);
   gz_free_retired(&g);
   {

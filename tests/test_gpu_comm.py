@@ -188,8 +188,14 @@ def test_bench_two_ranks_launched_like_the_driver(gpu):
     assert "configs[2]" in j["config"]["workload"] and j["config"]["seed"] == 20260102
     assert j["counters"]["bases"] > 2 * 2.5e8 / 2.5          # both shards are in the folded result
     assert "scfq_comm" in j["config"]["exchange"] and "exchange_note" not in j["config"]
+    # every rank's own view of the timed region rides on the line (what makes a first 8-GPU curve explain itself)
+    pr = j["config"]["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["exchange_path"] == "library" and r["transport"].startswith("tcp") for r in pr), pr
+    assert all(r["avg_kernel_ms"] > 0 and r["exchanges_waited_for"] == 4 and r["exchange_wait_ms_per_step"] >= 0 and r["shard_bytes"] > 2e8 for r in pr), pr
+    assert max(r["elapsed_s"] for r in pr) * 1e3 / 4 == pytest.approx(j["ms_per_step"], rel=0.02)
     j2 = _bench(["--gpus", "2", "--same-device", "--exchange", "torch", "--bytes-per-gpu", "2.5e8", "--steps", "4", "--warmup", "2"], nproc=2)
     assert j2["counters"] == j["counters"] and "torch.distributed" in j2["config"]["exchange"]
+    assert all(r["exchange_path"] == "torch mirror" for r in j2["config"]["per_rank"])
 
 
 def test_bench_configs2_shape_at_full_shard_size(gpu):

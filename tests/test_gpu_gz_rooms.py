@@ -233,7 +233,20 @@ def test_member_beyond_4_gib(gpu, scfq, tmp_path):
     assert '"input_bytes": %d' % plan.bytes in r.stderr and int(r.stderr.split('"h2d_bytes": ')[1].split(",")[0].rstrip("}")) < plan.bytes // 2, r.stderr[-2000:]
 
 
-def test_configs3_ten_gb_member(gpu, scfq, tmp_path):
+@pytest.fixture(scope="module")
+def configs3_member(gpu, scfq, tmp_path_factory):
+    """BASELINE configs[3]'s file, written once per module: 10 GB of the seed-20260101 stream as ONE gzip member (zlib level 6, written the
+    way pigz does it by 16 threads).  (path, (records, gc, n, bases), inflated bytes)"""
+    plan, info, data = _synth_on_device(scfq, gpu, 20260101, 10e9)
+    f = tmp_path_factory.mktemp("configs3") / "configs3.fq.gz"
+    _pigz_like(str(f), data, level=6)
+    del data
+    yield f, (plan.records, info.gc_bases, info.n_bases, info.bases), plan.bytes
+    if os.path.exists(f):
+        os.remove(f)
+
+
+def test_configs3_ten_gb_member(gpu, scfq, configs3_member):
     """BASELINE configs[3] at its own size: 10 GB of the seed-20260101 stream as ONE gzip member (zlib level 6, written the way pigz
     does it by 16 threads), counted (a) through the device inflate by a fresh `sc fq-count` process and by a second call in this
     process, (b) through the path north_star names — the HOST inflates (SCFQ_GZ_DEVICE=0: the library's parallel reader) into pinned
@@ -241,11 +254,11 @@ def test_configs3_ten_gb_member(gpu, scfq, tmp_path):
     generator's tallies; the scan kernels stay hidden under the host's fill.  (src/fq_count.nim:30-45, gzip_stream.nim:16-17)"""
     import json
     import time
-    plan, info, data = _synth_on_device(scfq, gpu, 20260101, 10e9)
-    want = (plan.records, info.gc_bases, info.n_bases, info.bases)
-    f = tmp_path / "configs3.fq.gz"
-    _pigz_like(str(f), data, level=6)
-    del data
+    f, want, n_inflated = configs3_member
+
+    class _Plan:
+        bytes = n_inflated
+    plan = _Plan()
 
     def row(r):
         c = r.stdout.strip().split("\t")
@@ -269,3 +282,58 @@ def test_configs3_ten_gb_member(gpu, scfq, tmp_path):
           "ingest wall %.0f ms, host fill %.0f ms, scan kernels %.1f ms"
           % (cold_s, walls[1], plan.bytes / walls[1] / 1e9, st["ingest_wall_ms"], st["host_fill_ms"], st["scan_kernel_ms"]))
     assert walls[1] < 1.0          # (r3: 0.129 s; a regression to the host path's 1.8 s must not pass for the device path)
+
+
+def test_configs3_member_across_ranks(gpu, scfq, configs3_member):
+    """The 10 GB configs[3] member over 2 and 4 `sc fq-count --shard-rank` processes on this one device (TCP transport): a rank's share of
+    the ONE deflate stream is 0.6 - 1.2 GB — several batches of 4096 segments each, the proven symbols of every batch kept across batch
+    pools until the other ranks' window maps arrive (SCFQ_SHARD_GZ_KEEP=1, the default) or decoded a second time (=0), and once with the
+    device reporting too little free memory for the kept symbols, which must send that rank over its stretch twice of its own accord.
+    Row == the generator's tallies, every rank moved its share of the compressed bytes, the member's CRC-32 joined from the stretches
+    (a mismatch would send the file to rank 0: `h2d_bytes` of the others would be 0).  src/fq_count.nim:30-34 over gzread's bytes."""
+    import json
+    import socket
+    import time
+    f, want, n_inflated = configs3_member
+    gz_bytes = os.path.getsize(f)
+
+    def free_port():
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            return s_.getsockname()[1]
+
+    def ranks(world, **env):
+        port = free_port()
+        t0 = time.time()
+        procs = [subprocess.Popen([SC, "fq-count", "--shard-rank=%d" % r, "--shard-world=%d" % world, "--rendezvous=127.0.0.1:%d" % port, "--transport=tcp",
+                                   "--devices=0", "--stats", str(f)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, SCFQ_VERBOSE="1", **env)) for r in reversed(range(world))]
+        outs = [p.communicate(timeout=600) for p in procs][::-1]          # rank order
+        wall = time.time() - t0
+        assert [p.returncode for p in procs] == [0] * world, [o[1][-1500:] for o in outs]
+        c = outs[0][0].strip().split("\t")
+        assert (int(c[0]), int(c[2]), int(c[3]), int(c[4])) == want, (world, env, outs[0][0])
+        stats = [[json.loads(ln) for ln in se.splitlines() if ln.startswith("{")][-1] for _, se in outs]
+        shares = [st["h2d_bytes"] for st in stats]
+        # balanced: every rank moved about a world-th of the compressed bytes (a batch's margin and the cut's block on top)
+        assert all(0.7 * gz_bytes / world < s_ < 1.3 * gz_bytes / world + (16 << 20) for s_ in shares), (world, env, shares, gz_bytes)
+        for _, se in outs:
+            assert "did not join up" not in se and "declined at" not in se, se[-2500:]
+            nb = [int(ln.split(" batch(es)")[0].split()[-1]) for ln in se.splitlines() if " batch(es), " in ln and "segments planned" in ln]
+            assert nb and min(nb) >= 2, (world, env, nb)                 # several batches per stretch (and per pass)
+        return wall, stats, outs
+
+    rows = []
+    for world, keep in ((2, "1"), (4, "1"), (4, "0")):
+        wall, stats, outs = ranks(world, SCFQ_SHARD_GZ_KEEP=keep)
+        passes = [sum(1 for ln in se.splitlines() if " batch(es), " in ln and "segments planned" in ln) for _, se in outs]
+        assert passes == [1 if keep == "1" else 2] * world, (world, keep, passes)
+        rows.append((world, keep, wall, [round(st["ingest_wall_ms"]) for st in stats]))
+    # a device that reports 20 GB free (SCFQ_TEST_DEVICE_FREE_GB): the kept symbols of a 0.6 GB stretch + the pipeline's 16 GB do not fit,
+    # so every rank goes over its stretch twice although keeping was asked for
+    wall, stats, outs = ranks(4, SCFQ_SHARD_GZ_KEEP="1", SCFQ_TEST_DEVICE_FREE_GB="20")
+    passes = [sum(1 for ln in se.splitlines() if " batch(es), " in ln and "segments planned" in ln) for _, se in outs]
+    assert passes == [2] * 4, passes
+    rows.append((4, "1, short of memory", wall, [round(st["ingest_wall_ms"]) for st in stats]))
+    for world, keep, wall, ing in rows:
+        print("configs[3] member across %d ranks on one device (keep=%s): %.2f s for the group of processes, ingest wall per rank %s ms" % (world, keep, wall, ing))
