@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SC = os.path.join(ROOT, "seq-collection_amd", "sc")
 n = sys.argv[1] if len(sys.argv) > 1 else "10e9"
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-variants = [(v.split("|")[0], dict(kv.split("=", 1) for kv in v.split("|")[1].split())) for v in (sys.argv[3] if len(sys.argv) > 3 else "default|SCFQ_NOTHING=1").split(";")]
+variants = [(v.split("|")[0], dict(kv.split("=", 1) for kv in v.split("|")[1].split())) for v in (sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "x" else "default|SCFQ_NOTHING=1").split(";")]
 gz = "/tmp/cold_ab.fq.gz"
 info = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "write_pigz_member.py"), n, gz] + (["--bgzf"] if len(sys.argv) > 4 and sys.argv[4] == "bgzf" else []),
                                  capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
