@@ -166,12 +166,24 @@ def ingest_rows(scfq, member_bytes, bgzf_bytes):
         walls = [walls[0], min(walls[1:])]
         # a fresh process three times over, each with --stats: the library's stage marks (ms since it was loaded) say where a slow
         # one spent its time — runtime initialisation, context, allocations, first copy, first kernel, fold
-        colds = sorted((run_sc(path, want) for _ in range(3)), key=lambda x: x[0])
+        in_order = [run_sc(path, want) for _ in range(3)]
+        colds = sorted(in_order, key=lambda x: x[0])
         cold = colds[1][0]
+
+        def key_marks(wall, st):
+            # the stamps that tell a slow RUNTIME from a slow library: when hipGetDevice returned, when the context was up, when the first
+            # copy and the first inflate kernel were queued, when the session was folded (ms since the library was loaded)
+            m = dict((n, ms) for n, ms in (st or {}).get("stages_ms") or [])
+            pick = lambda *names: next((round(m[n], 1) for n in names if n in m), None)
+            return {"wall_ms": round(wall * 1e3, 1), "runtime_initialised_ms": pick("runtime initialised (hipGetDevice returned)"), "context_up_ms": pick("context up"),
+                    "first_copy_queued_ms": pick("gzip engine: first batch's compressed bytes queued for the device", "BGZF: first chunk's compressed bytes queued for the device"),
+                    "first_inflate_kernel_queued_ms": pick("gzip engine: first decode kernel queued", "BGZF: first inflate kernel queued"),
+                    "session_folded_ms": pick("session folded"), "row_computed_ms": pick("sc: row computed")}
         rows[name] = {"layout": how, "inflated_bytes": int(data_size), "compressed_bytes": os.path.getsize(path),
                       "cold_process_wall_s": round(cold, 4), "cold_GBps": round(data_size / cold / 1e9, 2),
                       "cold_process_walls_s": {"min": round(colds[0][0], 4), "median": round(colds[1][0], 4), "max": round(colds[2][0], 4),
                                                "what": "three fresh `sc fq-count --stats FILE` processes one after the other; cold_process_wall_s is their median"},
+                      "cold_runs_in_order": [key_marks(w, st) for w, st in in_order],
                       "cold_stages_ms": {"median_run": stage_row(*colds[1]), "slowest_run": stage_row(*colds[2]),
                                          "what": "[stage, ms since the library was loaded] (include/sc_fqcount_debug.h: scfq_debug_stages)"},
                       "first_call_wall_s": round(walls[0], 4), "warm_wall_s": round(walls[1], 4), "warm_GBps": round(data_size / walls[1] / 1e9, 2),

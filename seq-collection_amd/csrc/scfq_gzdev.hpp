@@ -1366,14 +1366,17 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
 int ingest_gz_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, bool timing, uint64_t* end_off = nullptr, int fd = -1, uint64_t fd_off = 0, GzStretch* sx = nullptr) {
   GzShared& gs = gz_shared(c->dev);
   static const int n_engines = std::min((int)GzShared::kMax, std::max(1, env_int("SCFQ_GZ_DEVICE_ENGINES", 4)));
-  const bool big = fsize > (1ull << 30);
+  // (a STRETCH — one rank's share of a sharded member — is never "big" and only waits for a free engine: its call holds the engine across a
+  // collective — the exchange of the window maps —, so ranks that are threads of one process on one device would otherwise wait for each
+  // other's engines until the exchange times out.  More such ranks than engines, SCFQ_GZ_DEVICE_ENGINES = 4, must be separate processes.)
+  const bool big = !sx && fsize > (1ull << 30);
   int e = -1;
   {
     std::unique_lock<std::mutex> lk(gs.mu);
     // (a big file waits for the pool to drain, and while one waits no further small file is admitted: a steady stream of small
     // sessions would otherwise keep n_busy above zero for ever and the big one — which holds its context all along — would starve)
     if (big) ++gs.big_waiting;
-    gs.cv.wait(lk, [&] { return !gs.big_running && (big ? gs.n_busy == 0 : (gs.big_waiting == 0 && gs.n_busy < n_engines)); });
+    gs.cv.wait(lk, [&] { return sx ? gs.n_busy < n_engines : (!gs.big_running && (big ? gs.n_busy == 0 : (gs.big_waiting == 0 && gs.n_busy < n_engines))); });
     if (big) --gs.big_waiting;
     for (int k = 0; k < n_engines; ++k) if (!gs.busy[k]) { e = k; break; }
     gs.busy[e] = true;
