@@ -24,7 +24,8 @@ gz)      # the warm device-gzip call of the 10 GB member: seven calls, twice; th
   REPS=7 VARIANTS="default|SCFQ_NOTHING=1;default_again|SCFQ_NOTHING=1" bash scripts/gpu_r5_gz_probe.sh $TAG/gz 10e9 trace,variants ;;
 gzkernels)   # decode / search / BGZF kernels with bytes per dispatch (the 10 GB member as ONE dispatch; a 6 GB BGZF file)
   bash scripts/gpu_r5_gz_probe.sh $TAG/gz_one 10e9 one
-  bash scripts/gpu_profile_inflate.sh $TAG 2e9 6e9 ;;
+  bash scripts/gpu_profile_inflate.sh $TAG/inflate_2g 2e9
+  bash scripts/gpu_profile_inflate.sh $TAG/inflate_6g 6e9 ;;
 sharded)
   python3 scripts/measure_gz_sharded.py 10e9 gpurun_out/$TAG/gz_sharded.jsonl 2> gpurun_out/$TAG/gz_sharded.err; cut -c1-300 gpurun_out/$TAG/gz_sharded.jsonl ;;
 cold)

@@ -46,6 +46,7 @@ def run(world, **env):
 
 with open(out, "a") as f:
     for world, env in ((1, {}), (2, {}), (4, {}), (4, {"SCFQ_SHARD_GZ_KEEP": "0"}), (2, {"SCFQ_SHARD_GZ_KEEP": "0"}), (1, {})):
+        time.sleep(4.0)      # (the driver wipes what the processes before freed, 16 - 70 GB here, for a second or more: a group that starts into that waits for it)
         row = run(world, **env)
         row.update({"inflated_bytes": info["inflated_bytes"], "gz_bytes": info["gz_bytes"]})
         f.write(json.dumps(row) + "\n")

@@ -1,14 +1,14 @@
 // scfq_gzdev.hpp — host side of the device gzip inflate (kernels: gz_inflate_kernels.hpp).  Included by scfq_api.hip
 // inside its anonymous namespace (uses Ctx, HIPCHK, scan_async, parallel_pieces, kFallbackToHost).
 //
-// ingest_gz_device(): the COMPRESSED file goes through the pinned ring to HBM in BATCHES of 4096 planned segments (128 KiB
-// of compressed data each), and three batches are in flight at once:
-//      batch k+2   copy (copy stream) + block-start search (search stream)
-//      batch k+1   segment decode to 16-bit symbols (one of two decode streams)
-//      batch k     chain walk (host), window chain, resolve, CRC-32 tiles, scan (compute stream)
-// so the PCIe copy and everything behind the decode hide under the decode of the next batches, the decode kernels of two
-// batches overlap (the slow waves at the end of one no longer idle the device), and the device memory in use is that of
-// three batches whatever the size of the file (the one-batch form of this path needed 14 x the compressed size in HBM).
+// ingest_gz_device(): the COMPRESSED file goes through a pinned ring to HBM in BATCHES of 4096 planned segments (64 KiB of compressed
+// data each for files beyond 512 MiB), and the stages of several batches are in flight at once (r5: an event-driven schedule, see "the pipeline"):
+//      copy        a copier thread of its own: file -> pinned ring -> one of slots + 2 compressed-byte buffers (copy stream)
+//      search      block starts behind every planned segment start (search stream, high priority)
+//      decode      one wave per segment, to 16-bit symbols in one of three symbol sets (decode stream)
+//      walk + post chain walk (host), window maps / chain, resolve, CRC-32 tiles, scan (compute stream)
+// so the PCIe copy and everything behind the decode hide under the decodes, and the device memory in use is that of three
+// batches whatever the size of the file (the one-batch form of this path needed 14 x the compressed size in HBM).
 // A decoded segment is only believed when the walk reaches its start bit EXACTLY — from the member's first block, through
 // every segment's end bit, over member trailers and headers, across batch borders — so a false sync, a corrupt block or a
 // truncated file can never contribute a byte: the walk stops there, gaps it can prove (a false sync skipped, the first block
@@ -448,12 +448,9 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   const double alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
   if (verbose) std::fprintf(stderr, "scfq gzdev: plan + tables in %.1f ms: %u batch(es), segments of %llu KiB, %.2f symbols per compressed byte assumed, literal classes the search rules out 0x%02x\n", alloc_ms, nb,
                             (unsigned long long)(seg_bytes >> 10), ratio_est, lit_mask);
-  // the pinned ring the compressed bytes cross in: pieces of 16 MiB (pinning memory costs 160 ms per GB — 21 of a small file's
-  // milliseconds with the host path's 64 MiB pieces); a ring another path of this context has set up already is used as it is
-  // Bigger files, bigger pieces — 64 MiB beyond 256 MiB compressed, 128 MiB beyond 1 GiB (SCFQ_GZ_DEVICE_RING_MB overrides both): with the
-  // decode waves of two batches on the device a piece crosses PCIe at 26 - 30 GB/s instead of 55, every piece costs the copier a
-  // round of eight memcpy threads, and the orchestrating thread waited for the copier 94 / 75 / 39 ms of a 10 GB file's 187 / 169 /
-  // 156 ms with pieces of 16 / 64 / 128 MiB (profiles/r03/gz_device_variants.txt); pinning 2 x 128 MiB costs a process 40 ms.
+  // the ring in use to begin with: the engine's own when it is big enough; else the context's small one, the copier changing over when the
+  // engine's has been pinned (r3: with 16 / 64 / 128 MiB pieces the orchestrating thread of a WARM call waited 94 / 75 / 39 ms for the
+  // copier, profiles/r03/gz_device_variants.txt)
   struct Ring { uint8_t* half[2] = {nullptr, nullptr}; uint64_t piece = 0; hipEvent_t ev[2] = {nullptr, nullptr}; uint32_t it = 0; };
   Ring ring_start, ring_big;
   if (g.ring_piece >= want_piece) {
