@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the symbol loops (SCFQ_INFLATE_LOOP=lanes | dense) on configs[3] (one member, default 10 GB) and on a 4 GB BGZF file;
-# with ablate/libsc_fqcount_hip_noalias.so present (a -DSCFQ_GZ_CLTAB_ALIAS=0 build of the library — `make -C seq-collection_amd noalias` —:
+# with ablate/libsc_fqcount_hip_noalias.so present (a -DSCFQ_GZ_CLTAB_ALIAS=0 build of the library — a make target of rounds 3 and 4; round 5 made the alias unconditional, in bgzf_inflate too —:
 # 16 decode waves per CU instead of 20), that build as well.
 mkdir -p gpurun_out/r03
 A=$PWD/seq-collection_amd/ablate/libsc_fqcount_hip_noalias.so

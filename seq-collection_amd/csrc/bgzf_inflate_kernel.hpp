@@ -50,8 +50,10 @@ enum : uint32_t { kOk = 0, kErrData = 1, kErrLength = 2, kErrCrc = 3 };
 constexpr uint32_t kLit = 1u << 8, kEob = 1u << 9, kVal = 1u << 10, kSub = 1u << 11;
 constexpr int kLitRoot = 10, kDistRoot = 8;
 constexpr int kLitEntries = 1344, kDistEntries = 416;   // first + second level: `enough 288 10 15` = 1334, `enough 32 8 15` = 402
-constexpr int kWaveLdsBytes = 4 * (kLitEntries + kDistEntries + 128 /*code-length table*/) + 320 /*lens*/ + 2 * (320 /*sorted*/ + 32 /*count, offs*/);
-constexpr int kWavesPerWg = 4;      // 16 waves per CU (LDS); 18 waves (2 per workgroup, 5 per SIMD) measured the same: scalar-issue bound
+// A wave's LDS.  The code-length table (128 entries, needed only until the last code length of a block has been read) lies where the distance
+// table is built afterwards (r3 for gz_segment_decode, r5 for bgzf_inflate): 8064 bytes per wave, 32 256 per workgroup of four.
+constexpr int kWaveLdsBytes = 4 * (kLitEntries + kDistEntries) + 320 /*lens*/ + 2 * (320 /*sorted*/ + 32 /*count, offs*/);
+constexpr int kWavesPerWg = 4;      // five workgroups = 20 waves per CU (LDS: 5 x (32 256 + a few hundred bytes of static tables) <= 160 KiB)
 enum : int { kKindCodeLen = 0, kKindLitLen = 1, kKindDist = 2 };
 
 __device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -1025,36 +1027,18 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   const uint32_t b = blockIdx.x * kWavesPerWg + wave;
   uint32_t* lit = lds + wave * (kWaveLdsBytes / 4);
   uint32_t* dist = lit + kLitEntries;
-  uint32_t* cltab = dist + kDistEntries;
-  uint8_t* lens = reinterpret_cast<uint8_t*>(cltab + 128);               // 320 bytes
+  uint32_t* cltab = dist;                                                // (aliased: see kWaveLdsBytes)
+  uint8_t* lens = reinterpret_cast<uint8_t*>(dist + kDistEntries);       // 320 bytes
   uint16_t* sorted = reinterpret_cast<uint16_t*>(lens + 320);
   uint16_t* count = sorted + 320;
   uint16_t* offs = count + 16;
   __shared__ uint32_t build_ok[kWavesPerWg];
   __shared__ uint32_t s_len[32], s_dist[32];           // base << 16 | extra bits << 4 | kVal: table entries minus the code length
-  // CRC-32, four bytes per step: crc_tab[0] is the byte-wise table, crc_tab[k][i] the CRC of byte i followed by k zero bytes;
-  // crc_xp[k] = x^(8 * 2^k) mod P (the shifts that stitch the lanes' slices)
-  __shared__ uint32_t crc_tab[4][256];
-  __shared__ uint32_t crc_xp[20];
-  static_assert(64 * kWavesPerWg == 256, "one table entry per thread");
+  // (r5: the member's CRC-32 is checked by a kernel of its own, bgzf_crc32_members below — its four 1 KiB tables were what kept a fifth
+  // workgroup off every CU, and 20 waves per CU instead of 16 are worth 7 % on the symbol loop)
   if (threadIdx.x < 29) s_len[threadIdx.x] = ((uint32_t)kLenBase[threadIdx.x] << 16) | ((uint32_t)kLenExtra[threadIdx.x] << 4) | kVal;
   if (threadIdx.x < 30) s_dist[threadIdx.x] = ((uint32_t)kDistBase[threadIdx.x] << 16) | ((uint32_t)kDistExtra[threadIdx.x] << 4) | kVal;
-  {
-    uint32_t t = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t = (t >> 1) ^ (0xEDB88320u & (0u - (t & 1u)));
-    crc_tab[0][threadIdx.x] = t;
-    if (threadIdx.x == 0) {
-      uint32_t sq = 1u << 23;                            // x^8
-      for (int k = 0; k < 20; ++k) { crc_xp[k] = sq; sq = gf2_mulmod(sq, sq); }
-    }
-  }
   __syncthreads();
-  for (int k = 1; k < 4; ++k) {
-    const uint32_t t = crc_tab[k - 1][threadIdx.x];
-    crc_tab[k][threadIdx.x] = (t >> 8) ^ crc_tab[0][t & 255u];
-    __syncthreads();
-  }
   if (b >= n_blocks) return;
 
   const Block blk = blocks[b];
@@ -1208,44 +1192,6 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   // bits taken beyond the end of the deflate data (they were trailer bytes, or the clamped load's): the stream is malformed
   if (err == kOk && (uint64_t)ip * 8 - bc > (uint64_t)ip_end * 8) err = kErrData;
   if (err == kOk && pos != isize) err = kErrLength;
-  // ---- CRC-32 of the member ------------------------------------------------------------------------------------------------
-  // Every lane takes the RAW CRC (zero initial value, no final inversion: R(M) = M(x) x^32 mod P) of one slice of a virtual message
-  // "pad zero bytes, then the member's output" whose 64 slices are equally long: leading zeros do not change R, and
-  // R(A || B) = R(A) x^(8|B|) + R(B), so the slices are stitched in six steps of a tree with ONE shift per step (x^(8 per 2^j),
-  // each the square of the one before); crc32(M) = R(M) ^ 0xFFFFFFFF x^(8|M|) ^ 0xFFFFFFFF.  Four bytes per step through the
-  // tables above (the first form of this: bit by bit, 24 vector instructions per byte, a tenth of the kernel's time; and 63
-  // serial products with a shift computed bit by bit for the stitching).
-  if (err == kOk && !(SCFQ_DABLATE & 2)) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)isize, 0x00020000);
-    auto xpow = [&](uint32_t nbytes) {                  // x^(8 nbytes) mod P, nbytes < 2^20
-      uint32_t p = 1u << 31;
-      for (uint32_t k = 0; nbytes && k < 20u; ++k, nbytes >>= 1)      // (the host's planner admits members of at most 64 KiB)
-        if (nbytes & 1u) p = gf2_mulmod(crc_xp[k], p);
-      return p;
-    };
-    const uint32_t per = (((isize + 63u) / 64u) + 3u) & ~3u;            // bytes per lane: whole dwords
-    const uint32_t pad = 64u * per - isize;
-    const uint32_t v0 = lane * per, v1 = v0 + per;                      // the lane's slice of the virtual message
-    const uint32_t lo = v1 <= pad ? 0u : (v0 > pad ? v0 - pad : 0u), hi = v1 <= pad ? 0u : v1 - pad;
-    uint32_t c = 0;
-    uint32_t k = lo;
-    for (; k + 4u <= hi; k += 4u) {
-      c ^= __builtin_amdgcn_raw_buffer_load_b32(crsrc, k, 0, 1 /*sc0*/);
-      c = crc_tab[3][c & 255u] ^ crc_tab[2][(c >> 8) & 255u] ^ crc_tab[1][(c >> 16) & 255u] ^ crc_tab[0][c >> 24];
-    }
-    for (; k < hi; ++k) c = crc_tab[0][(c ^ (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(crsrc, k, 0, 1)) & 255u] ^ (c >> 8);
-    uint32_t shift = xpow(per);
-#pragma unroll
-    for (uint32_t j = 0; j < 6; ++j) {
-      const uint32_t right = (uint32_t)__shfl_down((int)c, 1 << j);
-      c = gf2_mulmod(c, shift) ^ right;                  // (meaningful in the lanes that are multiples of 2^(j+1): lane 0 in the end)
-      shift = gf2_mulmod(shift, shift);
-    }
-    const uint32_t total = uni(c) ^ gf2_mulmod(xpow(isize), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
-    if (total != blk.crc) err = kErrCrc;
-  }
 #undef SCFQ_DREFILL
 #undef SCFQ_DPREFETCH
 #undef SCFQ_DTAKE
@@ -1253,6 +1199,71 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void bgzf_inflate(const uint8_t* 
   if (lane == 0) { atomicAdd(status + 1, n_blk); atomicAdd(status + 2, n_lit); atomicAdd(status + 3, n_match); atomicAdd(status + 4, n_mbytes >> 4); atomicAdd(status + 5, n_overlap); atomicAdd(status + 6, n_long); }
 #endif
   if (lane == 0 && err) atomicOr(status, 1u << err);      // one word for the whole launch: bit k = some block ended with error k
+}
+
+// ---- CRC-32 of every member of a launch (r5: a kernel of its own) ---------------------------------------------------------------------
+// One workgroup per member.  As gz_crc32_tiles: the raw CRC (zero initial value, no final inversion: R(M) = M(x) x^32 mod P) of a virtual
+// message "pad zero bytes, then the member's bytes" of 64 KiB — leading zeros do not change R —, thread t owning the 64-byte pieces t, t + 256,
+// ... (four of them), folded with x^(8 * 16384) per step, the 256 threads shifted to the message's end and xor-ed; then
+// crc32(M) = R(M) ^ 0xFFFFFFFF x^(8 |M|) ^ 0xFFFFFFFF against the member's trailer.  Four bytes per step through LDS tables.
+// A launch that has failed already (a member with corrupt deflate data or a wrong length) keeps its error word as it is.
+constexpr uint32_t kMemberSpan = 1u << 16, kMemberStep = 256u * 64u;
+__global__ __launch_bounds__(256) void bgzf_crc32_members(const uint8_t* __restrict__ out, const Block* __restrict__ blocks, uint32_t n_blocks, uint32_t* status) {
+  __shared__ uint32_t red[256];
+  __shared__ uint32_t tab[4][256];               // tab[0] the byte-wise table, tab[k][i] the CRC of byte i followed by k zero bytes
+  const uint32_t t = threadIdx.x;
+  {
+    uint32_t e = t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e = (e >> 1) ^ (0xEDB88320u & (0u - (e & 1u)));
+    tab[0][t] = e;
+    __syncthreads();
+    for (int k = 1; k < 4; ++k) {
+      const uint32_t q = tab[k - 1][t];
+      tab[k][t] = (q >> 8) ^ tab[0][q & 255u];
+      __syncthreads();
+    }
+  }
+  if (blockIdx.x >= n_blocks) return;            // (workgroup-uniform)
+  const Block blk = blocks[blockIdx.x];
+  const uint32_t n = blk.isize;
+  if (n > kMemberSpan) { if (t == 0) atomicOr(status, 1u << kErrLength); return; }      // (the host's planner admits members of at most 64 KiB)
+  const uint8_t* data = out + blk.out_off;
+  const uint32_t pad = kMemberSpan - n;
+  const uint32_t x_step = x_pow_8n(kMemberStep);
+  uint32_t acc = 0;
+  for (uint32_t st = 0; st < kMemberSpan / kMemberStep; ++st) {
+    const uint32_t v = st * kMemberStep + t * 64u;           // virtual offset of this thread's piece
+    uint32_t c = 0;
+    if (v + 64u <= pad) {
+      // all zeros: contributes nothing
+    } else if (v >= pad) {
+      uint4 q[4];
+      __builtin_memcpy(q, data + (v - pad), 64);             // any alignment
+      const uint32_t w[16] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        c ^= w[j];
+        c = tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24];
+      }
+    } else {
+      for (uint32_t j = 0; j < 64u; ++j) {
+        const uint32_t p = v + j;
+        c = crc_byte(c, p >= pad ? (uint32_t)data[p - pad] : 0u);
+      }
+    }
+    acc = gf2_mulmod(x_step, acc) ^ c;
+  }
+  red[t] = gf2_mulmod(x_pow_8n(64u * (255u - t)), acc);      // thread t's pieces end 64 * (255 - t) bytes before the end of every step
+  __syncthreads();
+  for (uint32_t s2 = 128; s2 > 0; s2 >>= 1) {
+    if (t < s2) red[t] ^= red[t + s2];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const uint32_t total = red[0] ^ gf2_mulmod(x_pow_8n(n), 0xFFFFFFFFu) ^ 0xFFFFFFFFu;
+    if (total != blk.crc && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(status, 1u << kErrCrc);
+  }
 }
 
 }  // namespace scfq_dinflate

@@ -330,12 +330,8 @@ struct GzSegOut {
 };
 enum : uint32_t { kGzOk = 0, kGzMemberEnd = 1, kGzErrData = 2, kGzErrOverflow = 3 };
 
-// A wave's LDS: as bgzf_inflate's, but the code-length table (512 bytes, needed only until the last code length has been read) lies where
-// the distance table is built afterwards: 8064 bytes per wave, twenty waves per CU instead of sixteen.
-#ifndef SCFQ_GZ_CLTAB_ALIAS
-#define SCFQ_GZ_CLTAB_ALIAS 1
-#endif
-constexpr int kGzWaveLdsBytes = kWaveLdsBytes - (SCFQ_GZ_CLTAB_ALIAS ? 512 : 0);
+// A wave's LDS: bgzf_inflate's (the code-length table lies where the distance table is built afterwards: 8064 bytes per wave, twenty waves per CU).
+constexpr int kGzWaveLdsBytes = kWaveLdsBytes;
 __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint8_t* __restrict__ comp, uint64_t comp_bytes, const GzSeg* __restrict__ segs,
                                                                      uint32_t n_seg, uint16_t* syms, GzSegOut* __restrict__ outs, uint32_t serial_loop) {
   extern __shared__ uint32_t lds[];
@@ -344,8 +340,8 @@ __global__ __launch_bounds__(64 * kWavesPerWg) void gz_segment_decode(const uint
   const uint32_t b = blockIdx.x * kWavesPerWg + wave;
   uint32_t* lit = lds + wave * (kGzWaveLdsBytes / 4);
   uint32_t* dist = lit + kLitEntries;
-  uint32_t* cltab = SCFQ_GZ_CLTAB_ALIAS ? dist : dist + kDistEntries;
-  uint8_t* lens = reinterpret_cast<uint8_t*>(dist + kDistEntries + (SCFQ_GZ_CLTAB_ALIAS ? 0 : 128));
+  uint32_t* cltab = dist;
+  uint8_t* lens = reinterpret_cast<uint8_t*>(dist + kDistEntries);
   uint16_t* sorted = reinterpret_cast<uint16_t*>(lens + 320);
   uint16_t* count = sorted + 320;
   uint16_t* offs = count + 16;

@@ -1008,6 +1008,9 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
                          dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
                          d_comp, c->d_blk[b], nb, base, c->d_dstatus, inflate_serial_loop());
       HIPCHK(hipGetLastError());
+      // every member's CRC-32 trailer against its bytes (a kernel of its own since r5: bgzf_inflate_kernel.hpp)
+      hipLaunchKernelGGL(scfq_dinflate::bgzf_crc32_members, dim3(nb), dim3(256), 0, c->compute, base, c->d_blk[b], nb, c->d_dstatus);
+      HIPCHK(hipGetLastError());
       if (first) trace("BGZF: first inflate kernel queued");
       // measurement aid: one line per bgzf_inflate dispatch (members, compressed bytes, inflated bytes), in dispatch order, so
       // that a rocprofv3 kernel trace of the same run can be priced in GB/s per dispatch (scripts/gpu_profile_inflate.sh)
@@ -2061,6 +2064,8 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
                                    dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes,
                                    c->compute, c->d_comp[b], c->d_blk[b], nb, d_buf + off, c->d_dstatus, inflate_serial_loop());
                 HIPCHK(hipGetLastError());
+                hipLaunchKernelGGL(scfq_dinflate::bgzf_crc32_members, dim3(nb), dim3(256), 0, c->compute, d_buf + off, c->d_blk[b], nb, c->d_dstatus);
+                HIPCHK(hipGetLastError());
               }
               HIPCHK(hipEventRecord(c->ev_scanned[b], c->compute));
               pos += (uint64_t)used;
@@ -2219,6 +2224,8 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
     hipLaunchKernelGGL(scfq_dinflate::bgzf_inflate, dim3((nb + scfq_dinflate::kWavesPerWg - 1) / scfq_dinflate::kWavesPerWg),
                        dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
                        d_comp, d_blocks, nb, d_out, d_status, inflate_serial_loop());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(scfq_dinflate::bgzf_crc32_members, dim3(nb), dim3(256), 0, c->compute, d_out, d_blocks, nb, d_status);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(out) + total, d_out, (size_t)ob, hipMemcpyDeviceToHost, c->compute));
     HIPCHK(hipStreamSynchronize(c->compute));

@@ -62,6 +62,20 @@ def test_levels_and_strategies(gpu, oracle, tmp_path):
     check(oracle, f, data)
 
 
+def test_schedule_shapes(gpu, oracle, tmp_path):
+    """the event-driven schedule (r5) at every setting of its rings: 2 .. 6 sets of symbols (compressed-byte buffers: sets + 2, at most 8),
+    1 .. 3 decode streams, the first batch split — a file of several members across ~40 batches of 8 segments, so that every ring wraps many
+    times, with a truncation that must still behave as on the host path; rows == oracle, on the device, several batches"""
+    data = fastq_bytes(9_000_000, seed=57)
+    f = tmp_path / "shapes.fq.gz"
+    f.write_bytes(member(data[:5_000_000]) + member(data[5_000_000:]) + b"\0 trailing")
+    want = oracle.tsv(oracle.count(np.frombuffer(data, dtype=np.uint8))) + "\n"
+    for slots, streams, first_div in ((2, 1, 1), (3, 2, 1), (4, 3, 1), (5, 1, 4), (6, 3, 1), (3, 1, 4)):
+        r = run(f, **dict(BATCH_ENV, SCFQ_GZ_DEVICE_SLOTS=str(slots), SCFQ_GZ_DEVICE_DECODE_STREAMS=str(streams), SCFQ_GZ_DEVICE_FIRST_BATCH_DIV=str(first_div)))
+        assert r.returncode == 0 and r.stdout == want, (slots, streams, first_div, r.stderr[-2000:])
+        assert "on the chain" in r.stderr and " 1 batch(es)" not in r.stderr and "the rest on the host" not in r.stderr, (slots, streams, r.stderr[-1500:])
+
+
 def test_other_corpora(gpu, oracle, tmp_path):
     rng = np.random.default_rng(5)
     corpora = {
