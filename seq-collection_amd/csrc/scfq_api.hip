@@ -148,6 +148,7 @@ struct Ctx {
   int n_cu = 256;
   hipStream_t compute = nullptr, copy = nullptr;
   uint64_t n_sessions = 0;              // sessions begun on this context so far
+  bool bgzf_crc_consts = false;         // bgzf_crc_consts_init has been queued on this context's compute stream
   bool copy_is_alias = false;           // `copy` IS the compute stream (no second chunk has had to move yet): want_copy_stream()
   uint64_t* d_partials = nullptr;
   uint64_t cap_ranges = 0;
@@ -907,6 +908,15 @@ static uint32_t bgzf_members_per_launch(uint64_t inflated_chunk, int launch = 3)
   return (uint32_t)full;
 }
 
+// the powers of x bgzf_crc32_members multiplies with: made once per context, on its compute stream (in front of the kernels that read them)
+inline int bgzf_crc_ready(Ctx* c) {
+  if (c->bgzf_crc_consts) return SCFQ_OK;
+  hipLaunchKernelGGL(scfq_dinflate::bgzf_crc_consts_init, dim3(1), dim3(256), 0, c->compute);
+  HIPCHK(hipGetLastError());
+  c->bgzf_crc_consts = true;
+  return SCFQ_OK;
+}
+
 // first_prev: the byte in front of the first inflated byte (0..255), or -1 when the members start the input (a rank of a sharded
 // BGZF file starts in the middle of the inflated stream: scfq_count_file_sharded)
 int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1, int fd = -1, uint64_t fd_off = 0) {
@@ -1009,6 +1019,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
                          d_comp, c->d_blk[b], nb, base, c->d_dstatus, inflate_serial_loop());
       HIPCHK(hipGetLastError());
       // every member's CRC-32 trailer against its bytes (a kernel of its own since r5: bgzf_inflate_kernel.hpp)
+      if ((rc = bgzf_crc_ready(c))) return rc;
       hipLaunchKernelGGL(scfq_dinflate::bgzf_crc32_members, dim3(nb), dim3(256), 0, c->compute, base, c->d_blk[b], nb, c->d_dstatus);
       HIPCHK(hipGetLastError());
       if (first) trace("BGZF: first inflate kernel queued");
@@ -2064,6 +2075,7 @@ int scfq_stage_file(const char* path, const scfq_opts* opts, void** dptr_out, ui
                                    dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes,
                                    c->compute, c->d_comp[b], c->d_blk[b], nb, d_buf + off, c->d_dstatus, inflate_serial_loop());
                 HIPCHK(hipGetLastError());
+                if ((rc = bgzf_crc_ready(c))) return rc;
                 hipLaunchKernelGGL(scfq_dinflate::bgzf_crc32_members, dim3(nb), dim3(256), 0, c->compute, d_buf + off, c->d_blk[b], nb, c->d_dstatus);
                 HIPCHK(hipGetLastError());
               }
@@ -2225,6 +2237,7 @@ int64_t scfq_debug_bgzf_inflate(const void* image, uint64_t n, void* out, uint64
                        dim3(64 * scfq_dinflate::kWavesPerWg), scfq_dinflate::kWavesPerWg * scfq_dinflate::kWaveLdsBytes, c->compute,
                        d_comp, d_blocks, nb, d_out, d_status, inflate_serial_loop());
     HIPCHK(hipGetLastError());
+    { const int r_ = bgzf_crc_ready(c); if (r_) return r_; }
     hipLaunchKernelGGL(scfq_dinflate::bgzf_crc32_members, dim3(nb), dim3(256), 0, c->compute, d_out, d_blocks, nb, d_status);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(out) + total, d_out, (size_t)ob, hipMemcpyDeviceToHost, c->compute));
