@@ -11,7 +11,13 @@ hist)
     n=hist_f${f}$(echo $w | sed 's/--workload /_/')
     python bench.py --steps 10 --warmup 2 --no-cpu-baseline --ingest-bytes 0 --flags $f $w 2>/dev/null | tail -1 > gpurun_out/$TAG/bench_$n.json
     python -c "import json;d=json.load(open('gpurun_out/$TAG/bench_$n.json'));print('$n',d['ms_per_step'],d['roofline']['frac'],d['roofline'].get('avg_kernel_ms'),d['roofline'].get('avg_fold_ms'))"
-  done; done ;;
+  done; done
+  # K3's exact form (SCFQ_HIST_EXACT; what a range whose guess does not verify is counted again with), the whole workload through it
+  for w in "" "--workload nanopore"; do
+    n=hist_exact$(echo $w | sed 's/--workload /_/')
+    SCFQ_HIST_MODE=exact python bench.py --steps 6 --warmup 2 --no-cpu-baseline --ingest-bytes 0 --flags 1 $w 2>/dev/null | tail -1 > gpurun_out/$TAG/bench_$n.json
+    python -c "import json;d=json.load(open('gpurun_out/$TAG/bench_$n.json'));print('$n',d['ms_per_step'],d['roofline']['frac'],d['roofline'].get('avg_kernel_ms'))"
+  done ;;
 prof)
   bash scripts/gpu_profile.sh $TAG > gpurun_out/$TAG/profile_summary.txt 2>&1
   grep -E "fq_scan_tiles|FETCH|WRITE" gpurun_out/$TAG/profile_summary.txt | head -20 ;;

@@ -87,7 +87,7 @@ constexpr int kExtAt = SCFQ_PARTIAL_WORDS + SCFQ_HIST_WORDS;
 using scfq_arena::DevBuf;
 using scfq_arena::SymPool;
 struct GzSlot {            // one batch being decoded: symbols + its segment tables (device and pinned mirror: slices of GzDevBuffers' tables)
-  SymPool sym;                                            // 16-bit symbols of every segment of the batch, markers in front: chunks of 2 GB
+  SymPool sym;                                            // 16-bit symbols of every segment of the batch, markers in front: chunks of 512 MB
   uint8_t* d_meta = nullptr;
   uint8_t* h_meta = nullptr;
 };

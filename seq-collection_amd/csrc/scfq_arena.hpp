@@ -11,7 +11,7 @@
 // with "invalid value", and kernels over a range whose address had been mapped, unmapped and mapped again summed WRONG bytes.
 //
 // So nothing here needs a large contiguous range:
-//   SymPool   the 16-bit symbols of a batch's segments.  A segment needs ITS symbols in one piece, not the batch: chunks of 1 GB,
+//   SymPool   the 16-bit symbols of a batch's segments.  A segment needs ITS symbols in one piece, not the batch: chunks of 512 MB,
 //             allocated as segments are placed, a segment's offset given relative to the first chunk (the kernels add it to that
 //             base with 64-bit wrap-around: chunks may lie anywhere)
 //   DevBuf    a plain buffer that is REPLACED by a bigger one when a batch needs more; the old one may still be read by a kernel
@@ -48,7 +48,7 @@ struct DevBuf {
 
 class SymPool {
  public:
-  static constexpr uint64_t kChunkSyms = 1ull << 29;      // 1 GB of 16-bit symbols per chunk (about a thousand segments)
+  static constexpr uint64_t kChunkSyms = 1ull << 28;      // 512 MB of 16-bit symbols per chunk (about five hundred segments; r3 - r4: 1 GB — a set of 2.4 GB then held 3)
   void rewind() { cur_ = 0; used_ = 0; }                   // a new batch places its segments from the start again
   uint16_t* base() const { return chunks_.empty() ? nullptr : chunks_[0].p; }
   uint64_t bytes() const { uint64_t t = 0; for (const Chunk& c : chunks_) t += 2 * c.cap; return t; }
