@@ -116,8 +116,10 @@ struct GzDevBuffers {
   uint8_t* h_search[kGzMaxComp] = {};
   uint8_t* h_ring = nullptr; uint64_t ring_piece = 0;     // the engine's own pinned ring (two pieces) the compressed bytes cross in: ingest_gz_device_batches
   hipEvent_t ev_ring[2] = {};
+  uint8_t* fg_stage[2] = {nullptr, nullptr}; uint64_t fg_cap = 0;      // SCFQ_GZ_DEVICE_HOST_WRITES: fine-grained DEVICE memory the host's threads write a batch's bytes into
+  hipEvent_t ev_fg[2] = {};
   uint64_t held() const {
-    uint64_t t = out.cap + win.cap + maps.cap + gwin.cap + crc.cap + wcarry_cap + tables_cap;
+    uint64_t t = out.cap + win.cap + maps.cap + gwin.cap + crc.cap + wcarry_cap + tables_cap + (fg_stage[0] ? 2 * fg_cap : 0);
     for (int b = 0; b < kGzMaxComp; ++b) t += comp[b].cap;
     for (int b = 0; b < kGzMaxSlots; ++b) t += slot[b].sym.bytes();
     return t;

@@ -103,6 +103,13 @@ inline void gz_free(GzDevBuffers* g) {
     if (g->s_decode[b]) (void)hipStreamDestroy(g->s_decode[b]);
     g->s_decode[b] = nullptr;
   }
+  for (int b = 0; b < 2; ++b) {
+    if (g->fg_stage[b]) (void)hipFree(g->fg_stage[b]);
+    g->fg_stage[b] = nullptr;
+    if (g->ev_fg[b]) (void)hipEventDestroy(g->ev_fg[b]);
+    g->ev_fg[b] = nullptr;
+  }
+  g->fg_cap = 0;
   if (g->h_ring) (void)hipHostFree(g->h_ring);
   g->h_ring = nullptr; g->ring_piece = 0;
   for (int b = 0; b < 2; ++b) { if (g->ev_ring[b]) (void)hipEventDestroy(g->ev_ring[b]); g->ev_ring[b] = nullptr; }
@@ -386,7 +393,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // (an engine whose ring is too small for this file — a long-running host that met a bigger file — waits for the new one below, as round 4
   // did: pinned under the device buffers' allocation.  A process's FIRST ring is pinned only once those allocations are through — the
   // runtime takes the two one after the other anyway: side by side, both were done 40 ms later than either alone)
-  if (g.h_ring && g.ring_piece < want_piece) start_ring_maker();
+  static const bool host_writes_early = env_int("SCFQ_GZ_DEVICE_HOST_WRITES", 1) != 0;      // (no ring then: see "SCFQ_GZ_DEVICE_HOST_WRITES" below)
+  if (g.h_ring && g.ring_piece < want_piece && !host_writes_early) start_ring_maker();
   const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
   const uint64_t comp_pad = 256;
   const uint64_t end_bit = stretch_to ? sx->stop_bit : fsize * 8;
@@ -422,6 +430,26 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
                  offp_mfirst = offp_gfirst + 4ull * (max_groups + 2), post_meta = offp_mfirst + 4ull * (max_groups + 2) + 64;
   const uint64_t res_crc = 4 * (16 + (comp * kMaxRatio) / kCrcTile + 2ull * n_plan + 4ull * nb + 8192);      // tiles of the whole file + a part per member and batch
   for (uint32_t b = 0; b < std::min(nb, n_comp); ++b) if ((rc = gz_buf(g, g.comp[b], batch_comp_max + comp_pad + 4096))) return rc;
+  // SCFQ_GZ_DEVICE_HOST_WRITES=1 (files of several batches): no pinned ring and no copy engine between the file and the device — the copier's
+  // threads pread a batch's bytes straight into one of two FINE-GRAINED device buffers (mapped into the process: posted writes over PCIe, one
+  // pass over host memory), and a device-to-device copy moves them into the batch's ordinary buffer, which is what the kernels read (read in
+  // place, uncached, the decode is 12 % slower: profiles/r05/gz_host_writes_ab.txt)
+  static const bool host_writes_env = env_int("SCFQ_GZ_DEVICE_HOST_WRITES", 1) != 0;
+  bool host_writes = host_writes_env && nb > 1;
+  if (host_writes) {
+    const uint64_t want = batch_comp_max + comp_pad + 4096;
+    if (g.fg_cap < want) {
+      for (int b = 0; b < 2; ++b) { if (g.fg_stage[b]) { g.retired.push_back(g.fg_stage[b]); g.fg_stage[b] = nullptr; } }
+      note_dev_bytes(-(int64_t)(2 * g.fg_cap));
+      g.fg_cap = 0;
+      const uint64_t bytes = (want + want / 8 + 4095) & ~4095ull;
+      for (int b = 0; b < 2 && host_writes; ++b)
+        if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g.fg_stage[b]), bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); g.fg_stage[b] = nullptr; host_writes = false; }
+      if (host_writes) { g.fg_cap = bytes; note_dev_bytes((int64_t)(2 * bytes)); }
+      else for (int b = 0; b < 2; ++b) { if (g.fg_stage[b]) (void)hipFree(g.fg_stage[b]); g.fg_stage[b] = nullptr; }
+    }
+    for (int b = 0; b < 2 && host_writes; ++b) if (!g.ev_fg[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_fg[b], hipEventDisableTiming));
+  }
   if ((rc = gz_buf(g, g.win, (uint64_t)kGzWindow * max_seg)) || (rc = gz_buf(g, g.crc, res_crc))) return rc;
   trace("gzip engine: compressed-byte, window and CRC buffers allocated");
   {
@@ -453,7 +481,9 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // copier, profiles/r03/gz_device_variants.txt)
   struct Ring { uint8_t* half[2] = {nullptr, nullptr}; uint64_t piece = 0; hipEvent_t ev[2] = {nullptr, nullptr}; uint32_t it = 0; };
   Ring ring_start, ring_big;
-  if (g.ring_piece >= want_piece) {
+  if (host_writes) {
+    // (no ring at all)
+  } else if (g.ring_piece >= want_piece) {
     ring_start.half[0] = g.h_ring; ring_start.half[1] = g.h_ring + g.ring_piece; ring_start.piece = g.ring_piece; ring_start.ev[0] = g.ev_ring[0]; ring_start.ev[1] = g.ev_ring[1];
   } else {
     if (g.h_ring) {
@@ -550,6 +580,26 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     const int cb = (int)(k % n_comp);
     const uint64_t b0 = byte0_of(k), b1 = copy_end_of(k);
     if (verbose) { Span sp; (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b); (void)hipEventRecord(sp.a, c->copy); cp.spans.push_back(sp); }
+    if (host_writes) {
+      const int sb = (int)(k & 1u);
+      auto t0 = clk::now();
+      if (k >= 2) HIPCHK(hipEventSynchronize(g.ev_fg[sb]));          // the device-to-device copy of batch k - 2 has read this buffer
+      auto t1 = clk::now();
+      for (uint64_t off = b0; off < b1; off += (64ull << 20)) copy_file_bytes(fbytes, off, g.fg_stage[sb] + (off - b0), std::min<uint64_t>(64ull << 20, b1 - off));
+      std::memset(g.fg_stage[sb] + (b1 - b0), 0, comp_pad);
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+      auto t2 = clk::now();
+      HIPCHK(hipMemcpyAsync(g.comp[cb].p, g.fg_stage[sb], (size_t)(b1 - b0 + comp_pad), hipMemcpyDeviceToDevice, c->copy));
+      HIPCHK(hipEventRecord(g.ev_fg[sb], c->copy));
+      cp.evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+      cp.memcpy_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
+      if (verbose) (void)hipEventRecord(cp.spans.back().b, c->copy);
+      HIPCHK(hipEventRecord(g.ev_copy[cb], c->copy));
+      cp.bytes += b1 - b0;
+      if (k == 0) trace("gzip engine: first batch's compressed bytes written to the device");
+      cp.fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
+      return SCFQ_OK;
+    }
     for (uint64_t off = b0, len = 0; off < b1; off += len) {
       if (ring == &ring_start && !g.h_ring && ring_maker.state.load(std::memory_order_acquire) == 1) {
         // the big ring is there: from this piece on (what is in flight out of the small one finishes by itself; nobody frees that ring)
