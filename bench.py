@@ -176,7 +176,8 @@ def ingest_rows(scfq, member_bytes, bgzf_bytes):
             m = dict((n, ms) for n, ms in (st or {}).get("stages_ms") or [])
             pick = lambda *names: next((round(m[n], 1) for n in names if n in m), None)
             return {"wall_ms": round(wall * 1e3, 1), "runtime_initialised_ms": pick("runtime initialised (hipGetDevice returned)"), "context_up_ms": pick("context up"),
-                    "first_copy_queued_ms": pick("gzip engine: first batch's compressed bytes queued for the device", "BGZF: first chunk's compressed bytes queued for the device"),
+                    "first_copy_queued_ms": pick("gzip engine: first batch's compressed bytes written to the device", "gzip engine: first batch's compressed bytes queued for the device",
+                                                 "BGZF: first chunk's compressed bytes queued for the device"),
                     "first_inflate_kernel_queued_ms": pick("gzip engine: first decode kernel queued", "BGZF: first inflate kernel queued"),
                     "session_folded_ms": pick("session folded"), "row_computed_ms": pick("sc: row computed")}
         rows[name] = {"layout": how, "inflated_bytes": int(data_size), "compressed_bytes": os.path.getsize(path),

@@ -28,7 +28,7 @@ for rep in range(2):
             mem = st["device_bytes_high_water"]
             m = dict((k, v) for k, v in st["stages_ms"])
             marks.append({"runtime_up": m.get("runtime initialised (hipGetDevice returned)"), "context_up": m.get("context up"),
-                          "first_copy_queued": m.get("gzip engine: first batch's compressed bytes queued for the device", m.get("BGZF: first chunk's compressed bytes queued for the device")),
+                          "first_copy_queued": m.get("gzip engine: first batch's compressed bytes written to the device", m.get("gzip engine: first batch's compressed bytes queued for the device", m.get("BGZF: first chunk's compressed bytes queued for the device"))),
                           "first_decode_queued": m.get("gzip engine: first decode kernel queued", m.get("BGZF: first inflate kernel queued")),
                           "folded": m.get("session folded"), "row_computed": m.get("sc: row computed"), "ingest_wall_ms": round(st["ingest_wall_ms"], 1)})
         print(json.dumps({"variant": name, "env": env, "walls_ms": walls, "median_ms": sorted(walls)[len(walls) // 2], "device_GB": round(mem / 1e9, 2), "marks": marks}), flush=True)

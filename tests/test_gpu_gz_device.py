@@ -70,10 +70,14 @@ def test_schedule_shapes(gpu, oracle, tmp_path):
     f = tmp_path / "shapes.fq.gz"
     f.write_bytes(member(data[:5_000_000]) + member(data[5_000_000:]) + b"\0 trailing")
     want = oracle.tsv(oracle.count(np.frombuffer(data, dtype=np.uint8))) + "\n"
-    for slots, streams, first_div in ((2, 1, 1), (3, 2, 1), (4, 3, 1), (5, 1, 4), (6, 3, 1), (3, 1, 4)):
-        r = run(f, **dict(BATCH_ENV, SCFQ_GZ_DEVICE_SLOTS=str(slots), SCFQ_GZ_DEVICE_DECODE_STREAMS=str(streams), SCFQ_GZ_DEVICE_FIRST_BATCH_DIV=str(first_div)))
-        assert r.returncode == 0 and r.stdout == want, (slots, streams, first_div, r.stderr[-2000:])
-        assert "on the chain" in r.stderr and " 1 batch(es)" not in r.stderr and "the rest on the host" not in r.stderr, (slots, streams, r.stderr[-1500:])
+    # (the last two: the feed through the pinned ring and the copy engine, r2 - r4's and still what SCFQ_GZ_DEVICE_HOST_WRITES=0 selects, instead
+    # of the host's threads writing fine-grained device memory)
+    for slots, streams, first_div, host_writes in ((2, 1, 1, 1), (3, 2, 1, 1), (4, 3, 1, 1), (5, 1, 4, 1), (6, 3, 1, 1), (3, 1, 4, 1), (3, 1, 1, 0), (5, 2, 4, 0)):
+        r = run(f, **dict(BATCH_ENV, SCFQ_GZ_DEVICE_SLOTS=str(slots), SCFQ_GZ_DEVICE_DECODE_STREAMS=str(streams), SCFQ_GZ_DEVICE_FIRST_BATCH_DIV=str(first_div),
+                          SCFQ_GZ_DEVICE_HOST_WRITES=str(host_writes)))
+        assert r.returncode == 0 and r.stdout == want, (slots, streams, first_div, host_writes, r.stderr[-2000:])
+        assert "on the chain" in r.stderr and " 1 batch(es)" not in r.stderr and "the rest on the host" not in r.stderr, (slots, streams, host_writes, r.stderr[-1500:])
+        assert ("written to the device" in r.stderr) == bool(host_writes), (host_writes, r.stderr[-1500:])
 
 
 def test_other_corpora(gpu, oracle, tmp_path):
