@@ -19,10 +19,11 @@ sys.path.insert(0, sys.argv[1] + "/seq-collection_amd/pyhost")
 import scfq
 for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 3):
     t = time.time(); c = scfq.count_file(sys.argv[2]); print(c.reads, c.input_bytes, round((time.time() - t) * 1e3, 1), "ms", flush=True)
+    time.sleep(0.1)      # (the trace summary finds a call by the pause before it)
 PY
 trace_one() {      # $1 = sub-directory, further arguments: environment assignments
   local d=$1; shift
-  (cd /tmp && export TMPDIR=/tmp && export "$@" && timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/$d -o t -- python3 /tmp/r5_count.py $R $GZ > $OUT/$d.out 2> $OUT/$d.err)
+  (cd /tmp && export TMPDIR=/tmp && export "$@" && timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/$d -o t -- python3 /tmp/r5_count.py $R $GZ ${TRACE_REPS:-4} > $OUT/$d.out 2> $OUT/$d.err)
   cat $OUT/$d.out
   python3 $R/scripts/gz_trace_summary.py $OUT/$d > $OUT/$d.txt
   # (the raw traces are tens of MB: the summaries are what is kept)

@@ -56,6 +56,11 @@ if h2d:
     print("# %d pieces, %.1f ms of copy time inside %.1f ms from the first piece's start to the last one's end (the engine idle %.1f ms of it)" % (len(h2d), busy / 1e6, span / 1e6, (span - busy) / 1e6))
     if alone: print("#   full pieces with no decode kernel beside them: %d, %.1f GB/s on average" % (len(alone), sum(alone) / len(alone)))
     if beside: print("#   full pieces beside decode kernels (> 80 %% of their time): %d, %.1f GB/s on average" % (len(beside), sum(beside) / len(beside)))
+other = [c for c in call_c if (c[1] - c[0]) > 300_000 and "HOST_TO_DEVICE" not in c[2].upper()]
+if other:
+    print("# other copies longer than 0.3 ms (the host-writes feed's staging buffer -> batch buffer, device to device): start ms, ms, direction")
+    for s_, e_, dr, b, sa, da, st in other:
+        print("%9.3f %8.3f  %s" % ((s_ - t0) / 1e6, (e_ - s_) / 1e6, dr))
 small = [c for c in call_c if (c[1] - c[0]) <= 300_000]
 print("# %d short copies (tables, one-byte parks; <= 0.3 ms each), %.2f ms of copy time in all" % (len(small), sum(c[1] - c[0] for c in small) / 1e6))
 print("# every dispatch >= 0.2 ms, and the decode / search kernels: start ms, ms, kernel, queue")

@@ -238,10 +238,22 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // PROCESS pays for: the driver wipes what a process frees at ~20 GB/s after it exits and the next process's allocations wait for
   // it, so `for f in *.gz; do sc fq-count $f; done` spends 1.7 / 0.7 / 0.3 s per file waiting: profiles/r03/gz_segment_size.txt,
   // gz_cold.jsonl)
+  // (r5, with the feed that writes device memory from the host's threads: 128 KiB segments — batches of 512 MiB, half the window-chain steps and
+  // marker symbols per byte — take a warm 10 GB call from 88.7 - 91.8 ms to 84.8 - 86.9, 96 / 160 KiB 87 - 88, 192 KiB 94 - 95, and hold 24.4 GB
+  // where 64 KiB hold 14.7: profiles/r05/gz_final_knobs_ab.txt.  A long-running host takes them from its context's second session on, for a
+  // whole file of more than 1 GiB, when the device has the room; a process's one session keeps 64 KiB — it pays for memory at its exit.)
   const uint64_t target_segs = 4096;
+  bool wide_segments = false;
+  if (seg_kb_env <= 0 && !stretch_from && comp > (1ull << 30) && c->n_sessions > 1) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    static const int test_free_gb = env_int("SCFQ_TEST_DEVICE_FREE_GB", -1);
+    if (test_free_gb >= 0) free_b = std::min<size_t>(free_b, (size_t)test_free_gb << 30);
+    wide_segments = (uint64_t)free_b + g.held() >= (48ull << 30);
+  }
   const uint64_t seg_bytes = seg_kb_env > 0 ? ((((uint64_t)std::max(32, seg_kb_env)) << 10) + 4095) & ~4095ull
                                             : comp <= (512ull << 20) ? std::min<uint64_t>(128u << 10, std::max<uint64_t>(16u << 10, ((comp + target_segs - 1) / target_segs + 4095) & ~4095ull))
-                                                                     : (64u << 10);      // (up to 512 MiB: one batch of ~4096 segments, the device filled once, <= 9 GB held)
+                                                                     : wide_segments ? (128u << 10) : (64u << 10);      // (up to 512 MiB: one batch of ~4096 segments, the device filled once, <= 9 GB held)
   // Output room of a segment = `ratio_est` symbols per compressed byte it spans + 128 Ki (it runs on to the end of a block),
   // behind its 32768 markers.  ratio_est comes from the file itself: the host inflates the first 192 KiB of the first member
   // (a millisecond) and adds a third; a segment that needs more ends with kGzErrOverflow and is decoded again, alone, with four
@@ -853,6 +865,8 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     if (carry_out) wcarry ^= 1;
     if (n_work) {
       span_begin(sp_resolve, c->compute);
+      // (r5: the same kernel reading the window where it lies instead of from LDS — it could start on CUs whose LDS the decode's workgroups
+      // hold — made the call 2 - 3 ms longer, CUs kept free of the decode 18 ms: profiles/r05/gz_post_starvation_ab.txt)
       hipLaunchKernelGGL(gz_resolve, dim3((unsigned)n_work), dim3(256), 0, c->compute, reinterpret_cast<const GzChain*>(g.d_pmeta[pp] + offp_chain),
                          reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_we), reinterpret_cast<const uint32_t*>(g.d_pmeta[pp] + offp_wt), d_sym,
                          d_win, d_out, reinterpret_cast<uint32_t*>(g.crc.p));

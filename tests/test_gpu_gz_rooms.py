@@ -268,12 +268,15 @@ def test_configs3_ten_gb_member(gpu, scfq, configs3_member):
     cold_s = time.time() - t
     assert r.returncode == 0 and row(r) == want, r.stderr[-3000:]
     assert "on the chain" in r.stderr and "the rest on the host" not in r.stderr and "%d bytes inflated" % plan.bytes in r.stderr, r.stderr[-2000:]
+    # (the fresh process above decodes in 64 KiB segments; a context's later sessions — these: the module's earlier tests have used it —
+    # take 128 KiB ones for a file of this size, the first of them growing the buffers: scfq_gzdev.hpp "wide_segments")
     walls = []
-    for _ in range(2):
+    for _ in range(3):
         t = time.time()
         c = scfq.count_file(str(f))
         walls.append(time.time() - t)
         assert (c.reads, c.gc_bases, c.n_bases, c.bases) == want
+    walls = [walls[0], min(walls[1:])]
     r = subprocess.run([SC, "fq-count", "--stats", str(f)], capture_output=True, text=True, env=dict(os.environ, SCFQ_GZ_DEVICE="0"), timeout=900)
     assert r.returncode == 0 and row(r) == want, r.stderr[-3000:]
     st = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{")][-1]
