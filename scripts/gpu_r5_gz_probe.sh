@@ -11,7 +11,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 GZ=/tmp/r5_gz.fq.gz
-python3 scripts/write_pigz_member.py $N $GZ > $OUT/file.txt 2>&1 || { cat $OUT/file.txt; exit 1; }
+python3 scripts/write_pigz_member.py $N $GZ ${WRITE_FLAGS:-} > $OUT/file.txt 2>&1 || { cat $OUT/file.txt; exit 1; }
 cat $OUT/file.txt
 cat > /tmp/r5_count.py <<'PY'
 import sys, time

@@ -30,6 +30,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -187,6 +188,12 @@ struct Ctx {
   bool bgzf_warmed = false;                        // bgzf_inflate's first (empty) launch has set the device's scratch up
   hipEvent_t ev_piece[2] = {nullptr, nullptr};     // pieces of compressed bytes crossing the pinned ring (device inflate paths)
   unsigned piece_it = 0;
+  // ... or written by the host's threads into one of two FINE-GRAINED device buffers and moved on by a device-to-device copy (copy_through_ring)
+  uint8_t* fg_stage[2] = {nullptr, nullptr};
+  uint64_t fg_cap = 0;
+  hipEvent_t ev_fg[2] = {nullptr, nullptr};
+  unsigned fg_it = 0;
+  bool fg_refused = false;
   uint8_t* d_inf[2] = {nullptr, nullptr};      // inflated chunks (kStagePad + inf_cap each)
   uint32_t* d_dstatus = nullptr;
   uint64_t comp_cap = 0, inf_cap = 0;
@@ -711,6 +718,34 @@ int fold_device_partials(const scfq_opts& o, int nd, const std::vector<scfq_part
 // of them reached pinned memory — and the ring is 2 x 16 MiB, not two buffers of the size of a chunk (pinning memory costs
 // 160 ms per GB: 170 of the 310 ms of a cold `sc fq-count` over a 2 GB BGZF file went into two pinned buffers of 0.5 GB).
 int copy_through_ring(Ctx* c, uint8_t* dst_device, const FileBytes& src, uint64_t src_off, uint64_t n) {
+  // (r5) Chunks of 8 MiB and more do not go through the pinned ring at all: the host's threads pread them into one of two 64 MiB buffers of
+  // fine-grained device memory (mapped into the process: posted writes over PCIe, 43 GB/s from 8 threads on, one pass over host memory),
+  // and a device-to-device copy moves a piece to where the kernels read it — the device gzip path's feed (scfq_gzdev.hpp).  Through the
+  // ring's 16 MiB halves the same threads reach 17 GB/s (profiles/r05/h2d_rate.txt), and the copy engine was idle for three quarters of a
+  // warm BGZF call (profiles/r05/bgzf_timeline.txt).  SCFQ_BGZF_HOST_WRITES=0: the ring.
+  static const bool host_writes = env_int("SCFQ_BGZF_HOST_WRITES", 1) != 0;
+  if (host_writes && n >= (8ull << 20) && !c->fg_refused) {
+    if (!c->fg_stage[0]) {
+      const uint64_t bytes = 64ull << 20;
+      for (int b = 0; b < 2 && !c->fg_refused; ++b)
+        if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->fg_stage[b]), bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); c->fg_stage[b] = nullptr; c->fg_refused = true; }
+      if (c->fg_refused) { for (int b = 0; b < 2; ++b) { if (c->fg_stage[b]) (void)hipFree(c->fg_stage[b]); c->fg_stage[b] = nullptr; } }
+      else { c->fg_cap = bytes; note_dev_bytes((int64_t)(2 * bytes)); }
+    }
+    if (c->fg_stage[0]) {
+      for (int b = 0; b < 2; ++b) if (!c->ev_fg[b]) HIPCHK(hipEventCreateWithFlags(&c->ev_fg[b], hipEventDisableTiming));
+      for (uint64_t o = 0; o < n; o += c->fg_cap, ++c->fg_it) {
+        const int sb = (int)(c->fg_it & 1);
+        const uint64_t len = std::min(c->fg_cap, n - o);
+        if (c->fg_it >= 2) HIPCHK(hipEventSynchronize(c->ev_fg[sb]));      // the device-to-device copy of the piece before last has read this buffer
+        copy_file_bytes(src, src_off + o, c->fg_stage[sb], len, true);
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        HIPCHK(hipMemcpyAsync(dst_device + o, c->fg_stage[sb], (size_t)len, hipMemcpyDeviceToDevice, c->copy));
+        HIPCHK(hipEventRecord(c->ev_fg[sb], c->copy));
+      }
+      return SCFQ_OK;
+    }
+  }
   int rc = ensure_staging(c, c->stage_cap ? c->stage_cap : (16ull << 20), true);
   if (rc) return rc;
   const uint64_t piece = std::min<uint64_t>(c->stage_cap, 64ull << 20);
@@ -838,15 +873,30 @@ int ensure_bgzf_first(Ctx* c) {
   return SCFQ_OK;
 }
 
+// One wave inflates one member and a member is slow on its own (a serial bit stream): the kernel needs thousands of
+// members per launch to fill 256 CUs, so the device path works in large inflated chunks (SCFQ_BGZF_DEVICE_CHUNK_MB) whatever
+// the staging chunk of the host path is; compressed chunks are a third to a quarter of that.
+// (r5: 640 MiB — two rounds of the kernel's 5120 wave slots — instead of 1 GiB: a launch of one round runs at 120 GB/s, of two at 149,
+// of three at 179, but the call ends one launch after the last byte arrived: 2 GB file 25 -> 22 ms warm, 6 GB the same either way)
+// (scfq_dinflate::Block keeps 32-bit offsets into the chunk: the knob is clamped so that a chunk stays below 4 GiB)
+inline void bgzf_wanted_caps(uint64_t fsize, uint64_t* want_inf, uint64_t* want_comp) {
+  static const uint64_t max_inf = (uint64_t)std::min(2048, std::max(64, env_int("SCFQ_BGZF_DEVICE_CHUNK_MB", 640))) << 20;
+  *want_inf = std::min<uint64_t>(max_inf, std::max<uint64_t>(64ull << 20, (fsize * 5 + 4095) & ~4095ull));
+  *want_comp = std::min<uint64_t>(*want_inf / 2, std::max<uint64_t>(32ull << 20, (fsize + 4095) & ~4095ull));
+}
+// the caps the big buffers WILL have for this file once ensure_bgzf_device_buffers has run (the member walk runs ahead of it)
+inline void bgzf_caps_for(const Ctx* c, uint64_t fsize, uint64_t* inf, uint64_t* comp) {
+  uint64_t want_inf = 0, want_comp = 0;
+  bgzf_wanted_caps(fsize, &want_inf, &want_comp);
+  const bool grow = c->comp_cap < want_comp || c->inf_cap < want_inf;
+  *inf = grow ? want_inf : c->inf_cap;
+  *comp = grow ? want_comp : c->comp_cap;
+}
+
 // buffers of the device-inflate path; kFallbackToHost when they cannot be had (nothing queued yet)
 int ensure_bgzf_device_buffers(Ctx* c, uint64_t fsize, bool on_helper = false) {
-  // One wave inflates one member and a member is slow on its own (a serial bit stream): the kernel needs thousands of
-  // members per launch to fill 256 CUs, so the device path works in large inflated chunks (up to 1 GiB, i.e. ~16 K
-  // members) whatever the staging chunk of the host path is; compressed chunks are a third to a quarter of that.
-  // (scfq_dinflate::Block keeps 32-bit offsets into the chunk: the knob is clamped so that a chunk stays below 4 GiB)
-  static const uint64_t max_inf = (uint64_t)std::min(2048, std::max(64, env_int("SCFQ_BGZF_DEVICE_CHUNK_MB", 1024))) << 20;
-  const uint64_t want_inf = std::min<uint64_t>(max_inf, std::max<uint64_t>(64ull << 20, (fsize * 5 + 4095) & ~4095ull));
-  const uint64_t want_comp = std::min<uint64_t>(want_inf / 2, std::max<uint64_t>(32ull << 20, (fsize + 4095) & ~4095ull));
+  uint64_t want_inf = 0, want_comp = 0;
+  bgzf_wanted_caps(fsize, &want_inf, &want_comp);
   if (c->comp_cap < want_comp || c->inf_cap < want_inf) {
     // (on the helper thread of ingest_bgzf_device the streams carry the first chunk of the NEW call, which does not touch these
     // buffers; the call before ended with both streams idle)
@@ -921,7 +971,11 @@ inline int bgzf_crc_ready(Ctx* c) {
 
 // first_prev: the byte in front of the first inflated byte (0..255), or -1 when the members start the input (a rank of a sharded
 // BGZF file starts in the middle of the inflated stream: scfq_count_file_sharded)
-int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1, int fd = -1, uint64_t fd_off = 0) {
+// bytes_left_host (optional): called once when the last compressed byte has left the mapping (the launches behind it still run): the
+// caller's moment to unmap the file — tearing down the page tables the member walk filled costs 8 ms for a 1.5 GB file, which then
+// pass under the last chunk's inflate instead of behind it
+int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flags, uint64_t /*chunk*/, bool timing, int first_prev = -1, int fd = -1, uint64_t fd_off = 0,
+                       const std::function<void()>& bytes_left_host = std::function<void()>()) {
   FileBytes fbytes;
   fbytes.img = img; fbytes.fd = fd; fbytes.fd_off = fd_off;
   // (bgzf_inflate keeps 72 bytes of scratch per lane and the runtime sets the device's scratch up inside the first launch of such
@@ -959,9 +1013,49 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
   uint64_t pos = 0;
   const uint8_t* prev_base = nullptr;
   uint64_t prev_n = 0;
+  double plan_ms = 0, wait_ms = 0, copy_ms = 0;     // (SCFQ_VERBOSE: where the orchestrating thread spent the call)
+  unsigned n_chunks = 0;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+  // (r5) The member walk runs AHEAD on a thread of its own.  It reads two pages of the mapped file per member — a header, a trailer —
+  // and pays a page fault for each: 23 ms for the 92 000 members of a 6 GB file, which the orchestrating thread used to spend between
+  // two chunks' copies with the device idle (profiles/r05/bgzf_timeline.txt).  The plans are the same ones, made in the same order.
+  struct Plan { int64_t used = 0; uint32_t nb = 0; uint64_t ob = 0; std::vector<scfq_dinflate::Block> blocks; };
+  struct Walker {
+    std::mutex mu; std::condition_variable cv; std::deque<Plan> q; bool done = false, stop = false; std::thread th;
+    ~Walker() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+  } walker;
+  {
+    uint64_t big_inf = 0, big_comp = 0;
+    bgzf_caps_for(c, fsize, &big_inf, &big_comp);
+    (void)bgzf_members_per_launch(big_inf);            // (asks the runtime for the kernel's occupancy once, on this thread)
+    const uint64_t first_inf = c->inf_first_cap, first_comp = c->comp_first_cap;
+    walker.th = std::thread([&walker, img, fsize, big_inf, big_comp, first_inf, first_comp] {
+      uint64_t at = 0;
+      for (unsigned it = 0; at < fsize; ++it) {
+        const bool first = it == 0;
+        const uint64_t chunk = first ? first_inf : big_inf, comp_chunk = first ? first_comp : big_comp;
+        const uint32_t members = first ? (uint32_t)(kBgzfFirstInflated >> 16) : bgzf_members_per_launch(chunk, (int)std::min(it, 3u));
+        Plan pl;
+        pl.blocks.resize(std::min<uint64_t>(members, kMaxBlocksPerChunk));
+        pl.used = bgzf_plan(img, fsize, at, chunk, comp_chunk, (uint32_t)pl.blocks.size(), pl.blocks.data(), &pl.nb, &pl.ob);
+        const int64_t used = pl.used;
+        {
+          std::unique_lock<std::mutex> lk(walker.mu);
+          walker.cv.wait(lk, [&] { return walker.stop || walker.q.size() < 4; });
+          if (walker.stop) return;
+          walker.q.push_back(std::move(pl));
+        }
+        walker.cv.notify_all();
+        if (used <= 0) break;
+        at += (uint64_t)used;
+      }
+      { std::lock_guard<std::mutex> lk(walker.mu); walker.done = true; }
+      walker.cv.notify_all();
+    });
+  }
   for (unsigned it = 0; pos < fsize; ++it) {
     const int b = it & 1;
-    if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b]));      // pinned table b is free again
+    { const auto tw = clk::now(); if (it >= 2) HIPCHK(hipEventSynchronize(c->ev_copied[b])); wait_ms += ms_since(tw); }      // pinned table b is free again
     if (it == 1 && alloc.th.joinable()) {
       alloc.th.join();
       if (alloc_rc) {
@@ -980,8 +1074,23 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
     const auto tf = clk::now();
     uint32_t nb = 0;
     uint64_t ob = 0;
-    const uint32_t members = first ? (uint32_t)(kBgzfFirstInflated >> 16) : bgzf_members_per_launch(chunk, (int)std::min(it, 3u));
-    const int64_t used = bgzf_plan(img, fsize, pos, chunk, comp_chunk, members, c->h_blk[b], &nb, &ob);
+    int64_t used = 0;
+    {
+      Plan pl;
+      {
+        std::unique_lock<std::mutex> lk(walker.mu);
+        walker.cv.wait(lk, [&] { return !walker.q.empty() || walker.done; });
+        if (walker.q.empty()) break;                   // (the walk ended exactly at the file's end)
+        pl = std::move(walker.q.front());
+        walker.q.pop_front();
+      }
+      walker.cv.notify_all();
+      used = pl.used; nb = pl.nb; ob = pl.ob;
+      if (nb) std::memcpy(c->h_blk[b], pl.blocks.data(), (size_t)nb * sizeof(scfq_dinflate::Block));
+    }
+    (void)chunk; (void)comp_chunk;
+    plan_ms += ms_since(tf);
+    ++n_chunks;
     if (used < 0) {                                    // not a BGZF member, or a truncated one: the host path decides what it is
       HIPCHK(hipStreamSynchronize(c->copy));
       HIPCHK(hipStreamSynchronize(c->compute));
@@ -1005,7 +1114,7 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
       while (c->cp_pool.size() < c->cp_used + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->cp_pool.push_back(e); }
       HIPCHK(hipEventRecord(c->cp_pool[c->cp_used], c->copy));
     }
-    if ((rc = copy_through_ring(c, d_comp, fbytes, pos, (uint64_t)used))) return rc;
+    { const auto tc = clk::now(); if ((rc = copy_through_ring(c, d_comp, fbytes, pos, (uint64_t)used))) return rc; copy_ms += ms_since(tc); }
     fill_ms += std::chrono::duration<double, std::milli>(clk::now() - tf).count();
     HIPCHK(hipMemcpyAsync(c->d_blk[b], c->h_blk[b], nb * sizeof(scfq_dinflate::Block), hipMemcpyHostToDevice, c->copy));
     if (timing) { HIPCHK(hipEventRecord(c->cp_pool[c->cp_used + 1], c->copy)); c->cp_used += 2; }
@@ -1042,7 +1151,15 @@ int ingest_bgzf_device(Ctx* c, const uint8_t* img, uint64_t fsize, uint32_t flag
   }
   uint32_t st = 0;
   HIPCHK(hipMemcpyAsync(c->h_state + kStateWords - 1, c->d_dstatus, sizeof(uint32_t), hipMemcpyDeviceToHost, c->compute));
+  const auto t_drain = clk::now();
+  if (bytes_left_host) {
+    { std::unique_lock<std::mutex> lk(walker.mu); walker.cv.wait(lk, [&] { return walker.done; }); }      // (the walk reads the mapping; it has ended when the last plan was taken)
+    bytes_left_host();
+  }
   HIPCHK(hipStreamSynchronize(c->compute));
+  if (trace_on())
+    std::fprintf(stderr, "scfq bgzf: %u chunk(s), %.2f GB compressed; orchestrating thread: waits for the member walk %.1f ms, bytes to the device %.1f ms, waits for a table %.1f ms, "
+                         "drain behind the last launch %.1f ms; wall %.1f ms\n", n_chunks, (double)pos / 1e9, plan_ms, copy_ms, wait_ms, ms_since(t_drain), ms_since(t_begin));
   std::memcpy(&st, c->h_state + kStateWords - 1, sizeof st);
   if (st) { std::snprintf(g_err, sizeof g_err, "device inflate: error mask 0x%x (2 = corrupt deflate data, 4 = length, 8 = CRC-32)", st); return SCFQ_EGZ; }
   return SCFQ_OK;
@@ -1261,7 +1378,8 @@ static int count_file_partial(const char* path, const scfq_opts* opts, scfq_part
           if (m != MAP_FAILED) {
             // (no purity walk up front: touching every member header of a mapped 1 GB file costs 15 ms of page faults;
             // the chunk planner walks them anyway, under the device's work, and reports what it cannot take)
-            rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing, -1, bfd, 0);
+            rc = ingest_bgzf_device(c, static_cast<const uint8_t*>(m), (uint64_t)bsb.st_size, o.flags, opt_chunk(&o), timing, -1, bfd, 0,
+                                    [&] { munmap(m, (size_t)bsb.st_size); m = MAP_FAILED; });
             on_device = (rc != kFallbackToHost && rc != kNotPureBgzf);
             if (rc == kNotPureBgzf) rc = begin_session(c, true);      // drop what the device path accumulated
             else if (!on_device) rc = SCFQ_OK;
@@ -1993,7 +2111,10 @@ int scfq_shutdown(void) {
       if (c->d_blk[b]) (void)hipFree(c->d_blk[b]);
       if (c->h_blk[b]) (void)hipHostFree(c->h_blk[b]);
       if (c->ev_piece[b]) (void)hipEventDestroy(c->ev_piece[b]);
+      if (c->ev_fg[b]) (void)hipEventDestroy(c->ev_fg[b]);
+      if (c->fg_stage[b]) (void)hipFree(c->fg_stage[b]);
     }
+    note_dev_bytes(-(int64_t)(2 * c->fg_cap));
     if (c->d_dstatus) (void)hipFree(c->d_dstatus);
     if (c->d_comp_first) (void)hipFree(c->d_comp_first);
     if (c->d_inf_first) (void)hipFree(c->d_inf_first);

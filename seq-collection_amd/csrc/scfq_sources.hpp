@@ -48,12 +48,12 @@ struct FileBytes {
   int fd = -1;                       // ... and, when there is one, the file they are mapped from,
   uint64_t fd_off = 0;               // img[0] being the byte at this offset of it
 };
-inline int copy_file_bytes(const FileBytes& fb, uint64_t off, uint8_t* dst, uint64_t len) {
+inline int copy_file_bytes(const FileBytes& fb, uint64_t off, uint8_t* dst, uint64_t len, bool always_pread = false) {
   // (pread for the big pieces of big files only — 128 MiB pieces: 49 ms per 2.43 GB against 80 with memcpy; with the 16 MiB pieces of
   // files up to 1 GiB memcpy out of the mapping is the faster by 3 - 8 %: profiles/r04/copy_variants.jsonl.  SCFQ_COPY_PREAD = 0 / 2:
   // never / always)
   static const int pread_mode = env_int("SCFQ_COPY_PREAD", 1);
-  const bool use_pread = pread_mode == 2 || (pread_mode == 1 && len >= (64ull << 20));
+  const bool use_pread = pread_mode == 2 || (pread_mode == 1 && (always_pread || len >= (64ull << 20)));
   return parallel_pieces(len, [&](uint64_t o, uint64_t l) {
     if (fb.fd >= 0 && use_pread) {
       uint64_t got = 0;
