@@ -110,6 +110,7 @@ struct GzDevBuffers {
   DevBuf crc;                                             // status words, then the tile CRCs of the whole file
   uint8_t* h_crc = nullptr;
   std::vector<void*> retired;                             // buffers replaced by bigger ones during a call: freed when it ends
+  bool copies_warmed = false;                             // the search stream has carried its first copies (a process's first ones cost 17 ms)
   bool decode_warmed = false;                             // the decode kernel's first (empty) launch has set the device's scratch up
   hipStream_t s_search = nullptr, s_gap = nullptr, s_decode[kGzDecodeStreams] = {};
   hipEvent_t ev_copy[kGzMaxComp] = {}, ev_found[kGzMaxComp] = {}, ev_dec[kGzMaxSlots] = {}, ev_post[kGzMaxSlots] = {};
