@@ -169,6 +169,12 @@ def ingest_rows(scfq, member_bytes, bgzf_bytes):
         in_order = [run_sc(path, want) for _ in range(3)]
         colds = sorted(in_order, key=lambda x: x[0])
         cold = colds[1][0]
+        # ... and three more with two seconds in front of each: a process that starts while the driver still reclaims what the one before held
+        # (its runtime initialisation and its allocations wait for that: 50 - 700 ms, box by box) measures that reclaim, not itself
+        spaced = []
+        for _ in range(3):
+            time.sleep(2.0)
+            spaced.append(run_sc(path, want))
 
         def key_marks(wall, st):
             # the stamps that tell a slow RUNTIME from a slow library: when hipGetDevice returned, when the context was up, when the first
@@ -179,12 +185,18 @@ def ingest_rows(scfq, member_bytes, bgzf_bytes):
                     "first_copy_queued_ms": pick("gzip engine: first batch's compressed bytes written to the device", "gzip engine: first batch's compressed bytes queued for the device",
                                                  "BGZF: first chunk's compressed bytes queued for the device"),
                     "first_inflate_kernel_queued_ms": pick("gzip engine: first decode kernel queued", "BGZF: first inflate kernel queued"),
-                    "session_folded_ms": pick("session folded"), "row_computed_ms": pick("sc: row computed")}
+                    "session_folded_ms": pick("session folded"), "row_computed_ms": pick("sc: row computed"),
+                    # which side a slow process was slow on: the scan kernels' device time (HIP events; 0.3 ms per GB when the device is
+                    # itself) and the host's time filling the feed
+                    "scan_kernel_ms": (st or {}).get("scan_kernel_ms"), "host_fill_ms": (st or {}).get("host_fill_ms"), "ingest_wall_ms": (st or {}).get("ingest_wall_ms")}
         rows[name] = {"layout": how, "inflated_bytes": int(data_size), "compressed_bytes": os.path.getsize(path),
                       "cold_process_wall_s": round(cold, 4), "cold_GBps": round(data_size / cold / 1e9, 2),
                       "cold_process_walls_s": {"min": round(colds[0][0], 4), "median": round(colds[1][0], 4), "max": round(colds[2][0], 4),
                                                "what": "three fresh `sc fq-count --stats FILE` processes one after the other; cold_process_wall_s is their median"},
                       "cold_runs_in_order": [key_marks(w, st) for w, st in in_order],
+                      "cold_process_walls_2s_apart_s": {"median": round(sorted(w for w, _ in spaced)[1], 4), "in_order": [round(w, 4) for w, _ in spaced],
+                                                        "runs": [key_marks(w, st) for w, st in spaced],
+                                                        "what": "the same with a pause of 2 s before each process (not cold_process_wall_s: that stays the back-to-back median)"},
                       "cold_stages_ms": {"median_run": stage_row(*colds[1]), "slowest_run": stage_row(*colds[2]),
                                          "what": "[stage, ms since the library was loaded] (include/sc_fqcount_debug.h: scfq_debug_stages)"},
                       "first_call_wall_s": round(walls[0], 4), "warm_wall_s": round(walls[1], 4), "warm_GBps": round(data_size / walls[1] / 1e9, 2),

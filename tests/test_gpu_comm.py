@@ -225,6 +225,9 @@ def test_bench_ingest_object(gpu):
         assert "runtime initialised (hipGetDevice returned)" in marks and "context up" in marks and "session folded" in marks
         w = ing[k]["cold_process_walls_s"]
         assert w["min"] <= w["median"] <= w["max"]
+        # every cold run says which side it was slow on, and three further processes ran 2 s apart
+        assert all(r["scan_kernel_ms"] is not None and r["ingest_wall_ms"] > 0 for r in ing[k]["cold_runs_in_order"])
+        assert len(ing[k]["cold_process_walls_2s_apart_s"]["in_order"]) == 3 and ing[k]["cold_process_walls_2s_apart_s"]["median"] > 0
     ho = ing["gzip_member_host_inflate_overlap"]          # the same member inflated on the host, overlapped with copy + scan
     assert ho["counters_match_generator"] is True and ho["scan_kernel_ms"] < 0.5 * ho["host_fill_ms"]
     assert ing["device_bytes_high_water"] > 0
