@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the device gzip path's event-driven schedule (r5): a few hundred `sc fq-count` processes over gzip files of several shapes (one member,
 many members, trailing garbage; 3 - 40 MB inflated) with the schedule's rings at random settings — sets of symbols 2 .. 6, decode streams 1 .. 3,
-batches of 4 .. 64 segments, segments of 16 .. 64 KiB, the first batch split or not — every row against the oracle's, every run on the device path.
+batches of 4 .. 64 segments, segments of 16 .. 128 KiB, the first batch split or not — every row against the oracle's, every run on the device path.
 usage: gpu_soak_gz_schedule.py [runs] [seed]"""
 import os, random, subprocess, sys, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +37,7 @@ bad = 0
 for i in range(runs):
     path, want = rng.choice(files)
     env = {"SCFQ_GZ_DEVICE_MIN_MB": "0", "SCFQ_VERBOSE": "1", "SCFQ_GZ_DEVICE_SLOTS": str(rng.randint(2, 6)), "SCFQ_GZ_DEVICE_DECODE_STREAMS": str(rng.randint(1, 3)),
-           "SCFQ_GZ_DEVICE_BATCH_SEGMENTS": str(rng.choice((4, 8, 16, 64))), "SCFQ_GZ_DEVICE_SEGMENT_KB": str(rng.choice((16, 32, 64))),
+           "SCFQ_GZ_DEVICE_BATCH_SEGMENTS": str(rng.choice((4, 8, 16, 64))), "SCFQ_GZ_DEVICE_SEGMENT_KB": str(rng.choice((16, 32, 64, 128))),
            "SCFQ_GZ_DEVICE_FIRST_BATCH_DIV": str(rng.choice((1, 4))), "SCFQ_GZ_DEVICE_CHAIN_GROUP": str(rng.choice((3, 5, 64)))}
     r = subprocess.run([SC, "fq-count", path], capture_output=True, text=True, env=dict(os.environ, **env), timeout=120)
     ok = r.returncode == 0 and r.stdout == want and "on the chain" in r.stderr and "the rest on the host" not in r.stderr
