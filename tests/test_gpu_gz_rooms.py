@@ -233,6 +233,27 @@ def test_member_beyond_4_gib(gpu, scfq, tmp_path):
     assert '"input_bytes": %d' % plan.bytes in r.stderr and int(r.stderr.split('"h2d_bytes": ')[1].split(",")[0].rstrip("}")) < plan.bytes // 2, r.stderr[-2000:]
 
 
+def test_wide_segments_on_a_level_1_member(gpu, scfq, tmp_path):
+    """A member of more than 1 GiB of deflate data counted INSIDE a running process: a context's later sessions cut such a file into 128 KiB
+    segments (scfq_gzdev.hpp "wide_segments"; a fresh process keeps 64 KiB) — here 4 GB of the synthetic stream at zlib level 1, whose blocks
+    and matches are not level 6's (the configs[3] member below): three calls (the first may still be this context's first session), every
+    row == the generator's tallies == the row of a fresh process.  src/fq_count.nim:30-45 over gzread's bytes (gzip_stream.nim:16-17)."""
+    plan, info, data = _synth_on_device(scfq, gpu, 20260202, 4e9)
+    want = (plan.records, info.gc_bases, info.n_bases, info.bases)
+    f = tmp_path / "level1.fq.gz"
+    _pigz_like(str(f), data, level=1)
+    del data
+    assert os.path.getsize(f) > (1 << 30)
+    for _ in range(3):
+        c = scfq.count_file(str(f))
+        assert (c.reads, c.gc_bases, c.n_bases, c.bases) == want
+    r = subprocess.run([SC, "fq-count", str(f)], capture_output=True, text=True, env=dict(os.environ, SCFQ_VERBOSE="1"), timeout=600)
+    c = r.stdout.strip().split("\t")
+    assert r.returncode == 0 and (int(c[0]), int(c[2]), int(c[3]), int(c[4])) == want, r.stderr[-2000:]
+    assert "segments of 64 KiB" in r.stderr and "the rest on the host" not in r.stderr, r.stderr[-2000:]
+    os.remove(f)
+
+
 @pytest.fixture(scope="module")
 def configs3_member(gpu, scfq, tmp_path_factory):
     """BASELINE configs[3]'s file, written once per module: 10 GB of the seed-20260101 stream as ONE gzip member (zlib level 6, written the
