@@ -299,6 +299,52 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     if (n_batches >= 3 && first_div > 1 && bstart[1] / first_div >= 64) bstart.insert(bstart.begin() + 1, bstart[1] / first_div);
   }
   const uint32_t nb = (uint32_t)bstart.size() - 1;
+  const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
+  const uint64_t comp_pad = 256;
+  const uint64_t end_bit = stretch_to ? sx->stop_bit : fsize * 8;
+  // geometry of batch k: bytes [byte0, copy_end) of the file are on the device, its territory ends at byte1
+  auto p0_of = [&](uint32_t k) { return bstart[k]; };
+  auto p1_of = [&](uint32_t k) { return bstart[k + 1]; };
+  auto byte0_of = [&](uint32_t k) { return k == 0 ? (stretch_from ? (data0 & ~4095ull) : 0ull) : ((data0 + p0_of(k) * seg_bytes) & ~4095ull); };
+  auto byte1_of = [&](uint32_t k) { return p1_of(k) == n_plan ? lim_byte : data0 + p1_of(k) * seg_bytes; };
+  auto copy_end_of = [&](uint32_t k) { return std::min<uint64_t>(fsize, byte1_of(k) + margin); };
+  const uint64_t batch_comp_max = std::min<uint64_t>(fsize, (uint64_t)std::min<uint64_t>(batch_segs, n_plan) * seg_bytes + margin + 8192 + (stretch_from ? 4096 : 0));
+  // SCFQ_GZ_DEVICE_HOST_WRITES=1 (files of several batches): no pinned ring and no copy engine between the file and the device — the copier's
+  // threads pread a batch's bytes straight into one of two FINE-GRAINED device buffers (mapped into the process: posted writes over PCIe, one
+  // pass over host memory), and a device-to-device copy moves them into the batch's ordinary buffer, which is what the kernels read (read in
+  // place, uncached, the decode is 12 % slower: profiles/r05/gz_host_writes_ab.txt)
+  static const bool host_writes_env = env_int("SCFQ_GZ_DEVICE_HOST_WRITES", 1) != 0;
+  bool host_writes = host_writes_env && nb > 1;
+  if (host_writes) {
+    const uint64_t want = batch_comp_max + comp_pad + 4096;
+    if (g.fg_cap < want) {
+      for (int b = 0; b < 2; ++b) { if (g.fg_stage[b]) { g.retired.push_back(g.fg_stage[b]); g.fg_stage[b] = nullptr; } }
+      note_dev_bytes(-(int64_t)(2 * g.fg_cap));
+      g.fg_cap = 0;
+      const uint64_t bytes = (want + want / 8 + 4095) & ~4095ull;
+      for (int b = 0; b < 2 && host_writes; ++b)
+        if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g.fg_stage[b]), bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); g.fg_stage[b] = nullptr; host_writes = false; }
+      if (host_writes) { g.fg_cap = bytes; note_dev_bytes((int64_t)(2 * bytes)); }
+      else for (int b = 0; b < 2; ++b) { if (g.fg_stage[b]) (void)hipFree(g.fg_stage[b]); g.fg_stage[b] = nullptr; }
+    }
+    for (int b = 0; b < 2 && host_writes; ++b) if (!g.ev_fg[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_fg[b], hipEventDisableTiming));
+  }
+  // (r5) A process's first call spends 25 - 30 ms between here and the copier thread's start — three streams, a dozen allocations — and the
+  // first batch's bytes need nothing of that: a thread reads them into the first staging buffer meanwhile (page cache to device memory,
+  // no runtime call), and the copier, when it gets to batch 0, only waits for it (profiles/r05/cold_prefill_ab.txt).
+  struct Prefill { std::thread th; ~Prefill() { if (th.joinable()) th.join(); } } prefill;
+  static const bool prefill_env = env_int("SCFQ_GZ_DEVICE_PREFILL", 1) != 0;
+  if (host_writes && prefill_env) {
+    const uint64_t pb0 = byte0_of(0), pb1 = copy_end_of(0);
+    uint8_t* const dst = g.fg_stage[0];
+    const FileBytes fb = fbytes;
+    prefill.th = std::thread([fb, pb0, pb1, dst] {
+      for (uint64_t off = pb0; off < pb1; off += (64ull << 20)) copy_file_bytes(fb, off, dst + (off - pb0), std::min<uint64_t>(64ull << 20, pb1 - off));
+      std::memset(dst + (pb1 - pb0), 0, 256);      // (comp_pad)
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+    });
+    trace("gzip engine: the first batch's bytes are being read (staging buffers allocated)");
+  }
   // ---- streams.  A file of ONE batch is a chain — copy, search, decode, walk, windows, bytes, scan — and runs on the context's two
   // streams (copy + search on one, decode and everything behind it on the other): creating a stream costs 10 - 15 ms, and an
   // engine's three were half of what a small file's first call paid.  Files of several batches get the engine's own streams: the
@@ -409,16 +455,6 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // runtime takes the two one after the other anyway: side by side, both were done 40 ms later than either alone)
   static const bool host_writes_early = env_int("SCFQ_GZ_DEVICE_HOST_WRITES", 1) != 0;      // (no ring then: see "SCFQ_GZ_DEVICE_HOST_WRITES" below)
   if (g.h_ring && g.ring_piece < want_piece && !host_writes_early) start_ring_maker();
-  const uint64_t margin = 4ull << 20;                  // a batch's last segment runs on to the end of its block
-  const uint64_t comp_pad = 256;
-  const uint64_t end_bit = stretch_to ? sx->stop_bit : fsize * 8;
-  // geometry of batch k: bytes [byte0, copy_end) of the file are on the device, its territory ends at byte1
-  auto p0_of = [&](uint32_t k) { return bstart[k]; };
-  auto p1_of = [&](uint32_t k) { return bstart[k + 1]; };
-  auto byte0_of = [&](uint32_t k) { return k == 0 ? (stretch_from ? (data0 & ~4095ull) : 0ull) : ((data0 + p0_of(k) * seg_bytes) & ~4095ull); };
-  auto byte1_of = [&](uint32_t k) { return p1_of(k) == n_plan ? lim_byte : data0 + p1_of(k) * seg_bytes; };
-  auto copy_end_of = [&](uint32_t k) { return std::min<uint64_t>(fsize, byte1_of(k) + margin); };
-  const uint64_t batch_comp_max = std::min<uint64_t>(fsize, (uint64_t)std::min<uint64_t>(batch_segs, n_plan) * seg_bytes + margin + 8192 + (stretch_from ? 4096 : 0));
   const uint32_t spare = 64 + batch_segs / 16;         // gap segments of later rounds
   const uint32_t max_seg = batch_segs + spare;
   const uint64_t kSegSlack = 98304;       // (zlib's level-6 blocks inflate to ~60 KB, memLevel 9's to ~130 KB: those overflow now and then and are decoded again)
@@ -444,26 +480,6 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
                  offp_mfirst = offp_gfirst + 4ull * (max_groups + 2), post_meta = offp_mfirst + 4ull * (max_groups + 2) + 64;
   const uint64_t res_crc = 4 * (16 + (comp * kMaxRatio) / kCrcTile + 2ull * n_plan + 4ull * nb + 8192);      // tiles of the whole file + a part per member and batch
   for (uint32_t b = 0; b < std::min(nb, n_comp); ++b) if ((rc = gz_buf(g, g.comp[b], batch_comp_max + comp_pad + 4096))) return rc;
-  // SCFQ_GZ_DEVICE_HOST_WRITES=1 (files of several batches): no pinned ring and no copy engine between the file and the device — the copier's
-  // threads pread a batch's bytes straight into one of two FINE-GRAINED device buffers (mapped into the process: posted writes over PCIe, one
-  // pass over host memory), and a device-to-device copy moves them into the batch's ordinary buffer, which is what the kernels read (read in
-  // place, uncached, the decode is 12 % slower: profiles/r05/gz_host_writes_ab.txt)
-  static const bool host_writes_env = env_int("SCFQ_GZ_DEVICE_HOST_WRITES", 1) != 0;
-  bool host_writes = host_writes_env && nb > 1;
-  if (host_writes) {
-    const uint64_t want = batch_comp_max + comp_pad + 4096;
-    if (g.fg_cap < want) {
-      for (int b = 0; b < 2; ++b) { if (g.fg_stage[b]) { g.retired.push_back(g.fg_stage[b]); g.fg_stage[b] = nullptr; } }
-      note_dev_bytes(-(int64_t)(2 * g.fg_cap));
-      g.fg_cap = 0;
-      const uint64_t bytes = (want + want / 8 + 4095) & ~4095ull;
-      for (int b = 0; b < 2 && host_writes; ++b)
-        if (hipExtMallocWithFlags(reinterpret_cast<void**>(&g.fg_stage[b]), bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); g.fg_stage[b] = nullptr; host_writes = false; }
-      if (host_writes) { g.fg_cap = bytes; note_dev_bytes((int64_t)(2 * bytes)); }
-      else for (int b = 0; b < 2; ++b) { if (g.fg_stage[b]) (void)hipFree(g.fg_stage[b]); g.fg_stage[b] = nullptr; }
-    }
-    for (int b = 0; b < 2 && host_writes; ++b) if (!g.ev_fg[b]) HIPCHK(hipEventCreateWithFlags(&g.ev_fg[b], hipEventDisableTiming));
-  }
   if ((rc = gz_buf(g, g.win, (uint64_t)kGzWindow * max_seg)) || (rc = gz_buf(g, g.crc, res_crc))) return rc;
   trace("gzip engine: compressed-byte, window and CRC buffers allocated");
   {
@@ -487,6 +503,22 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   }
   uint8_t* d_out = nullptr;                            // (set when the first batch's bytes get their room)
   trace("gzip engine: plan made, tables and compressed-byte buffers allocated");
+  static const bool warm_copies = env_int("SCFQ_GZ_DEVICE_WARM_COPIES", 1) != 0;
+  if (warm_copies && !g.copies_warmed && nb > 1) {
+    // (r5) With the host-writes feed no host-to-device copy precedes the first search's table, and a process's FIRST copy of tens of KB in
+    // either direction costs 9 - 10 ms (the runtime brings a copy engine's queue up; a copy of 8 bytes goes another way and costs nothing): the
+    // orchestrating thread spends them here, where it would otherwise wait for the first batch's bytes, instead of between their arrival and
+    // the first search (profiles/r05/cold_first_launches.txt)
+    g.copies_warmed = true;
+    HIPCHK(hipMemcpyAsync(g.d_search[0], g.h_search[0], 8ull * max_seg, hipMemcpyHostToDevice, s_search));
+    HIPCHK(hipMemcpyAsync(g.h_search[0] + off_found, g.d_search[0] + off_found, 8ull * max_seg, hipMemcpyDeviceToHost, s_search));
+    // (... and the first device-to-device copy — the staging buffer's bytes moving on — brings the runtime's copy kernels in: 9 ms, which
+    // fell between the first batch's arrival and its search in two processes of three)
+    if (host_writes && g.win.cap >= 2 * 65536) HIPCHK(hipMemcpyAsync(g.win.p + 65536, g.win.p, 65536, hipMemcpyDeviceToDevice, c->copy));
+    HIPCHK(hipStreamSynchronize(s_search));            // (the first search's table is written into h_search[0] next)
+    if (host_writes) HIPCHK(hipStreamSynchronize(c->copy));
+    trace("gzip engine: the search stream's first copies done");
+  }
   const double alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
   if (verbose) std::fprintf(stderr, "scfq gzdev: plan + tables in %.1f ms: %u batch(es), segments of %llu KiB, %.2f symbols per compressed byte assumed, literal classes the search rules out 0x%02x\n", alloc_ms, nb,
                             (unsigned long long)(seg_bytes >> 10), ratio_est, lit_mask);
@@ -599,8 +631,12 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
       auto t0 = clk::now();
       if (k >= 2) HIPCHK(hipEventSynchronize(g.ev_fg[sb]));          // the device-to-device copy of batch k - 2 has read this buffer
       auto t1 = clk::now();
-      for (uint64_t off = b0; off < b1; off += (64ull << 20)) copy_file_bytes(fbytes, off, g.fg_stage[sb] + (off - b0), std::min<uint64_t>(64ull << 20, b1 - off));
-      std::memset(g.fg_stage[sb] + (b1 - b0), 0, comp_pad);
+      if (k == 0 && prefill.th.joinable()) {
+        prefill.th.join();                               // (batch 0 went into fg_stage[0] while the streams and buffers were being made)
+      } else {
+        for (uint64_t off = b0; off < b1; off += (64ull << 20)) copy_file_bytes(fbytes, off, g.fg_stage[sb] + (off - b0), std::min<uint64_t>(64ull << 20, b1 - off));
+        std::memset(g.fg_stage[sb] + (b1 - b0), 0, comp_pad);
+      }
       std::atomic_thread_fence(std::memory_order_seq_cst);
       auto t2 = clk::now();
       HIPCHK(hipMemcpyAsync(g.comp[cb].p, g.fg_stage[sb], (size_t)(b1 - b0 + comp_pad), hipMemcpyDeviceToDevice, c->copy));
@@ -1275,22 +1311,6 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // decode is through.  Round 4's loop did one search, one decode and one walk per iteration in a fixed order, each stage waiting for
   // its own event: at most two decode kernels were ever queued, and the second only once the first one's predecessor had been walked
   // — the device ran decode kernels one after the other with gaps of 1 - 3 ms (profiles/r04/gz_timeline_after_border_stop.txt).
-  static const bool warm_copies = env_int("SCFQ_GZ_DEVICE_WARM_COPIES", 1) != 0;
-  if (warm_copies && !g.copies_warmed && nb > 1) {
-    // (r5) With the host-writes feed no host-to-device copy precedes the first search's table, and a process's FIRST copy of tens of KB in
-    // either direction costs 9 - 10 ms (the runtime brings a copy engine's queue up; a copy of 8 bytes goes another way and costs nothing): the
-    // orchestrating thread spends them here, where it would otherwise wait for the first batch's bytes, instead of between their arrival and
-    // the first search (profiles/r05/cold_first_launches.txt)
-    g.copies_warmed = true;
-    HIPCHK(hipMemcpyAsync(g.d_search[0], g.h_search[0], 8ull * max_seg, hipMemcpyHostToDevice, s_search));
-    HIPCHK(hipMemcpyAsync(g.h_search[0] + off_found, g.d_search[0] + off_found, 8ull * max_seg, hipMemcpyDeviceToHost, s_search));
-    // (... and the first device-to-device copy — the staging buffer's bytes moving on — brings the runtime's copy kernels in: 9 ms, which
-    // fell between the first batch's arrival and its search in two processes of three)
-    if (host_writes && g.win.cap >= 2 * 65536) HIPCHK(hipMemcpyAsync(g.win.p + 65536, g.win.p, 65536, hipMemcpyDeviceToDevice, c->copy));
-    HIPCHK(hipStreamSynchronize(s_search));            // (the first search's table is written into h_search[0] next)
-    if (host_writes) HIPCHK(hipStreamSynchronize(c->copy));
-    trace("gzip engine: the search stream's first copies done");
-  }
   int fail = SCFQ_OK;
   {
     uint32_t ns = 0, nd = 0, nw = 0;
