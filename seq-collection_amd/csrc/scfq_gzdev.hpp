@@ -315,8 +315,15 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // place, uncached, the decode is 12 % slower: profiles/r05/gz_host_writes_ab.txt)
   static const bool host_writes_env = env_int("SCFQ_GZ_DEVICE_HOST_WRITES", 1) != 0;
   bool host_writes = host_writes_env && nb > 1;
+  // (r5, late) A context's FIRST session stages pieces of 32 MiB, not whole batches: the first write to a page of such a mapping is a fault, and a
+  // process's first two batches took 40 and 18 ms to read instead of 6.5 with 2 x 290 MiB to touch — its session 144 ms instead of 156.  Later
+  // sessions stage a batch at a time (one device-to-device copy, no waits between pieces: a warm call 85 - 86 ms against 88 - 89 with 32 or 64 MiB
+  // pieces): profiles/r05/cold_staging_pieces_ab.txt.  SCFQ_GZ_DEVICE_STAGING_MB = n: pieces of n MiB always; 0: always a batch.
+  static const int staging_mb = env_int("SCFQ_GZ_DEVICE_STAGING_MB", -1);
+  const uint64_t fg_piece = staging_mb > 0 ? ((uint64_t)std::max(8, staging_mb) << 20)
+                          : (staging_mb < 0 && c->n_sessions <= 1) ? (32ull << 20) : ((batch_comp_max + 4095) & ~4095ull);
   if (host_writes) {
-    const uint64_t want = batch_comp_max + comp_pad + 4096;
+    const uint64_t want = fg_piece + comp_pad + 4096;
     if (g.fg_cap < want) {
       for (int b = 0; b < 2; ++b) { if (g.fg_stage[b]) { g.retired.push_back(g.fg_stage[b]); g.fg_stage[b] = nullptr; } }
       note_dev_bytes(-(int64_t)(2 * g.fg_cap));
@@ -334,14 +341,23 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // no runtime call), and the copier, when it gets to batch 0, only waits for it (profiles/r05/cold_prefill_ab.txt).
   struct Prefill { std::thread th; ~Prefill() { if (th.joinable()) th.join(); } } prefill;
   static const bool prefill_env = env_int("SCFQ_GZ_DEVICE_PREFILL", 1) != 0;
+  uint32_t n_prefilled = 0;              // pieces of batch 0 the thread reads: both staging buffers' worth
   if (host_writes && prefill_env) {
     const uint64_t pb0 = byte0_of(0), pb1 = copy_end_of(0);
-    uint8_t* const dst = g.fg_stage[0];
+    n_prefilled = (uint32_t)std::min<uint64_t>(2, (pb1 - pb0 + fg_piece - 1) / fg_piece);
+    uint8_t* const dst0 = g.fg_stage[0];
+    uint8_t* const dst1 = g.fg_stage[1];
     const FileBytes fb = fbytes;
-    prefill.th = std::thread([fb, pb0, pb1, dst] {
-      for (uint64_t off = pb0; off < pb1; off += (64ull << 20)) copy_file_bytes(fb, off, dst + (off - pb0), std::min<uint64_t>(64ull << 20, pb1 - off));
-      std::memset(dst + (pb1 - pb0), 0, 256);      // (comp_pad)
+    const uint32_t np = n_prefilled;
+    prefill.th = std::thread([fb, pb0, pb1, dst0, dst1, np, fg_piece] {
+      for (uint32_t i = 0; i < np; ++i) {
+        const uint64_t off = pb0 + (uint64_t)i * fg_piece, len = std::min<uint64_t>(fg_piece, pb1 - off);
+        uint8_t* const d = i ? dst1 : dst0;
+        copy_file_bytes(fb, off, d, len, true);
+        if (off + len == pb1) std::memset(d + len, 0, 256);      // (comp_pad, behind the batch's last byte)
+      }
       std::atomic_thread_fence(std::memory_order_seq_cst);
+      trace("gzip engine: the first pieces of the first batch are in the staging buffers");
     });
     trace("gzip engine: the first batch's bytes are being read (staging buffers allocated)");
   }
@@ -621,28 +637,33 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
     HIPCHK(hipStreamCreateWithFlags(&s_copy2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_copy2, hipEventDisableTiming));
   }
+  uint32_t fg_it = 0;                                // (the copier thread's: staging pieces written so far in this call)
   auto copy_batch = [&](uint32_t k) -> int {       // (runs on the copier thread)
     const auto tf = clk::now();
     const int cb = (int)(k % n_comp);
     const uint64_t b0 = byte0_of(k), b1 = copy_end_of(k);
     if (verbose) { Span sp; (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b); (void)hipEventRecord(sp.a, c->copy); cp.spans.push_back(sp); }
     if (host_writes) {
-      const int sb = (int)(k & 1u);
-      auto t0 = clk::now();
-      if (k >= 2) HIPCHK(hipEventSynchronize(g.ev_fg[sb]));          // the device-to-device copy of batch k - 2 has read this buffer
-      auto t1 = clk::now();
-      if (k == 0 && prefill.th.joinable()) {
-        prefill.th.join();                               // (batch 0 went into fg_stage[0] while the streams and buffers were being made)
-      } else {
-        for (uint64_t off = b0; off < b1; off += (64ull << 20)) copy_file_bytes(fbytes, off, g.fg_stage[sb] + (off - b0), std::min<uint64_t>(64ull << 20, b1 - off));
-        std::memset(g.fg_stage[sb] + (b1 - b0), 0, comp_pad);
+      for (uint64_t off = b0; off < b1; off += fg_piece, ++fg_it) {
+        const int sb = (int)(fg_it & 1u);
+        const uint64_t len = std::min<uint64_t>(fg_piece, b1 - off);
+        const bool last = off + len == b1;
+        auto t0 = clk::now();
+        if (fg_it >= 2) HIPCHK(hipEventSynchronize(g.ev_fg[sb]));          // the device-to-device copy of the piece before last has read this buffer
+        auto t1 = clk::now();
+        if (k == 0 && fg_it < n_prefilled) {
+          if (prefill.th.joinable()) prefill.th.join();                    // (read while the streams and buffers were being made)
+        } else {
+          copy_file_bytes(fbytes, off, g.fg_stage[sb], len, true);
+          if (last) std::memset(g.fg_stage[sb] + len, 0, comp_pad);
+        }
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        auto t2 = clk::now();
+        HIPCHK(hipMemcpyAsync(g.comp[cb].p + (off - b0), g.fg_stage[sb], (size_t)(len + (last ? comp_pad : 0)), hipMemcpyDeviceToDevice, c->copy));
+        HIPCHK(hipEventRecord(g.ev_fg[sb], c->copy));
+        cp.evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        cp.memcpy_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
       }
-      std::atomic_thread_fence(std::memory_order_seq_cst);
-      auto t2 = clk::now();
-      HIPCHK(hipMemcpyAsync(g.comp[cb].p, g.fg_stage[sb], (size_t)(b1 - b0 + comp_pad), hipMemcpyDeviceToDevice, c->copy));
-      HIPCHK(hipEventRecord(g.ev_fg[sb], c->copy));
-      cp.evsync_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
-      cp.memcpy_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
       if (verbose) (void)hipEventRecord(cp.spans.back().b, c->copy);
       HIPCHK(hipEventRecord(g.ev_copy[cb], c->copy));
       cp.bytes += b1 - b0;
