@@ -726,8 +726,19 @@ int copy_through_ring(Ctx* c, uint8_t* dst_device, const FileBytes& src, uint64_
   // warm BGZF call (profiles/r05/bgzf_timeline.txt).  SCFQ_BGZF_HOST_WRITES=0: the ring.
   static const bool host_writes = env_int("SCFQ_BGZF_HOST_WRITES", 1) != 0;
   if (host_writes && n >= (8ull << 20) && !c->fg_refused) {
+    // (a context's first session: 32 MiB pieces — the first write to a page of such a buffer is a fault, 8 ms per 64 MiB, and a process pays for
+    // every page it touches once: profiles/r05/cold_staging_pieces_ab.txt; later sessions: 64 MiB.  SCFQ_BGZF_STAGING_MB = n: always n MiB)
+    static const int staging_mb = env_int("SCFQ_BGZF_STAGING_MB", 0);
+    const uint64_t want_piece = staging_mb > 0 ? ((uint64_t)std::max(8, staging_mb) << 20) : (c->n_sessions <= 1 ? (32ull << 20) : (64ull << 20));
+    if (c->fg_stage[0] && c->fg_cap < want_piece) {
+      // (a bigger piece than the last session's: the streams are idle between sessions)
+      HIPCHK(hipStreamSynchronize(c->copy));
+      for (int b = 0; b < 2; ++b) { (void)hipFree(c->fg_stage[b]); c->fg_stage[b] = nullptr; }
+      note_dev_bytes(-(int64_t)(2 * c->fg_cap));
+      c->fg_cap = 0;
+    }
     if (!c->fg_stage[0]) {
-      const uint64_t bytes = 64ull << 20;
+      const uint64_t bytes = want_piece;
       for (int b = 0; b < 2 && !c->fg_refused; ++b)
         if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->fg_stage[b]), bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); c->fg_stage[b] = nullptr; c->fg_refused = true; }
       if (c->fg_refused) { for (int b = 0; b < 2; ++b) { if (c->fg_stage[b]) (void)hipFree(c->fg_stage[b]); c->fg_stage[b] = nullptr; } }
