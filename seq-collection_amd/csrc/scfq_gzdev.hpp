@@ -519,22 +519,6 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   }
   uint8_t* d_out = nullptr;                            // (set when the first batch's bytes get their room)
   trace("gzip engine: plan made, tables and compressed-byte buffers allocated");
-  static const bool warm_copies = env_int("SCFQ_GZ_DEVICE_WARM_COPIES", 1) != 0;
-  if (warm_copies && !g.copies_warmed && nb > 1) {
-    // (r5) With the host-writes feed no host-to-device copy precedes the first search's table, and a process's FIRST copy of tens of KB in
-    // either direction costs 9 - 10 ms (the runtime brings a copy engine's queue up; a copy of 8 bytes goes another way and costs nothing): the
-    // orchestrating thread spends them here, where it would otherwise wait for the first batch's bytes, instead of between their arrival and
-    // the first search (profiles/r05/cold_first_launches.txt)
-    g.copies_warmed = true;
-    HIPCHK(hipMemcpyAsync(g.d_search[0], g.h_search[0], 8ull * max_seg, hipMemcpyHostToDevice, s_search));
-    HIPCHK(hipMemcpyAsync(g.h_search[0] + off_found, g.d_search[0] + off_found, 8ull * max_seg, hipMemcpyDeviceToHost, s_search));
-    // (... and the first device-to-device copy — the staging buffer's bytes moving on — brings the runtime's copy kernels in: 9 ms, which
-    // fell between the first batch's arrival and its search in two processes of three)
-    if (host_writes && g.win.cap >= 2 * 65536) HIPCHK(hipMemcpyAsync(g.win.p + 65536, g.win.p, 65536, hipMemcpyDeviceToDevice, c->copy));
-    HIPCHK(hipStreamSynchronize(s_search));            // (the first search's table is written into h_search[0] next)
-    if (host_writes) HIPCHK(hipStreamSynchronize(c->copy));
-    trace("gzip engine: the search stream's first copies done");
-  }
   const double alloc_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
   if (verbose) std::fprintf(stderr, "scfq gzdev: plan + tables in %.1f ms: %u batch(es), segments of %llu KiB, %.2f symbols per compressed byte assumed, literal classes the search rules out 0x%02x\n", alloc_ms, nb,
                             (unsigned long long)(seg_bytes >> 10), ratio_est, lit_mask);
@@ -1332,6 +1316,22 @@ int ingest_gz_device_batches(Ctx* c, GzDevBuffers& g, const uint8_t* img, uint64
   // decode is through.  Round 4's loop did one search, one decode and one walk per iteration in a fixed order, each stage waiting for
   // its own event: at most two decode kernels were ever queued, and the second only once the first one's predecessor had been walked
   // — the device ran decode kernels one after the other with gaps of 1 - 3 ms (profiles/r04/gz_timeline_after_border_stop.txt).
+  static const bool warm_copies = env_int("SCFQ_GZ_DEVICE_WARM_COPIES", 1) != 0;
+  if (warm_copies && !g.copies_warmed && nb > 1) {
+    // (r5) With the host-writes feed no host-to-device copy precedes the first search's table, and a process's FIRST copy of tens of KB in
+    // either direction costs 9 - 10 ms (the runtime brings a copy engine's queue up; a copy of 8 bytes goes another way and costs nothing): the
+    // orchestrating thread spends them here, where it would otherwise wait for the first batch's bytes, instead of between their arrival and
+    // the first search (profiles/r05/cold_first_launches.txt)
+    g.copies_warmed = true;
+    HIPCHK(hipMemcpyAsync(g.d_search[0], g.h_search[0], 8ull * max_seg, hipMemcpyHostToDevice, s_search));
+    HIPCHK(hipMemcpyAsync(g.h_search[0] + off_found, g.d_search[0] + off_found, 8ull * max_seg, hipMemcpyDeviceToHost, s_search));
+    // (... and the first device-to-device copy — the staging buffer's bytes moving on — brings the runtime's copy kernels in: 9 ms, which
+    // fell between the first batch's arrival and its search in two processes of three)
+    if (host_writes && g.win.cap >= 2 * 65536) HIPCHK(hipMemcpyAsync(g.win.p + 65536, g.win.p, 65536, hipMemcpyDeviceToDevice, c->copy));
+    HIPCHK(hipStreamSynchronize(s_search));            // (the first search's table is written into h_search[0] next)
+    if (host_writes) HIPCHK(hipStreamSynchronize(c->copy));
+    trace("gzip engine: the search stream's first copies done");
+  }
   int fail = SCFQ_OK;
   {
     uint32_t ns = 0, nd = 0, nw = 0;
